@@ -1,0 +1,168 @@
+/*
+ * xmodal.h -- C ABI of libxmodal_hip.so, the MI355X (gfx950) replacement for the
+ * MatConvNet / mcnExtraLayers operator MEX files that albanie/mcnCrossModalEmotions
+ * drives on its distillation hot path.
+ *
+ * One entry point per MATLAB operator direction.  A MEX gateway (the mex/ sources,
+ * INTEGRATION.md) or the ctypes mirror (mcncrossmodalemotions_amd/vl.py) maps the
+ * MATLAB call 1:1 onto these.  The reference reaches them through dagnn.DagNN.eval:
+ *     emoVoxCeleb/fetch_emovoxceleb_imdb.m:129   (teacher forward, test mode)
+ *     external/compute_audio_feats.m:126         (student forward)
+ *     emoVoxCeleb/run_distillation.m:170-182     (cnn_train_dag: fwd + bwd + update)
+ *
+ * Conventions
+ *   - every tensor is MATLAB `single`, H x W x C x N, column-major (H fastest),
+ *     densely packed, resident in device (HBM) memory; the caller owns all buffers,
+ *     inputs are never written (MATLAB copy-on-write safe), outputs never alias inputs;
+ *   - filters are FH x FW x FC x K (groups = C / FC), biases K x 1 (NULL = none);
+ *   - pad = [top bottom left right], stride = [sy sx], dilate = [dy dx];
+ *   - `stream` is a hipStream_t (NULL = the null stream, MatConvNet's behaviour);
+ *     calls are asynchronous with respect to the host, ordered on that stream;
+ *   - return value 0 = ok, otherwise an XM_E* code; xm_last_error() gives the text.
+ *     Nothing throws, aborts or leaks across this boundary (a MEX gateway turns a
+ *     non-zero code into mexErrMsgIdAndTxt).
+ *   - re-entrant per device, not thread-safe (MATLAB calls MEX from one thread).
+ */
+#ifndef XMODAL_H
+#define XMODAL_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  XM_OK = 0,
+  XM_EINVAL = 1,   /* bad shape / option combination (MATLAB side: "XM:invalidArgument") */
+  XM_ENOMEM = 2,   /* workspace allocation failed */
+  XM_EHIP = 3,     /* HIP runtime error (text has hipGetErrorString) */
+  XM_ETOOBIG = 4,  /* a tensor has >= 2^31 elements */
+  XM_ENOTSUP = 5   /* valid MatConvNet call that this build does not cover */
+};
+
+enum { XM_POOL_MAX = 0, XM_POOL_AVG = 1 };
+enum { XM_LOSS_SOFTMAXLOG = 0, XM_LOSS_CLASSERROR = 1 };
+enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
+
+/* fused-epilogue flags for xm_nnconv_forward_fused / xm_nnbnorm_forward_fused */
+enum { XM_FUSE_RELU = 1 };
+
+int xm_version(void);
+const char *xm_last_error(void);
+/* optional: pre-size the internal scratch (split-K partials, filter transposes, tap tables). */
+int xm_workspace_reserve(size_t bytes);
+size_t xm_workspace_bytes(void);
+/* output extent of conv / pool along one axis: floor((in + pa + pb - ((f-1)*d+1)) / s) + 1 */
+int xm_out_size(int in, int pad_a, int pad_b, int f, int dilate, int stride);
+
+/* ---- vl_nnconv  (MatConvNet matlab/vl_nnconv.m; dagnn.Conv at emoVoxZoo.m:118) -------------
+ * Y = vl_nnconv(X, F, B, 'stride', [sy sx], 'pad', [t b l r], 'dilate', [dy dx]) */
+int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                      int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                      int pl, int pr, int dy, int dx, void *stream);
+/* Extension (not a MatConvNet signature): same convolution with a fused epilogue
+ *   y = act( (conv + b) .* scale_k + shift_k + residual ),  scale/shift/residual may be NULL.
+ * Used to fold test-mode vl_nnbnorm, dagnn.Sum and vl_nnrelu of the frozen teacher into the
+ * producing convolution (fetch_emovoxceleb_imdb.m:107 sets dag.mode = 'test'). */
+int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const float *f, int FH,
+                            int FW, int FC, int K, const float *b, float *y, int sy, int sx,
+                            int pt, int pb, int pl, int pr, int dy, int dx, const float *scale,
+                            const float *shift, const float *residual, int flags, void *stream);
+/* [DX, DF, DB] = vl_nnconv(X, F, B, DZDY, ...); dx_out / df_out / db_out may be NULL
+ * (= 'NoDerData' / 'NoDerFilters' / 'NoDerBiases'). */
+int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                       int FC, int K, const float *dzdy, float *dx_out, float *df_out,
+                       float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
+                       int dx, void *stream);
+
+/* ---- vl_nnpool  (matlab/vl_nnpool.m; pool6 resized at emoVoxZoo.m:256-269) ------------------
+ * Y = vl_nnpool(X, [ph pw], 'stride', .., 'pad', .., 'method', 'max'|'avg') */
+int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                      int pt, int pb, int pl, int pr, int method, float *y, void *stream);
+/* DX = vl_nnpool(X, [ph pw], DZDY, ...) */
+int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                       int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
+                       void *stream);
+
+/* ---- vl_nnbnorm  (matlab/vl_nnbnorm.m) -----------------------------------------------------
+ * Y = vl_nnbnorm(X, G, B, 'epsilon', e [, 'moments', M]); M is C x 2 = [mean, sqrt(var+e)].
+ * moments_in == NULL: train mode (batch moments, biased variance); they are written to
+ * moments_out when it is non-NULL.  moments_in != NULL: test mode. */
+int xm_nnbnorm_forward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                       float epsilon, const float *moments_in, float *y, float *moments_out,
+                       void *stream);
+/* Extension: vl_nnbnorm followed by vl_nnrelu in one pass (flags = XM_FUSE_RELU). */
+int xm_nnbnorm_forward_fused(const float *x, int H, int W, int C, int N, const float *g,
+                             const float *b, float epsilon, const float *moments_in, float *y,
+                             float *moments_out, int flags, void *stream);
+/* [DX, DG, DB, MOMENTS] = vl_nnbnorm(X, G, B, DZDY, ...) */
+int xm_nnbnorm_backward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                        const float *dzdy, float epsilon, const float *moments_in, float *dx_out,
+                        float *dg_out, float *db_out, float *moments_out, void *stream);
+/* Extension: backward through relu(bnorm(x)): `y` is the fused forward output; dzdy is masked
+ * by (y > 0) before the vl_nnbnorm backward formulas. */
+int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int C, int N,
+                              const float *g, const float *b, const float *dzdy, float epsilon,
+                              const float *moments_in, float *dx_out, float *dg_out, float *db_out,
+                              float *moments_out, int flags, void *stream);
+
+/* ---- elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, mcnExtraLayers Scale/Axpy ------------
+ * dzdy == NULL: forward; otherwise y receives DZDX. */
+int xm_nnrelu(const float *x, size_t n, float leak, const float *dzdy, float *y, void *stream);
+int xm_nnsigmoid(const float *x, size_t n, const float *dzdy, float *y, void *stream);
+/* y = a + b, optional fused relu (flags = XM_FUSE_RELU) -- dagnn.Sum (+ vl_nnrelu) */
+int xm_sum2(const float *a, const float *b, size_t n, int flags, float *y, void *stream);
+/* SE excite: y(:,:,c,n) = a(c,n) * x(:,:,c,n) [+ r(:,:,c,n)] [relu]; a is 1 x 1 x C x N */
+int xm_scale_axpy(const float *x, int HW, int CN, const float *a, const float *r, int flags,
+                  float *y, void *stream);
+/* backward of y = a .* x: dx = a .* dzdy (NULL to skip), da(c,n) = sum_hw dzdy .* x */
+int xm_scale_backward(const float *x, int HW, int CN, const float *a, const float *dzdy,
+                      float *dx_out, float *da_out, void *stream);
+
+/* ---- losses --------------------------------------------------------------------------------
+ * vl_nnsoftmaxt(X, 'temperature', T): softmax(X / T) along dim 3; X is HW x C x N */
+int xm_nnsoftmaxt(const float *x, int HW, int C, int N, float temperature, float *y, void *stream);
+/* vl_nnsoftmaxceloss(X, P [, DZDY], 'temperature', T, 'logitTargets', tf, 'instanceWeights', w)
+ * (dagnn.SoftmaxCELoss at emoVoxZoo.m:152, ferPlusZoo.m:244).  X, P: 1 x 1 x C x N, C <= 64.
+ * forward (dzdy == NULL): y[0] = sum_n w_n * CE(softmax(P/T) or P, softmax(X/T));
+ * backward: y (C*N floats) = dzdy[0] * w_n * (softmax(X/T) * sum(p) - p) / T.
+ * dzdy is a DEVICE pointer to one float. */
+int xm_nnsoftmaxceloss(const float *x, const float *p, int C, int N, float temperature,
+                       int logit_targets, const float *instance_weights, const float *dzdy,
+                       float *y, void *stream);
+/* vl_nnloss(X, c [, DZDY], 'loss', 'softmaxlog'|'classerror'); labels are 1-based floats */
+int xm_nnloss(const float *x, const float *labels, int C, int N, int loss, const float *dzdy,
+              float *y, void *stream);
+
+/* ---- cnn_train_dag accumulateGradients + ParameterServer (run_distillation.m:88,170-182) ----
+ * trainMethod 'gradient':  m <- momentum*m - (wd*w + der/batch);  w <- w + lr*m */
+int xm_sgd_update(float *w, float *m, const float *der, size_t n, float lr, float momentum,
+                  float weight_decay, float batch, void *stream);
+/* trainMethod 'average' (BN moments):  w <- (1-lr)*w + lr*der/nworkers */
+int xm_average_update(float *w, const float *der, size_t n, float lr, float nworkers,
+                      void *stream);
+/* ParameterServer.{start,push,sync,pull}: sum of `buf` over all workers, in place, via RCCL.
+ * xm_comm_init takes the 128-byte ncclUniqueId produced by xm_comm_unique_id on rank 0 and
+ * distributed by the host (MATLAB labBroadcast / torch.distributed broadcast). */
+int xm_comm_unique_id(void *id128);
+int xm_comm_init(const void *id128, int rank, int world);
+int xm_allreduce_sum_f32(float *buf, size_t n, void *stream);
+int xm_comm_destroy(void);
+
+/* ---- batch-provider arithmetic (device side of getBatchEmoVoxCeleb / getImageBatch) ---------
+ * getBatchEmoVoxCeleb.m:164-169: per-frequency-row mean / unbiased std over time; H x W x 1 x N */
+int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream);
+/* getBatchEmoVoxCeleb.m:145-158,179-188: for sample n aggregate frame logits (F_total x E,
+ * column-major, all wavs concatenated) over rows [first[n], last[n]] (1-based, inclusive)
+ * -> out 1 x 1 x E x N and maxLabel (1-based argmax, getBatchEmoVoxCeleb.m:32) */
+int xm_aggregate_logits(const float *frame_logits, int F_total, int E, const int *first,
+                        const int *last, int N, int agg, float *out, float *max_label,
+                        void *stream);
+/* fetch_emovoxceleb_imdb.m:176-193: rgb2gray -> replicate x3 -> minus averageImage(c).
+ * avg3 is a HOST pointer to the three per-channel means (meta.normalization.averageImage). */
+int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMODAL_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libxmodal_hip.so (the C ABI in include/xmodal.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing
+an operator raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libxmodal_hip.so")
+
+c_fp = C.c_void_p  # device pointers travel as raw addresses
+_i, _f, _sz, _vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> argtypes; every function returns int (status) unless listed in _RESTYPES
+SIGNATURES = {
+    "xm_version": [],
+    "xm_last_error": [],
+    "xm_workspace_reserve": [_sz],
+    "xm_workspace_bytes": [],
+    "xm_out_size": [_i] * 6,
+    "xm_nnconv_forward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 + [_vp],
+    "xm_nnconv_forward_fused": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 +
+                               [c_fp, c_fp, c_fp, _i, _vp],
+    "xm_nnconv_backward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +
+                          [_i] * 8 + [_vp],
+    "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
+    "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
+    "xm_nnbnorm_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _vp],
+    "xm_nnbnorm_forward_fused": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _i, _vp],
+    "xm_nnbnorm_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                               _vp],
+    "xm_nnbnorm_backward_fused": [c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp,
+                                                             c_fp, c_fp, _i, _vp],
+    "xm_nnrelu": [c_fp, _sz, _f, c_fp, c_fp, _vp],
+    "xm_nnsigmoid": [c_fp, _sz, c_fp, c_fp, _vp],
+    "xm_sum2": [c_fp, c_fp, _sz, _i, c_fp, _vp],
+    "xm_scale_axpy": [c_fp, _i, _i, c_fp, c_fp, _i, c_fp, _vp],
+    "xm_scale_backward": [c_fp, _i, _i, c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_nnsoftmaxt": [c_fp, _i, _i, _i, _f, c_fp, _vp],
+    "xm_nnsoftmaxceloss": [c_fp, c_fp, _i, _i, _f, _i, c_fp, c_fp, c_fp, _vp],
+    "xm_nnloss": [c_fp, c_fp, _i, _i, _i, c_fp, c_fp, _vp],
+    "xm_sgd_update": [c_fp, c_fp, c_fp, _sz, _f, _f, _f, _f, _vp],
+    "xm_average_update": [c_fp, c_fp, _sz, _f, _f, _vp],
+    "xm_comm_unique_id": [_vp],
+    "xm_comm_init": [_vp, _i, _i],
+    "xm_allreduce_sum_f32": [c_fp, _sz, _vp],
+    "xm_comm_destroy": [],
+    "xm_spec_rownorm": [c_fp, _i, _i, _i, c_fp, _vp],
+    "xm_aggregate_logits": [c_fp, _i, _i, c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],
+    "xm_normalize_face": [c_fp, _i, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
+}
+_RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
+# test hooks (not part of include/xmodal.h)
+_DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": []}
+
+_lib = None
+
+
+class XmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("xmodal error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """dlopen the HIP library; raises if it is absent (no CPU fallback, by design)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -m mcncrossmodalemotions_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % SO_PATH)
+    lib = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    for name, args in list(SIGNATURES.items()) + list(_DEBUG.items()):
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise XmError(rc, load().xm_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,80 @@
+// Process-wide context of libxmodal_hip.so: last-error text, stream-ordered scratch buffer and a
+// content-addressed cache of small read-only device tables (convolution tap tables).
+// Mirrors MatConvNet's persistent per-process context (workspace + handles), SURVEY.md 8b.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "xm_common.h"
+
+namespace xm {
+
+static char g_err[512] = "";
+char *err_buf() { return g_err; }
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static void *g_ws = nullptr;
+static size_t g_ws_cap = 0;
+
+int ws_get(size_t bytes, void **ptr) {
+  if (bytes > g_ws_cap) {
+    // grow geometrically; a grow happens only while shapes are first seen (warm-up)
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    if (g_ws) {
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) return fail(XM_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(e));
+      (void)hipFree(g_ws);
+      g_ws = nullptr;
+      g_ws_cap = 0;
+    }
+    hipError_t e = hipMalloc(&g_ws, want);
+    if (e != hipSuccess) {
+      g_ws = nullptr;
+      return fail(XM_ENOMEM, "workspace hipMalloc(%zu) -> %s", want, hipGetErrorString(e));
+    }
+    g_ws_cap = want;
+  }
+  *ptr = g_ws;
+  return XM_OK;
+}
+
+static std::map<std::string, void *> g_tables;
+
+const void *cached_device_table(const void *host, size_t bytes) {
+  std::string key((const char *)host, bytes);
+  auto it = g_tables.find(key);
+  if (it != g_tables.end()) return it->second;
+  void *d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
+  g_tables.emplace(std::move(key), d);
+  return d;
+}
+
+}  // namespace xm
+
+extern "C" {
+
+int xm_version(void) { return 100; }
+const char *xm_last_error(void) { return xm::err_buf(); }
+
+int xm_workspace_reserve(size_t bytes) {
+  void *p;
+  return xm::ws_get(bytes, &p);
+}
+size_t xm_workspace_bytes(void) { return xm::g_ws_cap; }
+
+int xm_out_size(int in, int pad_a, int pad_b, int f, int dilate, int stride) {
+  return xm::out_size(in, pad_a, pad_b, f, dilate, stride);
+}
+}

@@ -1,0 +1,443 @@
+// Elementwise operators, losses, optimiser update and the batch-provider arithmetic on gfx950.
+// vl_nnrelu / vl_nnsigmoid / dagnn.Sum / mcnExtraLayers Scale+Axpy, vl_nnsoftmaxt,
+// vl_nnsoftmaxceloss (emoVoxZoo.m:152), vl_nnloss (emoVoxZoo.m:149,160), the SGD-momentum step of
+// cnn_train_dag (run_distillation.m:170-182) and the device side of getBatchEmoVoxCeleb /
+// getImageBatch.  All HBM- or latency-bound; float4 grid-stride loops, no atomics.
+#include "xm_common.h"
+
+namespace xm {
+
+static unsigned ew_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+enum { OP_RELU_F, OP_RELU_B, OP_SIG_F, OP_SIG_B, OP_SUM, OP_SUM_RELU };
+
+template <int OP>
+__device__ __forceinline__ float ew_op(float a, float b, float leak) {
+  if (OP == OP_RELU_F) return a > 0.f ? a : leak * a;
+  if (OP == OP_RELU_B) return a > 0.f ? b : leak * b;  // a = x, b = dzdy
+  if (OP == OP_SIG_F) return 1.f / (1.f + expf(-a));
+  if (OP == OP_SIG_B) {
+    float s = 1.f / (1.f + expf(-a));
+    return b * s * (1.f - s);
+  }
+  if (OP == OP_SUM) return a + b;
+  return fmaxf(a + b, 0.f);
+}
+
+template <int OP, bool BINARY>
+__global__ void __launch_bounds__(256)
+ew_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, size_t n,
+          float leak, int vec) {
+  size_t stride = (size_t)gridDim.x * 256;
+  size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (vec) {
+    size_t n4 = n >> 2;
+    for (size_t i = i0; i < n4; i += stride) {
+      float4 av = reinterpret_cast<const float4 *>(a)[i];
+      float4 bv = BINARY ? reinterpret_cast<const float4 *>(b)[i] : make_float4(0, 0, 0, 0);
+      float4 o;
+      o.x = ew_op<OP>(av.x, bv.x, leak);
+      o.y = ew_op<OP>(av.y, bv.y, leak);
+      o.z = ew_op<OP>(av.z, bv.z, leak);
+      o.w = ew_op<OP>(av.w, bv.w, leak);
+      reinterpret_cast<float4 *>(y)[i] = o;
+    }
+    for (size_t i = (n4 << 2) + i0; i < n; i += stride)
+      y[i] = ew_op<OP>(a[i], BINARY ? b[i] : 0.f, leak);
+  } else {
+    for (size_t i = i0; i < n; i += stride) y[i] = ew_op<OP>(a[i], BINARY ? b[i] : 0.f, leak);
+  }
+}
+
+template <int OP, bool BINARY>
+static int ew_launch(const float *a, const float *b, float *y, size_t n, float leak, hipStream_t st) {
+  if (n == 0) return XM_OK;
+  if (!a || !y || (BINARY && !b)) return fail(XM_EINVAL, "elementwise op: NULL tensor");
+  int vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL((ew_kernel<OP, BINARY>), dim3(ew_grid(vec ? n / 4 + 1 : n)), dim3(256), 0, st, a,
+                     b, y, n, leak, vec);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+// y(:,:,c,n) = a(c,n) * x(:,:,c,n) [+ r] [relu] : one block-row per plane chunk
+__global__ void __launch_bounds__(256)
+scale_axpy_kernel(const float *__restrict__ x, const float *__restrict__ a,
+                  const float *__restrict__ r, float *__restrict__ y, FastDiv divHW, size_t total,
+                  int relu) {
+  size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += stride) {
+    uint32_t plane = xm_div((uint32_t)i, divHW);
+    float v = a[plane] * x[i] + (r ? r[i] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+// one wave per plane: da = sum dy .* x ; dx = a .* dy
+__global__ void __launch_bounds__(256)
+scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a,
+                 const float *__restrict__ dy, float *__restrict__ dx, float *__restrict__ da, int HW,
+                 int planes) {
+  int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= planes) return;
+  int lane = threadIdx.x & 63;
+  size_t off = (size_t)plane * HW;
+  float av = a[plane], s = 0.f;
+  for (int i = lane; i < HW; i += 64) {
+    float d = dy[off + i];
+    s += d * x[off + i];
+    if (dx) dx[off + i] = av * d;
+  }
+  s = xm_wave_sum(s);
+  if (lane == 0 && da) da[plane] = s;
+}
+
+// softmax(X/T) along channels; one thread per (i, n) column
+__global__ void softmaxt_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, int C,
+                                int N, float T) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HW * N) return;
+  int i = idx % HW, n = idx / HW;
+  const float *p = x + i + (size_t)HW * C * n;
+  float *q = y + i + (size_t)HW * C * n;
+  double mx = -INFINITY, s = 0;
+  for (int c = 0; c < C; ++c) mx = fmax(mx, (double)p[(size_t)HW * c] / T);
+  for (int c = 0; c < C; ++c) s += exp((double)p[(size_t)HW * c] / T - mx);
+  for (int c = 0; c < C; ++c) q[(size_t)HW * c] = (float)(exp((double)p[(size_t)HW * c] / T - mx) / s);
+}
+
+// block-wide deterministic sum of one double per thread (256 threads) -> thread 0
+__device__ double block_sum_d(double v, double *red /*256*/) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// single block; thread-per-sample loop.  Matches oracle/xm_oracle.c orc_nnsoftmaxceloss.
+__global__ void __launch_bounds__(256)
+softmaxceloss_kernel(const float *__restrict__ x, const float *__restrict__ p, int C, int N, float T,
+                     int logit_targets, const float *__restrict__ w, const float *__restrict__ dzdy,
+                     float *__restrict__ y) {
+  __shared__ double red[256];
+  double total = 0;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float *xn = x + (size_t)C * n, *pn = p + (size_t)C * n;
+    double pt[64], mx = -INFINITY, s = 0, psum = 0;
+    if (logit_targets) {
+      double mp = -INFINITY, sp = 0;
+      for (int c = 0; c < C; ++c) mp = fmax(mp, (double)pn[c] / T);
+      for (int c = 0; c < C; ++c) sp += exp((double)pn[c] / T - mp);
+      for (int c = 0; c < C; ++c) pt[c] = exp((double)pn[c] / T - mp) / sp;
+    } else {
+      for (int c = 0; c < C; ++c) pt[c] = pn[c];
+    }
+    for (int c = 0; c < C; ++c) {
+      mx = fmax(mx, (double)xn[c] / T);
+      psum += pt[c];
+    }
+    for (int c = 0; c < C; ++c) s += exp((double)xn[c] / T - mx);
+    double lse = mx + log(s);
+    double wn = w ? (double)w[n] : 1.0;
+    if (!dzdy) {
+      double l = 0;
+      for (int c = 0; c < C; ++c) l += pt[c] * (lse - (double)xn[c] / T);
+      total += wn * l;
+    } else {
+      double dz = dzdy[0];
+      for (int c = 0; c < C; ++c) {
+        double q = exp((double)xn[c] / T - lse);
+        y[(size_t)C * n + c] = (float)(dz * wn * (q * psum - pt[c]) / T);
+      }
+    }
+  }
+  if (!dzdy) {
+    double t = block_sum_d(total, red);
+    if (threadIdx.x == 0) y[0] = (float)t;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+nnloss_kernel(const float *__restrict__ x, const float *__restrict__ labels, int C, int N, int loss,
+              const float *__restrict__ dzdy, float *__restrict__ y) {
+  __shared__ double red[256];
+  double total = 0;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float *xn = x + (size_t)C * n;
+    int c0 = (int)labels[n] - 1;
+    double mx = -INFINITY, s = 0;
+    int arg = 0;
+    for (int c = 0; c < C; ++c)
+      if ((double)xn[c] > mx) {
+        mx = xn[c];
+        arg = c;
+      }
+    for (int c = 0; c < C; ++c) s += exp((double)xn[c] - mx);
+    if (loss == XM_LOSS_SOFTMAXLOG) {
+      if (!dzdy)
+        total += mx + log(s) - (double)xn[c0];
+      else
+        for (int c = 0; c < C; ++c)
+          y[(size_t)C * n + c] =
+              (float)((double)dzdy[0] * (exp((double)xn[c] - mx) / s - (c == c0 ? 1.0 : 0.0)));
+    } else {
+      if (!dzdy)
+        total += (arg != c0) ? 1.0 : 0.0;
+      else
+        for (int c = 0; c < C; ++c) y[(size_t)C * n + c] = 0.f;
+    }
+  }
+  if (!dzdy) {
+    double t = block_sum_d(total, red);
+    if (threadIdx.x == 0) y[0] = (float)t;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sgd_kernel(float *__restrict__ w, float *__restrict__ m, const float *__restrict__ der, size_t n,
+           float lr, float mom, float wd, float inv_batch, int vec) {
+  size_t stride = (size_t)gridDim.x * 256;
+  size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (vec) {
+    size_t n4 = n >> 2;
+    for (size_t i = i0; i < n4; i += stride) {
+      float4 wv = reinterpret_cast<float4 *>(w)[i], mv = reinterpret_cast<float4 *>(m)[i];
+      float4 dv = reinterpret_cast<const float4 *>(der)[i];
+      // written exactly as cnn_train_dag: m = mom*m - (wd*w + der/B); w = w + lr*m
+      mv.x = mom * mv.x - (wd * wv.x + dv.x * inv_batch);
+      mv.y = mom * mv.y - (wd * wv.y + dv.y * inv_batch);
+      mv.z = mom * mv.z - (wd * wv.z + dv.z * inv_batch);
+      mv.w = mom * mv.w - (wd * wv.w + dv.w * inv_batch);
+      wv.x += lr * mv.x;
+      wv.y += lr * mv.y;
+      wv.z += lr * mv.z;
+      wv.w += lr * mv.w;
+      reinterpret_cast<float4 *>(m)[i] = mv;
+      reinterpret_cast<float4 *>(w)[i] = wv;
+    }
+    for (size_t i = (n4 << 2) + i0; i < n; i += stride) {
+      float mm = mom * m[i] - (wd * w[i] + der[i] * inv_batch);
+      m[i] = mm;
+      w[i] += lr * mm;
+    }
+  } else {
+    for (size_t i = i0; i < n; i += stride) {
+      float mm = mom * m[i] - (wd * w[i] + der[i] * inv_batch);
+      m[i] = mm;
+      w[i] += lr * mm;
+    }
+  }
+}
+
+__global__ void average_kernel(float *__restrict__ w, const float *__restrict__ der, size_t n,
+                               float lr, float inv_workers) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) w[i] = (1.f - lr) * w[i] + lr * (der[i] * inv_workers);
+}
+
+// per-frequency-row normalisation: thread per (h, n); lanes along h are contiguous in memory
+__global__ void __launch_bounds__(256)
+spec_rownorm_kernel(const float *__restrict__ s, float *__restrict__ o, int H, int W, int N) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * N) return;
+  int h = idx % H, n = idx / H;
+  const float *p = s + h + (size_t)H * W * n;
+  float *q = o + h + (size_t)H * W * n;
+  float sum = 0.f;
+  for (int w = 0; w < W; ++w) sum += p[(size_t)H * w];
+  float mu = sum / (float)W;
+  float ss = 0.f;
+  for (int w = 0; w < W; ++w) {
+    float d = p[(size_t)H * w] - mu;
+    ss += d * d;
+  }
+  float inv = 1.f / sqrtf(ss / (float)(W - 1));
+  for (int w = 0; w < W; ++w) q[(size_t)H * w] = (p[(size_t)H * w] - mu) * inv;
+}
+
+__global__ void aggregate_logits_kernel(const float *__restrict__ lg, int F, int E,
+                                        const int *__restrict__ first, const int *__restrict__ last,
+                                        int N, int agg, float *__restrict__ out,
+                                        float *__restrict__ max_label) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int f0 = first[n] - 1, f1 = min(last[n], F);
+  float best = -INFINITY;
+  int arg = 0;
+  for (int e = 0; e < E; ++e) {
+    float a = agg == XM_AGG_MAX ? -INFINITY : 0.f;
+    for (int fr = f0; fr < f1; ++fr) {
+      float v = lg[fr + (size_t)F * e];
+      a = agg == XM_AGG_MAX ? fmaxf(a, v) : a + v;
+    }
+    if (agg == XM_AGG_MEAN) a /= (float)(f1 - f0);
+    out[(size_t)E * n + e] = a;
+    if (a > best) {
+      best = a;
+      arg = e;
+    }
+  }
+  if (max_label) max_label[n] = (float)(arg + 1);
+}
+
+__global__ void normalize_face_kernel(const float *__restrict__ rgb, float *__restrict__ out, int HW,
+                                      int N, float a0, float a1, float a2) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * N) return;
+  size_t n = i / HW, q = i % HW;
+  const float *p = rgb + q + (size_t)HW * 3 * n;
+  float gr = 0.2989f * p[0] + 0.5870f * p[HW] + 0.1140f * p[2 * (size_t)HW];
+  gr = fminf(floorf(gr + 0.5f), 255.f);
+  float *o = out + q + (size_t)HW * 3 * n;
+  o[0] = gr - a0;
+  o[HW] = gr - a1;
+  o[2 * (size_t)HW] = gr - a2;
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+extern "C" {
+
+int xm_nnrelu(const float *x, size_t n, float leak, const float *dzdy, float *y, void *stream) {
+  if (dzdy) return ew_launch<OP_RELU_B, true>(x, dzdy, y, n, leak, (hipStream_t)stream);
+  return ew_launch<OP_RELU_F, false>(x, nullptr, y, n, leak, (hipStream_t)stream);
+}
+
+int xm_nnsigmoid(const float *x, size_t n, const float *dzdy, float *y, void *stream) {
+  if (dzdy) return ew_launch<OP_SIG_B, true>(x, dzdy, y, n, 0.f, (hipStream_t)stream);
+  return ew_launch<OP_SIG_F, false>(x, nullptr, y, n, 0.f, (hipStream_t)stream);
+}
+
+int xm_sum2(const float *a, const float *b, size_t n, int flags, float *y, void *stream) {
+  if (flags & XM_FUSE_RELU) return ew_launch<OP_SUM_RELU, true>(a, b, y, n, 0.f, (hipStream_t)stream);
+  return ew_launch<OP_SUM, true>(a, b, y, n, 0.f, (hipStream_t)stream);
+}
+
+int xm_scale_axpy(const float *x, int HW, int CN, const float *a, const float *r, int flags,
+                  float *y, void *stream) {
+  if (HW <= 0 || CN <= 0) return fail(XM_EINVAL, "scale: empty tensor");
+  if (!x || !a || !y) return fail(XM_EINVAL, "scale: NULL tensor");
+  if (too_big(HW, CN)) return fail(XM_ETOOBIG, "scale: tensor with >= 2^31 elements");
+  size_t total = (size_t)HW * CN;
+  hipLaunchKernelGGL(scale_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, a,
+                     r, y, make_fastdiv((uint32_t)HW), total, (flags & XM_FUSE_RELU) ? 1 : 0);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_scale_backward(const float *x, int HW, int CN, const float *a, const float *dzdy,
+                      float *dx_out, float *da_out, void *stream) {
+  if (HW <= 0 || CN <= 0) return fail(XM_EINVAL, "scale: empty tensor");
+  if (!x || !a || !dzdy) return fail(XM_EINVAL, "scale: NULL tensor");
+  hipLaunchKernelGGL(scale_bwd_kernel, dim3((CN + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, a,
+                     dzdy, dx_out, da_out, HW, CN);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnsoftmaxt(const float *x, int HW, int C, int N, float temperature, float *y, void *stream) {
+  if (HW <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnsoftmaxt: empty tensor");
+  if (!(temperature > 0.f)) return fail(XM_EINVAL, "vl_nnsoftmaxt: temperature must be > 0");
+  int cols = HW * N;
+  hipLaunchKernelGGL(softmaxt_kernel, dim3((cols + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, y,
+                     HW, C, N, temperature);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnsoftmaxceloss(const float *x, const float *p, int C, int N, float temperature,
+                       int logit_targets, const float *instance_weights, const float *dzdy,
+                       float *y, void *stream) {
+  if (C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnsoftmaxceloss: empty tensor");
+  if (C > 64) return fail(XM_ENOTSUP, "vl_nnsoftmaxceloss: more than 64 classes (%d)", C);
+  if (!(temperature > 0.f)) return fail(XM_EINVAL, "vl_nnsoftmaxceloss: temperature must be > 0");
+  if (!x || !p || !y) return fail(XM_EINVAL, "vl_nnsoftmaxceloss: NULL tensor");
+  hipLaunchKernelGGL(softmaxceloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, p, C, N,
+                     temperature, logit_targets, instance_weights, dzdy, y);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnloss(const float *x, const float *labels, int C, int N, int loss, const float *dzdy,
+              float *y, void *stream) {
+  if (C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnloss: empty tensor");
+  if (loss != XM_LOSS_SOFTMAXLOG && loss != XM_LOSS_CLASSERROR)
+    return fail(XM_ENOTSUP, "vl_nnloss: loss type %d not built (softmaxlog, classerror only)", loss);
+  if (!x || !labels || !y) return fail(XM_EINVAL, "vl_nnloss: NULL tensor");
+  hipLaunchKernelGGL(nnloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, labels, C, N, loss,
+                     dzdy, y);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_sgd_update(float *w, float *m, const float *der, size_t n, float lr, float momentum,
+                  float weight_decay, float batch, void *stream) {
+  if (n == 0) return XM_OK;
+  if (!w || !m || !der) return fail(XM_EINVAL, "sgd: NULL tensor");
+  if (!(batch > 0.f)) return fail(XM_EINVAL, "sgd: batch must be > 0");
+  int vec = ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)der) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(vec ? n / 4 + 1 : n)), dim3(256), 0, (hipStream_t)stream,
+                     w, m, der, n, lr, momentum, weight_decay, 1.0f / batch, vec);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_average_update(float *w, const float *der, size_t n, float lr, float nworkers, void *stream) {
+  if (n == 0) return XM_OK;
+  if (!w || !der) return fail(XM_EINVAL, "average update: NULL tensor");
+  hipLaunchKernelGGL(average_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, der, n, lr, 1.0f / nworkers);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream) {
+  if (H <= 0 || W <= 1 || N <= 0) return fail(XM_EINVAL, "spec_rownorm: need H>0, W>1, N>0");
+  if (!spec || !out) return fail(XM_EINVAL, "spec_rownorm: NULL tensor");
+  int rows = H * N;
+  hipLaunchKernelGGL(spec_rownorm_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     spec, out, H, W, N);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_aggregate_logits(const float *frame_logits, int F_total, int E, const int *first,
+                        const int *last, int N, int agg, float *out, float *max_label,
+                        void *stream) {
+  if (F_total <= 0 || E <= 0 || N <= 0) return fail(XM_EINVAL, "aggregate_logits: empty input");
+  if (agg != XM_AGG_MAX && agg != XM_AGG_MEAN)
+    return fail(XM_EINVAL, "unrecognised aggregator %d", agg);
+  hipLaunchKernelGGL(aggregate_logits_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                     frame_logits, F_total, E, first, last, N, agg, out, max_label);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,
+                      void *stream) {
+  if (H <= 0 || W <= 0 || N <= 0) return fail(XM_EINVAL, "normalize_face: empty input");
+  if (!rgb || !avg3 || !out) return fail(XM_EINVAL, "normalize_face: NULL tensor");
+  float a[3];
+  // averageImage is a 3-vector of host-known constants in the reference (meta.normalization);
+  // accept a HOST pointer here to keep the launch free of a device round trip.
+  a[0] = avg3[0];
+  a[1] = avg3[1];
+  a[2] = avg3[2];
+  size_t n = (size_t)H * W * N;
+  hipLaunchKernelGGL(normalize_face_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, rgb, out, H * W, N, a[0], a[1], a[2]);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+}

@@ -1,0 +1,522 @@
+// vl_nnbnorm and vl_nnpool on gfx950 -- HBM-bound kernels: coalesced runs along H (the MATLAB
+// fastest axis), float4 where the plane size allows, wave-shuffle + LDS tree reductions, fixed
+// reduction order (no atomics) so results are run-to-run identical.
+// Replaces MatConvNet's vl_nnbnorm / vl_nnpool MEX (bits/nnbnorm.cu, bits/nnpooling.cu).
+#include "xm_common.h"
+
+namespace xm {
+
+// ============================== batch normalisation =========================================
+// Per-channel moments over H*W*N.  One pass, shifted sums (shift = first element of the channel)
+// so that var = E[(x-s)^2] - E[x-s]^2 does not cancel catastrophically in fp32.
+// grid = (C, S): block (c, s) reduces samples s, s+S, ... of channel c.
+__device__ __forceinline__ void block_reduce2(float &a, float &b, float *red /*8 floats*/) {
+  a = xm_wave_sum(a);
+  b = xm_wave_sum(b);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[w] = a;
+    red[4 + w] = b;
+  }
+  __syncthreads();
+  a = red[0] + red[1] + red[2] + red[3];
+  b = red[4] + red[5] + red[6] + red[7];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+bn_stats_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int HW, int C, int N,
+                        int S) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float shift = x[(size_t)HW * c];
+  float a = 0.f, b = 0.f;
+  const bool vec = (HW & 3) == 0;
+  for (int n = s; n < N; n += S) {
+    const float *p = x + (size_t)HW * (c + (size_t)C * n);
+    if (vec) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(p);
+      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+        float4 v = p4[i];
+        float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+        a += (d0 + d1) + (d2 + d3);
+        b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        float d = p[i] - shift;
+        a += d;
+        b += d * d;
+      }
+    }
+  }
+  __shared__ float red[8];
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) {
+    part[2 * ((size_t)c * S + s)] = a;
+    part[2 * ((size_t)c * S + s) + 1] = b;
+  }
+}
+
+// moments(c) = [mean, sqrt(var + eps)]
+__global__ void bn_finalize_kernel(const float *__restrict__ x, const float *__restrict__ part,
+                                   float *__restrict__ mom, int HW, int C, int S, float m,
+                                   float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < S; ++s) {
+    a += part[2 * ((size_t)c * S + s)];
+    b += part[2 * ((size_t)c * S + s) + 1];
+  }
+  float shift = x[(size_t)HW * c];
+  float d = a / m;
+  float var = b / m - d * d;
+  var = var < 0.f ? 0.f : var;
+  mom[c] = shift + d;
+  mom[C + c] = sqrtf(var + eps);
+}
+
+// y = g/sigma * (x - mu) + b   [relu]
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ g,
+                const float *__restrict__ b, const float *__restrict__ mom, FastDiv divHW, int C,
+                size_t total, int relu) {
+  size_t stride = (size_t)gridDim.x * 256;
+  if (VEC) {
+    size_t n4 = total >> 2;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += stride) {
+      uint32_t plane = xm_div((uint32_t)(i << 2), divHW);
+      int c = plane % C;
+      float sc = g[c] / mom[C + c], mu = mom[c], bb = b[c];
+      float4 v = reinterpret_cast<const float4 *>(x)[i];
+      v.x = sc * (v.x - mu) + bb;
+      v.y = sc * (v.y - mu) + bb;
+      v.z = sc * (v.z - mu) + bb;
+      v.w = sc * (v.w - mu) + bb;
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      }
+      reinterpret_cast<float4 *>(y)[i] = v;
+    }
+  } else {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += stride) {
+      uint32_t plane = xm_div((uint32_t)i, divHW);
+      int c = plane % C;
+      float v = g[c] / mom[C + c] * (x[i] - mom[c]) + b[c];
+      if (relu) v = fmaxf(v, 0.f);
+      y[i] = v;
+    }
+  }
+}
+
+// backward sums: part[c][s] = (sum dy, sum dy*(x-mu)); dy masked by (yfwd > 0) when yfwd != NULL
+__global__ void __launch_bounds__(256)
+bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                      const float *__restrict__ yfwd, const float *__restrict__ mom,
+                      float *__restrict__ part, int HW, int C, int N, int S) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float mu = mom[c];
+  float a = 0.f, b = 0.f;
+  const bool vec = (HW & 3) == 0;
+  for (int n = s; n < N; n += S) {
+    size_t off = (size_t)HW * (c + (size_t)C * n);
+    if (vec) {
+      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
+      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
+      const float4 *y4 = yfwd ? reinterpret_cast<const float4 *>(yfwd + off) : nullptr;
+      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+        float4 xv = x4[i], dv = d4[i];
+        if (y4) {
+          float4 yv = y4[i];
+          dv.x = yv.x > 0.f ? dv.x : 0.f;
+          dv.y = yv.y > 0.f ? dv.y : 0.f;
+          dv.z = yv.z > 0.f ? dv.z : 0.f;
+          dv.w = yv.w > 0.f ? dv.w : 0.f;
+        }
+        a += (dv.x + dv.y) + (dv.z + dv.w);
+        b += (dv.x * (xv.x - mu) + dv.y * (xv.y - mu)) + (dv.z * (xv.z - mu) + dv.w * (xv.w - mu));
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        float d = dy[off + i];
+        if (yfwd && !(yfwd[off + i] > 0.f)) d = 0.f;
+        a += d;
+        b += d * (x[off + i] - mu);
+      }
+    }
+  }
+  __shared__ float red[8];
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) {
+    part[2 * ((size_t)c * S + s)] = a;
+    part[2 * ((size_t)c * S + s) + 1] = b;
+  }
+}
+
+// sums(c) = [sum dy, sum dy*(x-mu)];  dg = sums1 / sigma, db = sums0
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, const float *__restrict__ mom,
+                                       float *__restrict__ sums, float *__restrict__ dg,
+                                       float *__restrict__ db, int C, int S) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < S; ++s) {
+    a += part[2 * ((size_t)c * S + s)];
+    b += part[2 * ((size_t)c * S + s) + 1];
+  }
+  sums[c] = a;
+  sums[C + c] = b;
+  if (dg) dg[c] = b / mom[C + c];
+  if (db) db[c] = a;
+}
+
+// train: dx = g/sigma * (dy - sum_dy/m - (x-mu) * sum_dyx / (m sigma^2));  test: dx = g/sigma * dy
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                    const float *__restrict__ yfwd, float *__restrict__ dx,
+                    const float *__restrict__ g, const float *__restrict__ mom,
+                    const float *__restrict__ sums, FastDiv divHW, int C, size_t total, float m,
+                    int train) {
+  size_t stride = (size_t)gridDim.x * 256;
+  const size_t cnt = VEC ? (total >> 2) : total;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < cnt; i += stride) {
+    uint32_t plane = xm_div((uint32_t)(VEC ? (i << 2) : i), divHW);
+    int c = plane % C;
+    float sg = mom[C + c], mu = mom[c];
+    float gs = g[c] / sg;
+    float c1 = train ? sums[c] / m : 0.f;
+    float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
+    if (VEC) {
+      float4 xv = reinterpret_cast<const float4 *>(x)[i];
+      float4 dv = reinterpret_cast<const float4 *>(dy)[i];
+      if (yfwd) {
+        float4 yv = reinterpret_cast<const float4 *>(yfwd)[i];
+        dv.x = yv.x > 0.f ? dv.x : 0.f;
+        dv.y = yv.y > 0.f ? dv.y : 0.f;
+        dv.z = yv.z > 0.f ? dv.z : 0.f;
+        dv.w = yv.w > 0.f ? dv.w : 0.f;
+      }
+      float4 o;
+      o.x = gs * (dv.x - c1 - (xv.x - mu) * c2);
+      o.y = gs * (dv.y - c1 - (xv.y - mu) * c2);
+      o.z = gs * (dv.z - c1 - (xv.z - mu) * c2);
+      o.w = gs * (dv.w - c1 - (xv.w - mu) * c2);
+      reinterpret_cast<float4 *>(dx)[i] = o;
+    } else {
+      float d = dy[i];
+      if (yfwd && !(yfwd[i] > 0.f)) d = 0.f;
+      dx[i] = gs * (d - c1 - (x[i] - mu) * c2);
+    }
+  }
+}
+
+static int bn_splits(int C, int N) {
+  int s = 2048 / (C > 0 ? C : 1);
+  if (s < 1) s = 1;
+  if (s > N) s = N;
+  return s;
+}
+
+static unsigned ew_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+static int bn_check(int H, int W, int C, int N) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnbnorm: empty tensor");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "vl_nnbnorm: tensor with >= 2^31 elements");
+  return XM_OK;
+}
+
+static int bnorm_forward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                         float eps, const float *moments_in, float *y, float *moments_out, int relu,
+                         hipStream_t st) {
+  int rc = bn_check(H, W, C, N);
+  if (rc) return rc;
+  if (!x || !g || !b || !y) return fail(XM_EINVAL, "vl_nnbnorm: NULL tensor");
+  const int HW = H * W;
+  const int S = bn_splits(C, N);
+  const float *mom = moments_in;
+  WsCarver ws;
+  if (!moments_in) {
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + WsCarver::need((size_t)2 * C, 4));
+    if (rc) return rc;
+    float *part = ws.take<float>((size_t)2 * C * S);
+    float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    XM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
+                       C, S, (float)((double)HW * N), eps);
+    XM_LAUNCH_CHECK();
+    mom = momw;
+  } else if (moments_out) {
+    XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
+  }
+  size_t total = (size_t)HW * C * N;
+  FastDiv d = make_fastdiv((uint32_t)HW);
+  if ((HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, g, b,
+                       mom, d, C, total, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, st, x, y, g, b,
+                       mom, d, C, total, relu);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C, int N,
+                          const float *g, const float *dzdy, float eps, const float *moments_in,
+                          float *dx_out, float *dg_out, float *db_out, float *moments_out,
+                          hipStream_t st) {
+  int rc = bn_check(H, W, C, N);
+  if (rc) return rc;
+  if (!x || !g || !dzdy) return fail(XM_EINVAL, "vl_nnbnorm: NULL tensor");
+  const int HW = H * W;
+  const int S = bn_splits(C, N);
+  WsCarver ws;
+  rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + 2 * WsCarver::need((size_t)2 * C, 4));
+  if (rc) return rc;
+  float *part = ws.take<float>((size_t)2 * C * S);
+  float *sums = ws.take<float>((size_t)2 * C);
+  const float *mom = moments_in;
+  if (!moments_in) {
+    float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    XM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
+                       C, S, (float)((double)HW * N), eps);
+    XM_LAUNCH_CHECK();
+    mom = momw;
+  } else if (moments_out) {
+    XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, x, dzdy, yfwd, mom, part, HW,
+                     C, N, S);
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, mom, sums,
+                     dg_out, db_out, C, S);
+  XM_LAUNCH_CHECK();
+  if (dx_out) {
+    size_t total = (size_t)HW * C * N;
+    FastDiv d = make_fastdiv((uint32_t)HW);
+    float m = (float)((double)HW * N);
+    int train = moments_in ? 0 : 1;
+    bool al = ((((uintptr_t)x | (uintptr_t)dzdy | (uintptr_t)dx_out | (uintptr_t)yfwd) & 15) == 0);
+    if ((HW & 3) == 0 && al)
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(total / 4)), dim3(256), 0, st, x,
+                         dzdy, yfwd, dx_out, g, mom, sums, d, C, total, m, train);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, st, x, dzdy,
+                         yfwd, dx_out, g, mom, sums, d, C, total, m, train);
+    XM_LAUNCH_CHECK();
+  }
+  return XM_OK;
+}
+
+// ===================================== pooling ===============================================
+struct PoolGeo {
+  int H, W, Ho, Wo, ph, pw, sy, sx, pt, pl;
+};
+
+// one thread per output element, lanes along ho (contiguous); window scan is column-major
+__global__ void __launch_bounds__(256)
+pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, PoolGeo g, FastDiv divHoWo,
+                FastDiv divHo, size_t total, int method) {
+  size_t stride = (size_t)gridDim.x * 256;
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
+    uint32_t plane = xm_div((uint32_t)idx, divHoWo);
+    uint32_t q = (uint32_t)idx - plane * divHoWo.d;
+    uint32_t wo = xm_div(q, divHo);
+    uint32_t ho = q - wo * divHo.d;
+    int w1 = (int)wo * g.sx - g.pl, h1 = (int)ho * g.sy - g.pt;
+    int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
+    w1 = max(w1, 0);
+    h1 = max(h1, 0);
+    const float *p = x + (size_t)plane * g.H * g.W;
+    float r;
+    if (method == XM_POOL_MAX) {
+      r = -INFINITY;
+      for (int w = w1; w < w2; ++w)
+        for (int h = h1; h < h2; ++h) r = fmaxf(r, p[h + g.H * w]);
+    } else {
+      r = 0.f;
+      for (int w = w1; w < w2; ++w)
+        for (int h = h1; h < h2; ++h) r += p[h + g.H * w];
+      r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
+    }
+    y[idx] = r;
+  }
+}
+
+// global pooling (window = whole plane, no padding): one wave per plane, shuffle reduction
+__global__ void __launch_bounds__(256)
+pool_global_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, int planes,
+                   int method) {
+  int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= planes) return;
+  const float *p = x + (size_t)plane * HW;
+  int lane = threadIdx.x & 63;
+  if (method == XM_POOL_MAX) {
+    float r = -INFINITY;
+    for (int i = lane; i < HW; i += 64) r = fmaxf(r, p[i]);
+    r = xm_wave_max(r);
+    if (lane == 0) y[plane] = r;
+  } else {
+    float r = 0.f;
+    for (int i = lane; i < HW; i += 64) r += p[i];
+    r = xm_wave_sum(r);
+    if (lane == 0) y[plane] = r * (1.0f / (float)HW);
+  }
+}
+
+// backward as a gather: one thread per INPUT element visits the <= ceil(ph/sy)*ceil(pw/sx)
+// windows that contain it.  max: the element receives dzdy(window) iff it is the first maximum
+// of that window in column-major scan order (MatConvNet CPU tie rule).  No atomics.
+__global__ void __launch_bounds__(256)
+pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx,
+                PoolGeo g, FastDiv divHW, FastDiv divH, size_t total, int method) {
+  size_t stride = (size_t)gridDim.x * 256;
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
+    uint32_t plane = xm_div((uint32_t)idx, divHW);
+    uint32_t q = (uint32_t)idx - plane * divHW.d;
+    int w = (int)xm_div(q, divH);
+    int h = (int)q - w * (int)divH.d;
+    const float *p = x + (size_t)plane * g.H * g.W;
+    const float *d = dy + (size_t)plane * g.Ho * g.Wo;
+    // windows ho with ho*sy - pt <= h < ho*sy - pt + ph
+    int ho_lo = h + g.pt - g.ph + 1;
+    ho_lo = ho_lo <= 0 ? 0 : (ho_lo + g.sy - 1) / g.sy;
+    int ho_hi = min((h + g.pt) / g.sy, g.Ho - 1);
+    int wo_lo = w + g.pl - g.pw + 1;
+    wo_lo = wo_lo <= 0 ? 0 : (wo_lo + g.sx - 1) / g.sx;
+    int wo_hi = min((w + g.pl) / g.sx, g.Wo - 1);
+    float acc = 0.f;
+    float xv = p[h + g.H * w];
+    for (int wo = wo_lo; wo <= wo_hi; ++wo)
+      for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        int w1 = wo * g.sx - g.pl, h1 = ho * g.sy - g.pt;
+        int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
+        w1 = max(w1, 0);
+        h1 = max(h1, 0);
+        float dv = d[ho + g.Ho * wo];
+        if (method == XM_POOL_MAX) {
+          // am I the first maximum?  every element scanned before me must be < xv (strictly),
+          // every element after me must be <= xv.
+          bool win = true;
+          for (int ww = w1; ww < w2 && win; ++ww)
+            for (int hh = h1; hh < h2; ++hh) {
+              float o = p[hh + g.H * ww];
+              bool before = (ww < w) || (ww == w && hh < h);
+              if (before ? !(o < xv) : (o > xv)) {
+                win = false;
+                break;
+              }
+            }
+          if (win) acc += dv;
+        } else {
+          acc += dv * (1.0f / (float)((h2 - h1) * (w2 - w1)));
+        }
+      }
+    dx[idx] = acc;
+  }
+}
+
+static int pool_geo(PoolGeo &g, int H, int W, int C, int N, int ph, int pw, int sy, int sx, int pt,
+                    int pb, int pl, int pr, int method) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnpool: empty tensor");
+  if (ph < 1 || pw < 1 || sy < 1 || sx < 1 || pt < 0 || pb < 0 || pl < 0 || pr < 0)
+    return fail(XM_EINVAL, "vl_nnpool: bad pool/stride/pad");
+  if (method != XM_POOL_MAX && method != XM_POOL_AVG)
+    return fail(XM_EINVAL, "vl_nnpool: unknown method %d", method);
+  // MatConvNet: padding must be smaller than the window
+  if (pt >= ph || pb >= ph || pl >= pw || pr >= pw)
+    return fail(XM_EINVAL, "vl_nnpool: pad must be smaller than the pooling window");
+  int Ho = out_size(H, pt, pb, ph, 1, sy), Wo = out_size(W, pl, pr, pw, 1, sx);
+  if (Ho <= 0 || Wo <= 0) return fail(XM_EINVAL, "vl_nnpool: window larger than padded input");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "vl_nnpool: tensor with >= 2^31 elements");
+  g = PoolGeo{H, W, Ho, Wo, ph, pw, sy, sx, pt, pl};
+  return XM_OK;
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+extern "C" {
+
+int xm_nnbnorm_forward_fused(const float *x, int H, int W, int C, int N, const float *g,
+                             const float *b, float epsilon, const float *moments_in, float *y,
+                             float *moments_out, int flags, void *stream) {
+  return bnorm_forward(x, H, W, C, N, g, b, epsilon, moments_in, y, moments_out,
+                       (flags & XM_FUSE_RELU) ? 1 : 0, (hipStream_t)stream);
+}
+
+int xm_nnbnorm_forward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                       float epsilon, const float *moments_in, float *y, float *moments_out,
+                       void *stream) {
+  return bnorm_forward(x, H, W, C, N, g, b, epsilon, moments_in, y, moments_out, 0,
+                       (hipStream_t)stream);
+}
+
+int xm_nnbnorm_backward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                        const float *dzdy, float epsilon, const float *moments_in, float *dx_out,
+                        float *dg_out, float *db_out, float *moments_out, void *stream) {
+  (void)b;
+  return bnorm_backward(x, nullptr, H, W, C, N, g, dzdy, epsilon, moments_in, dx_out, dg_out, db_out,
+                        moments_out, (hipStream_t)stream);
+}
+
+int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int C, int N,
+                              const float *g, const float *b, const float *dzdy, float epsilon,
+                              const float *moments_in, float *dx_out, float *dg_out, float *db_out,
+                              float *moments_out, int flags, void *stream) {
+  (void)b;
+  if ((flags & XM_FUSE_RELU) && !y) return fail(XM_EINVAL, "vl_nnbnorm(fused bwd): y is NULL");
+  return bnorm_backward(x, (flags & XM_FUSE_RELU) ? y : nullptr, H, W, C, N, g, dzdy, epsilon,
+                        moments_in, dx_out, dg_out, db_out, moments_out, (hipStream_t)stream);
+}
+
+int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                      int pt, int pb, int pl, int pr, int method, float *y, void *stream) {
+  PoolGeo g;
+  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
+  if (rc) return rc;
+  if (!x || !y) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  if (g.Ho == 1 && g.Wo == 1 && ph >= H && pw >= W && !(pt | pl)) {
+    int planes = C * N;
+    hipLaunchKernelGGL(pool_global_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, x, y, H * W,
+                       planes, method);
+    XM_LAUNCH_CHECK();
+    return XM_OK;
+  }
+  size_t total = (size_t)g.Ho * g.Wo * C * N;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, g,
+                     make_fastdiv((uint32_t)(g.Ho * g.Wo)), make_fastdiv((uint32_t)g.Ho), total,
+                     method);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                       int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
+                       void *stream) {
+  PoolGeo g;
+  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
+  if (rc) return rc;
+  if (!x || !dzdy || !dx_out) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  size_t total = (size_t)H * W * C * N;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dzdy,
+                     dx_out, g, make_fastdiv((uint32_t)(H * W)), make_fastdiv((uint32_t)H), total,
+                     method);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+}

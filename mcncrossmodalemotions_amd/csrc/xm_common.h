@@ -1,0 +1,103 @@
+// Shared host-side plumbing for libxmodal_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/xmodal.h"
+
+namespace xm {
+
+// ---- error reporting (C ABI never throws) -------------------------------------------------
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define XM_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return xm::fail(XM_EHIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+#define XM_LAUNCH_CHECK()                                                             \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess)                                                            \
+      return xm::fail(XM_EHIP, "kernel launch -> %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- stream-ordered scratch ----------------------------------------------------------------
+// One growable device buffer.  Every API call carves what it needs from offset 0; calls are
+// stream-ordered on the caller's stream, so reuse across consecutive calls is safe as long as a
+// process drives one stream at a time (MatConvNet's model).  Growing synchronises the device.
+int ws_get(size_t bytes, void **ptr);
+struct WsCarver {
+  char *base = nullptr;
+  size_t off = 0, cap = 0;
+  int init(size_t bytes) {
+    void *p = nullptr;
+    int rc = ws_get(bytes, &p);
+    base = (char *)p;
+    cap = bytes;
+    off = 0;
+    return rc;
+  }
+  template <class T>
+  T *take(size_t count) {
+    size_t b = (count * sizeof(T) + 255) & ~size_t(255);
+    T *p = (T *)(base + off);
+    off += b;
+    return p;
+  }
+  static size_t need(size_t count, size_t elt) { return (count * elt + 255) & ~size_t(255); }
+};
+
+// persistent small device objects keyed by content (tap tables)
+const void *cached_device_table(const void *host, size_t bytes);
+
+static inline int out_size(int in, int pa, int pb, int f, int d, int s) {
+  int feff = (f - 1) * d + 1;
+  int t = in + pa + pb - feff;
+  return t < 0 ? 0 : t / s + 1;
+}
+
+static inline bool too_big(long long a, long long b = 1, long long c = 1, long long d = 1) {
+  return a * b * c * d >= (1LL << 31);
+}
+
+// magic division of a 31-bit numerator by a runtime divisor: q = (n * m) >> s
+struct FastDiv {
+  uint32_t m;
+  uint32_t s;
+  uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.s = 31 + l;
+  f.m = (uint32_t)(((1ull << f.s) + d - 1) / d);
+  return f;
+}
+
+}  // namespace xm
+
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t xm_div(uint32_t n, const xm::FastDiv f) {
+  return (uint32_t)(((uint64_t)n * f.m) >> f.s);
+}
+__device__ __forceinline__ float xm_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float xm_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif

@@ -1,0 +1,435 @@
+"""Host-side mirror of the MatConvNet / mcnExtraLayers operator API, over the HIP C ABI.
+
+Same names, argument meaning and error behaviour as the MATLAB operators the reference's
+graphs execute:
+
+    y            = vl_nnconv(x, f, b, stride=.., pad=.., dilate=..)
+    dx, df, db   = vl_nnconv(x, f, b, dzdy, ...)           # backward when dzdy is given
+    y            = vl_nnpool(x, pool, stride=.., pad=.., method='max'|'avg')
+    y[, moments] = vl_nnbnorm(x, g, b, epsilon=1e-4, moments=M)
+    ...
+
+Tensors are torch float32 CUDA tensors in MATLAB layout: logical shape (H, W, C, N) with
+column-major strides (H fastest) -- create them with `mat_empty/mat_zeros/from_numpy`.
+torch is used for device memory and streams only; every operator below is one or more
+hand-written HIP kernels from libxmodal_hip.so.  There is no CPU / eager fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# --------------------------------------------------------------------------------------------
+# MATLAB-layout tensor helpers
+# --------------------------------------------------------------------------------------------
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def mat_empty(*shape, device=None):
+    """uninitialised `single` array of MATLAB shape `shape` (column-major)."""
+    shape = tuple(int(s) for s in (shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape))
+    t = torch.empty(tuple(reversed(shape)), dtype=torch.float32, device=device or _dev())
+    return t.permute(*reversed(range(len(shape))))
+
+
+def mat_zeros(*shape, device=None):
+    t = mat_empty(*shape, device=device)
+    t.zero_()
+    return t
+
+
+def from_numpy(a, device=None):
+    """numpy array (any order) -> device tensor with MATLAB (column-major) layout."""
+    a = np.asarray(a, dtype=np.float32)
+    ct = np.ascontiguousarray(a.transpose(*reversed(range(a.ndim))))
+    t = torch.from_numpy(ct).to(device or _dev())
+    return t.permute(*reversed(range(a.ndim)))
+
+
+def to_numpy(t):
+    """device tensor in MATLAB layout -> numpy Fortran-ordered array of the same shape."""
+    c = t.permute(*reversed(range(t.dim()))).contiguous().cpu().numpy()
+    return np.asfortranarray(c.transpose(*reversed(range(c.ndim))))
+
+
+def is_mat(t):
+    return t.permute(*reversed(range(t.dim()))).is_contiguous()
+
+
+def _chk(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch tensor" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s: expected single precision (float32), got %s" % (name, t.dtype))
+    if not t.is_cuda:
+        raise RuntimeError("%s: tensor is not on the GPU; this build has no CPU path" % name)
+    if not is_mat(t):
+        raise ValueError("%s: tensor is not in MATLAB column-major layout" % name)
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _shape4(t):
+    s = tuple(t.shape) + (1,) * (4 - t.dim())
+    if len(s) != 4:
+        raise ValueError("expected an array with at most 4 dimensions, got %r" % (tuple(t.shape),))
+    return [int(v) for v in s]
+
+
+def _pair(v, name):
+    if np.isscalar(v):
+        return int(v), int(v)
+    v = list(v)
+    if len(v) == 1:
+        return int(v[0]), int(v[0])
+    if len(v) != 2:
+        raise ValueError("%s must have 1 or 2 elements" % name)
+    return int(v[0]), int(v[1])
+
+
+def _pad4(pad):
+    if np.isscalar(pad):
+        return (int(pad),) * 4
+    pad = list(pad)
+    if len(pad) == 1:
+        return (int(pad[0]),) * 4
+    if len(pad) == 2:
+        return int(pad[0]), int(pad[0]), int(pad[1]), int(pad[1])
+    if len(pad) != 4:
+        raise ValueError("PAD must have 1, 2 or 4 elements")
+    return tuple(int(v) for v in pad)
+
+
+def _L():
+    return _lib.load()
+
+
+def out_size(n, pa, pb, f, d, s):
+    return _L().xm_out_size(n, pa, pb, f, d, s)
+
+
+# --------------------------------------------------------------------------------------------
+# vl_nnconv
+# --------------------------------------------------------------------------------------------
+
+
+def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
+              no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
+              relu=False):
+    """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
+
+    `scale/shift/residual/relu` select the fused forward epilogue (extension; see xmodal.h)."""
+    x, f = _chk(x, "X"), _chk(f, "F")
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = _shape4(f)
+    sy, sx = _pair(stride, "STRIDE")
+    dy, dx = _pair(dilate, "DILATE")
+    pt, pb, pl, pr = _pad4(pad)
+    bb = None
+    if b is not None and b.numel() > 0:
+        bb = _chk(b, "B")
+        if bb.numel() != K:
+            raise ValueError("vl_nnconv: B has %d elements, expected %d" % (bb.numel(), K))
+    L = _L()
+    Ho = L.xm_out_size(H, pt, pb, FH, dy, sy)
+    Wo = L.xm_out_size(W, pl, pr, FW, dx, sx)
+    if dzdy is None:
+        y = mat_empty(max(Ho, 0), max(Wo, 0), K, N, device=x.device)
+        fused = scale is not None or residual is not None or relu
+        if fused:
+            if residual is not None:
+                _chk(residual, "RESIDUAL")
+                if _shape4(residual) != [Ho, Wo, K, N]:
+                    raise ValueError("vl_nnconv: residual shape mismatch")
+            _lib.check(L.xm_nnconv_forward_fused(
+                _ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb), _ptr(y), sy, sx, pt, pb,
+                pl, pr, dy, dx, _ptr(scale), _ptr(shift), _ptr(residual), 1 if relu else 0,
+                _stream()))
+        else:
+            _lib.check(L.xm_nnconv_forward(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb),
+                                           _ptr(y), sy, sx, pt, pb, pl, pr, dy, dx, _stream()))
+        return y
+    dzdy = _chk(dzdy, "DZDY")
+    if _shape4(dzdy) != [Ho, Wo, K, N]:
+        raise ValueError("vl_nnconv: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, K, N)))
+    dxo = None if no_der_data else mat_empty(H, W, Cc, N, device=x.device)
+    dfo = None if no_der_filters else mat_empty(FH, FW, FC, K, device=x.device)
+    dbo = None if (no_der_biases or bb is None) else mat_empty(K, 1, device=x.device)
+    _lib.check(L.xm_nnconv_backward(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(dzdy),
+                                    _ptr(dxo), _ptr(dfo), _ptr(dbo), sy, sx, pt, pb, pl, pr, dy, dx,
+                                    _stream()))
+    return dxo, dfo, dbo
+
+
+# --------------------------------------------------------------------------------------------
+# vl_nnpool
+# --------------------------------------------------------------------------------------------
+_METHOD = {"max": 0, "avg": 1}
+
+
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max"):
+    """Y = VL_NNPOOL(X, POOL) / DX = VL_NNPOOL(X, POOL, DZDY)."""
+    x = _chk(x, "X")
+    if method not in _METHOD:
+        raise ValueError("vl_nnpool: unknown METHOD '%s'" % method)
+    H, W, Cc, N = _shape4(x)
+    ph, pw = _pair(pool, "POOL")
+    sy, sx = _pair(stride, "STRIDE")
+    pt, pb, pl, pr = _pad4(pad)
+    L = _L()
+    Ho = L.xm_out_size(H, pt, pb, ph, 1, sy)
+    Wo = L.xm_out_size(W, pl, pr, pw, 1, sx)
+    if dzdy is None:
+        y = mat_empty(max(Ho, 0), max(Wo, 0), Cc, N, device=x.device)
+        _lib.check(L.xm_nnpool_forward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
+                                       _METHOD[method], _ptr(y), _stream()))
+        return y
+    dzdy = _chk(dzdy, "DZDY")
+    if _shape4(dzdy) != [Ho, Wo, Cc, N]:
+        raise ValueError("vl_nnpool: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, Cc, N)))
+    dxo = mat_empty(H, W, Cc, N, device=x.device)
+    _lib.check(L.xm_nnpool_backward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
+                                    _METHOD[method], _ptr(dzdy), _ptr(dxo), _stream()))
+    return dxo
+
+
+# --------------------------------------------------------------------------------------------
+# vl_nnbnorm
+# --------------------------------------------------------------------------------------------
+
+
+def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None):
+    """forward:  Y, MOMENTS = VL_NNBNORM(X, G, B);  backward: DX, DG, DB, MOMENTS = (..., DZDY).
+
+    MOMENTS is C x 2 = [mean, sqrt(var + epsilon)].  `relu=True` fuses vl_nnrelu (forward) /
+    its mask (backward; pass the fused forward output as `y`)."""
+    x, g, b = _chk(x, "X"), _chk(g, "G"), _chk(b, "B")
+    H, W, Cc, N = _shape4(x)
+    if g.numel() != Cc or b.numel() != Cc:
+        raise ValueError("vl_nnbnorm: G and B must have %d elements" % Cc)
+    mi = None
+    if moments is not None:
+        mi = _chk(moments, "MOMENTS")
+        if mi.numel() != 2 * Cc:
+            raise ValueError("vl_nnbnorm: MOMENTS must be %d x 2" % Cc)
+    L = _L()
+    mo = mat_empty(Cc, 2, device=x.device)
+    if dzdy is None:
+        yo = mat_empty(H, W, Cc, N, device=x.device)
+        _lib.check(L.xm_nnbnorm_forward_fused(_ptr(x), H, W, Cc, N, _ptr(g), _ptr(b),
+                                              float(epsilon), _ptr(mi), _ptr(yo), _ptr(mo),
+                                              1 if relu else 0, _stream()))
+        return yo, mo
+    dzdy = _chk(dzdy, "DZDY")
+    if _shape4(dzdy) != [H, W, Cc, N]:
+        raise ValueError("vl_nnbnorm: DZDY shape mismatch")
+    dxo = mat_empty(H, W, Cc, N, device=x.device)
+    dg = mat_empty(Cc, 1, device=x.device)
+    db = mat_empty(Cc, 1, device=x.device)
+    if relu:
+        if y is None:
+            raise ValueError("vl_nnbnorm: fused backward needs the forward output y")
+        _lib.check(L.xm_nnbnorm_backward_fused(_ptr(x), _ptr(_chk(y, "Y")), H, W, Cc, N, _ptr(g),
+                                               _ptr(b), _ptr(dzdy), float(epsilon), _ptr(mi),
+                                               _ptr(dxo), _ptr(dg), _ptr(db), _ptr(mo), 1,
+                                               _stream()))
+    else:
+        _lib.check(L.xm_nnbnorm_backward(_ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), _ptr(dzdy),
+                                         float(epsilon), _ptr(mi), _ptr(dxo), _ptr(dg), _ptr(db),
+                                         _ptr(mo), _stream()))
+    return dxo, dg, db, mo
+
+
+# --------------------------------------------------------------------------------------------
+# elementwise
+# --------------------------------------------------------------------------------------------
+
+
+def vl_nnrelu(x, dzdy=None, leak=0.0):
+    x = _chk(x, "X")
+    y = mat_empty(*x.shape, device=x.device)
+    d = None if dzdy is None else _chk(dzdy, "DZDY")
+    _lib.check(_L().xm_nnrelu(_ptr(x), x.numel(), float(leak), _ptr(d), _ptr(y), _stream()))
+    return y
+
+
+def vl_nnsigmoid(x, dzdy=None):
+    x = _chk(x, "X")
+    y = mat_empty(*x.shape, device=x.device)
+    d = None if dzdy is None else _chk(dzdy, "DZDY")
+    _lib.check(_L().xm_nnsigmoid(_ptr(x), x.numel(), _ptr(d), _ptr(y), _stream()))
+    return y
+
+
+def sum2(a, b, relu=False):
+    """dagnn.Sum over two inputs (+ optional fused vl_nnrelu)."""
+    a, b = _chk(a, "A"), _chk(b, "B")
+    if a.shape != b.shape:
+        raise ValueError("dagnn.Sum: input sizes differ")
+    y = mat_empty(*a.shape, device=a.device)
+    _lib.check(_L().xm_sum2(_ptr(a), _ptr(b), a.numel(), 1 if relu else 0, _ptr(y), _stream()))
+    return y
+
+
+def scale_axpy(x, a, r=None, relu=False):
+    """y = a .* x (+ r) (relu): the SE-block excite + residual of SENet50 (mcnExtraLayers)."""
+    x, a = _chk(x, "X"), _chk(a, "A")
+    H, W, Cc, N = _shape4(x)
+    if a.numel() != Cc * N:
+        raise ValueError("scale: A must be 1 x 1 x %d x %d" % (Cc, N))
+    rr = None if r is None else _chk(r, "R")
+    y = mat_empty(H, W, Cc, N, device=x.device)
+    _lib.check(_L().xm_scale_axpy(_ptr(x), H * W, Cc * N, _ptr(a), _ptr(rr), 1 if relu else 0,
+                                  _ptr(y), _stream()))
+    return y
+
+
+def scale_backward(x, a, dzdy, need_dx=True):
+    x, a, dzdy = _chk(x, "X"), _chk(a, "A"), _chk(dzdy, "DZDY")
+    H, W, Cc, N = _shape4(x)
+    dx = mat_empty(H, W, Cc, N, device=x.device) if need_dx else None
+    da = mat_empty(1, 1, Cc, N, device=x.device)
+    _lib.check(_L().xm_scale_backward(_ptr(x), H * W, Cc * N, _ptr(a), _ptr(dzdy), _ptr(dx),
+                                      _ptr(da), _stream()))
+    return dx, da
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+
+
+def vl_nnsoftmaxt(x, temperature=1.0, dim=3):
+    """VL_NNSOFTMAXT(X, 'temperature', T, 'dim', d).  dim is 1-based as in MATLAB."""
+    x = _chk(x, "X")
+    shp = [int(s) for s in x.shape] + [1] * (4 - x.dim())
+    d = int(dim) - 1
+    HW = int(np.prod(shp[:d])) if d > 0 else 1
+    Cc = shp[d]
+    N = int(np.prod(shp[d + 1:])) if d < 3 else 1
+    y = mat_empty(*x.shape, device=x.device)
+    _lib.check(_L().xm_nnsoftmaxt(_ptr(x), HW, Cc, N, float(temperature), _ptr(y), _stream()))
+    return y
+
+
+def vl_nnsoftmax(x):
+    return vl_nnsoftmaxt(x, 1.0, 3)
+
+
+def vl_nnsoftmaxceloss(x, p, dzdy=None, temperature=1.0, logitTargets=False, instanceWeights=None):
+    """VL_NNSOFTMAXCELOSS(X, P [, DZDY], 'temperature', T, 'logitTargets', tf, ...)."""
+    x, p = _chk(x, "X"), _chk(p, "P")
+    H, W, Cc, N = _shape4(x)
+    if H != 1 or W != 1:
+        raise ValueError("vl_nnsoftmaxceloss: X must be 1 x 1 x C x N")
+    if _shape4(p) != [1, 1, Cc, N]:
+        raise ValueError("vl_nnsoftmaxceloss: P must have the size of X")
+    w = None if instanceWeights is None else _chk(instanceWeights, "instanceWeights")
+    if dzdy is None:
+        y = mat_empty(1, 1, device=x.device)
+        _lib.check(_L().xm_nnsoftmaxceloss(_ptr(x), _ptr(p), Cc, N, float(temperature),
+                                           1 if logitTargets else 0, _ptr(w), None, _ptr(y),
+                                           _stream()))
+        return y
+    if not isinstance(dzdy, torch.Tensor):
+        dzdy = from_numpy(np.array([[float(dzdy)]], np.float32), device=x.device)
+    y = mat_empty(1, 1, Cc, N, device=x.device)
+    _lib.check(_L().xm_nnsoftmaxceloss(_ptr(x), _ptr(p), Cc, N, float(temperature),
+                                       1 if logitTargets else 0, _ptr(w), _ptr(dzdy), _ptr(y),
+                                       _stream()))
+    return y
+
+
+_LOSS = {"softmaxlog": 0, "classerror": 1}
+
+
+def vl_nnloss(x, c, dzdy=None, loss="softmaxlog"):
+    """VL_NNLOSS(X, c [, DZDY], 'loss', 'softmaxlog' | 'classerror'); c holds 1-based labels."""
+    x, c = _chk(x, "X"), _chk(c, "C")
+    H, W, Cc, N = _shape4(x)
+    if H != 1 or W != 1:
+        raise ValueError("vl_nnloss: X must be 1 x 1 x C x N")
+    if loss not in _LOSS:
+        raise ValueError("vl_nnloss: unknown loss '%s'" % loss)
+    if c.numel() != N:
+        raise ValueError("vl_nnloss: need one label per sample")
+    if dzdy is None:
+        y = mat_empty(1, 1, device=x.device)
+        _lib.check(_L().xm_nnloss(_ptr(x), _ptr(c), Cc, N, _LOSS[loss], None, _ptr(y), _stream()))
+        return y
+    if not isinstance(dzdy, torch.Tensor):
+        dzdy = from_numpy(np.array([[float(dzdy)]], np.float32), device=x.device)
+    y = mat_empty(1, 1, Cc, N, device=x.device)
+    _lib.check(_L().xm_nnloss(_ptr(x), _ptr(c), Cc, N, _LOSS[loss], _ptr(dzdy), _ptr(y), _stream()))
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser / parameter server
+# --------------------------------------------------------------------------------------------
+
+
+def sgd_update(w, m, der, lr, momentum=0.9, weight_decay=5e-4, batch=1.0):
+    """in-place accumulateGradients step of cnn_train_dag (trainMethod 'gradient')."""
+    _lib.check(_L().xm_sgd_update(_ptr(w), _ptr(m), _ptr(der), w.numel(), float(lr),
+                                  float(momentum), float(weight_decay), float(batch), _stream()))
+
+
+def average_update(w, der, lr, nworkers=1.0):
+    """in-place trainMethod 'average' update (BN moments)."""
+    _lib.check(_L().xm_average_update(_ptr(w), _ptr(der), w.numel(), float(lr), float(nworkers),
+                                      _stream()))
+
+
+# --------------------------------------------------------------------------------------------
+# batch-provider arithmetic
+# --------------------------------------------------------------------------------------------
+
+
+def spec_rownorm(spec):
+    """getBatchEmoVoxCeleb.m:164-169 on the device; spec is H x W x 1 x N."""
+    spec = _chk(spec, "SPEC")
+    H, W, Cc, N = _shape4(spec)
+    out = mat_empty(*spec.shape, device=spec.device)
+    _lib.check(_L().xm_spec_rownorm(_ptr(spec), H, W, Cc * N, _ptr(out), _stream()))
+    return out
+
+
+def aggregate_logits(frame_logits, first, last, agg="max"):
+    """frame_logits F x E (column-major), first/last int32 device vectors (1-based, inclusive).
+    Returns (logitTarget 1 x 1 x E x N, maxLabel 1 x 1 x 1 x N)."""
+    fl = _chk(frame_logits, "LOGITS")
+    Fr, E = int(fl.shape[0]), int(fl.shape[1])
+    N = int(first.numel())
+    out = mat_empty(1, 1, E, N, device=fl.device)
+    lab = mat_empty(1, 1, 1, N, device=fl.device)
+    if agg not in ("max", "mean"):
+        raise ValueError("unreccognised aggregator %s" % agg)
+    _lib.check(_L().xm_aggregate_logits(_ptr(fl), Fr, E, C.c_void_p(first.data_ptr()),
+                                        C.c_void_p(last.data_ptr()), N, 0 if agg == "max" else 1,
+                                        _ptr(out), _ptr(lab), _stream()))
+    return out, lab
+
+
+def normalize_face(rgb, average_image):
+    """fetch_emovoxceleb_imdb.m:176-193: grey -> x3 -> minus averageImage; rgb H x W x 3 x N."""
+    rgb = _chk(rgb, "RGB")
+    H, W, c3, N = _shape4(rgb)
+    if c3 != 3:
+        raise ValueError("normalize_face: expected H x W x 3 x N")
+    avg = (C.c_float * 3)(*[float(v) for v in np.ravel(average_image)[:3]])
+    out = mat_empty(H, W, 3, N, device=rgb.device)
+    _lib.check(_L().xm_normalize_face(_ptr(rgb), H, W, N, avg, _ptr(out), _stream()))
+    return out

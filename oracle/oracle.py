@@ -1,0 +1,286 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/xm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  The product package never imports this module.
+
+Arrays are numpy float32 in MATLAB layout: shape (H, W, C, N), Fortran order.
+Function names and argument meaning follow the MATLAB operators they restate
+(vl_nnconv, vl_nnpool, vl_nnbnorm, ... -- SURVEY.md section 8b).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libxm_oracle.so")
+_lib = None
+
+c_fp = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "xm_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_aud_samples.restype = C.c_double
+        _lib.orc_aud_samples.argtypes = [C.c_int, C.c_double, C.c_double]
+        _lib.orc_time2idx.argtypes = [C.c_double]
+    return _lib
+
+
+def F(a):
+    """float32 Fortran-ordered copy/view (MATLAB `single`)."""
+    return np.asfortranarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_fp)
+
+
+def _shape4(a):
+    s = tuple(a.shape) + (1,) * (4 - a.ndim)
+    return [int(v) for v in s]
+
+
+def _pad4(pad):
+    if np.isscalar(pad):
+        return [int(pad)] * 4
+    pad = list(pad)
+    if len(pad) == 1:
+        return [int(pad[0])] * 4
+    if len(pad) == 2:  # [py px] -> [t b l r]
+        return [int(pad[0]), int(pad[0]), int(pad[1]), int(pad[1])]
+    return [int(v) for v in pad]
+
+
+def _pair(v):
+    if np.isscalar(v):
+        return [int(v), int(v)]
+    v = list(v)
+    return [int(v[0]), int(v[-1])]
+
+
+def conv_out_size(n, pa, pb, f, d, s):
+    return lib().orc_conv_out_size(int(n), int(pa), int(pb), int(f), int(d), int(s))
+
+
+def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, acc64=False,
+              no_der_data=False, no_der_filters=False, no_der_biases=False):
+    x, f = F(x), F(f)
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = _shape4(f)
+    sy, sx = _pair(stride)
+    dy, dx = _pair(dilate)
+    pt, pb, pl, pr = _pad4(pad)
+    Ho = conv_out_size(H, pt, pb, FH, dy, sy)
+    Wo = conv_out_size(W, pl, pr, FW, dx, sx)
+    bb = None if b is None or np.size(b) == 0 else F(np.ravel(b))
+    if dzdy is None:
+        y = np.zeros((Ho, Wo, K, N), np.float32, order="F")
+        rc = lib().orc_nnconv_forward(_p(x), H, W, Cc, N, _p(f), FH, FW, FC, K, _p(bb), _p(y),
+                                      sy, sx, pt, pb, pl, pr, dy, dx, int(acc64))
+        if rc:
+            raise ValueError("vl_nnconv: bad shapes (rc=%d)" % rc)
+        return y
+    dzdy = F(dzdy)
+    assert _shape4(dzdy) == [Ho, Wo, K, N], (dzdy.shape, (Ho, Wo, K, N))
+    dxo = None if no_der_data else np.zeros(x.shape, np.float32, order="F")
+    dfo = None if no_der_filters else np.zeros(f.shape, np.float32, order="F")
+    dbo = None if (no_der_biases or bb is None) else np.zeros(K, np.float32)
+    rc = lib().orc_nnconv_backward(_p(x), H, W, Cc, N, _p(f), FH, FW, FC, K, _p(dzdy), _p(dxo),
+                                   _p(dfo), _p(dbo), sy, sx, pt, pb, pl, pr, dy, dx, int(acc64))
+    if rc:
+        raise ValueError("vl_nnconv: bad shapes (rc=%d)" % rc)
+    return dxo, dfo, dbo
+
+
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max"):
+    x = F(x)
+    H, W, Cc, N = _shape4(x)
+    ph, pw = _pair(pool)
+    sy, sx = _pair(stride)
+    pt, pb, pl, pr = _pad4(pad)
+    m = {"max": 0, "avg": 1}[method]
+    Ho = conv_out_size(H, pt, pb, ph, 1, sy)
+    Wo = conv_out_size(W, pl, pr, pw, 1, sx)
+    if dzdy is None:
+        y = np.zeros((Ho, Wo, Cc, N), np.float32, order="F")
+        rc = lib().orc_nnpool_forward(_p(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr, m, _p(y))
+        assert rc == 0
+        return y
+    dzdy = F(dzdy)
+    dxo = np.zeros(x.shape, np.float32, order="F")
+    rc = lib().orc_nnpool_backward(_p(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr, m,
+                                   _p(dzdy), _p(dxo))
+    assert rc == 0
+    return dxo
+
+
+def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, acc64=False):
+    """forward: returns (y, moments[C,2]); backward: (dx, dg, db, moments)."""
+    x, g, b = F(x), F(np.ravel(g)), F(np.ravel(b))
+    H, W, Cc, N = _shape4(x)
+    mi = None if moments is None else F(np.reshape(moments, (Cc, 2), order="F"))
+    mo = np.zeros((Cc, 2), np.float32, order="F")
+    if dzdy is None:
+        y = np.zeros(x.shape, np.float32, order="F")
+        lib().orc_nnbnorm_forward(_p(x), H, W, Cc, N, _p(g), _p(b), C.c_float(epsilon), _p(mi),
+                                  _p(y), _p(mo), int(acc64))
+        return y, mo
+    dzdy = F(dzdy)
+    dxo = np.zeros(x.shape, np.float32, order="F")
+    dg = np.zeros(Cc, np.float32)
+    db = np.zeros(Cc, np.float32)
+    lib().orc_nnbnorm_backward(_p(x), H, W, Cc, N, _p(g), _p(b), _p(dzdy), C.c_float(epsilon),
+                               _p(mi), _p(dxo), _p(dg), _p(db), _p(mo), int(acc64))
+    return dxo, dg, db, mo
+
+
+def vl_nnrelu(x, dzdy=None, leak=0.0):
+    x = F(x)
+    y = np.zeros(x.shape, np.float32, order="F")
+    d = None if dzdy is None else F(dzdy)
+    lib().orc_nnrelu(_p(x), C.c_size_t(x.size), C.c_float(leak), _p(d), _p(y))
+    return y
+
+
+def vl_nnsigmoid(x, dzdy=None):
+    x = F(x)
+    y = np.zeros(x.shape, np.float32, order="F")
+    d = None if dzdy is None else F(dzdy)
+    lib().orc_nnsigmoid(_p(x), C.c_size_t(x.size), _p(d), _p(y))
+    return y
+
+
+def sum2(a, b, relu=False):
+    a, b = F(a), F(b)
+    y = np.zeros(a.shape, np.float32, order="F")
+    lib().orc_sum2(_p(a), _p(b), C.c_size_t(a.size), int(relu), _p(y))
+    return y
+
+
+def scale_axpy(x, a, r=None, relu=False):
+    x, a = F(x), F(np.ravel(a, order="F"))
+    H, W, Cc, N = _shape4(x)
+    rr = None if r is None else F(r)
+    y = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_scale_axpy(_p(x), C.c_size_t(H * W), C.c_size_t(Cc * N), _p(a), _p(rr), int(relu),
+                         _p(y))
+    return y
+
+
+def scale_backward(x, a, dzdy):
+    x, a, dzdy = F(x), F(np.ravel(a, order="F")), F(dzdy)
+    H, W, Cc, N = _shape4(x)
+    dx = np.zeros(x.shape, np.float32, order="F")
+    da = np.zeros((1, 1, Cc, N), np.float32, order="F")
+    lib().orc_scale_backward(_p(x), C.c_size_t(H * W), C.c_size_t(Cc * N), _p(a), _p(dzdy),
+                             _p(dx), _p(da))
+    return dx, da
+
+
+def vl_nnsoftmaxt(x, temperature=1.0):
+    x = F(x)
+    H, W, Cc, N = _shape4(x)
+    y = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_nnsoftmaxt(_p(x), C.c_size_t(H * W), Cc, N, C.c_float(temperature), _p(y))
+    return y
+
+
+def vl_nnsoftmaxceloss(x, p, dzdy=None, temperature=1.0, logit_targets=False,
+                       instance_weights=None):
+    x, p = F(x), F(p)
+    H, W, Cc, N = _shape4(x)
+    assert H == 1 and W == 1
+    w = None if instance_weights is None else F(np.ravel(instance_weights))
+    if dzdy is None:
+        y = np.zeros(1, np.float32)
+        lib().orc_nnsoftmaxceloss(_p(x), _p(p), Cc, N, C.c_float(temperature), int(logit_targets),
+                                  _p(w), None, _p(y))
+        return y[0]
+    d = F(np.ravel(dzdy))
+    y = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_nnsoftmaxceloss(_p(x), _p(p), Cc, N, C.c_float(temperature), int(logit_targets),
+                              _p(w), _p(d), _p(y))
+    return y
+
+
+def vl_nnloss(x, c, dzdy=None, loss="softmaxlog"):
+    x = F(x)
+    H, W, Cc, N = _shape4(x)
+    assert H == 1 and W == 1
+    lab = F(np.ravel(c))
+    lid = {"softmaxlog": 0, "classerror": 1}[loss]
+    if dzdy is None:
+        y = np.zeros(1, np.float32)
+        lib().orc_nnloss(_p(x), _p(lab), Cc, N, lid, None, _p(y))
+        return y[0]
+    d = F(np.ravel(dzdy))
+    y = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_nnloss(_p(x), _p(lab), Cc, N, lid, _p(d), _p(y))
+    return y
+
+
+def sgd_update(w, m, der, lr, momentum=0.9, wd=5e-4, batch=1.0):
+    """in-place on copies; returns (w, m)."""
+    w, m, der = F(w).copy(order="F"), F(m).copy(order="F"), F(der)
+    lib().orc_sgd_update(_p(w), _p(m), _p(der), C.c_size_t(w.size), C.c_float(lr),
+                         C.c_float(momentum), C.c_float(wd), C.c_float(batch))
+    return w, m
+
+
+def average_update(w, der, lr, nworkers=1.0):
+    w, der = F(w).copy(order="F"), F(der)
+    lib().orc_average_update(_p(w), _p(der), C.c_size_t(w.size), C.c_float(lr), C.c_float(nworkers))
+    return w
+
+
+def spec_rownorm(spec):
+    s = F(spec)
+    if s.ndim == 2:
+        s = s.reshape(s.shape + (1,), order="F")
+    H, W, N = s.shape[0], s.shape[1], int(np.prod(s.shape[2:]))
+    out = np.zeros(s.shape, np.float32, order="F")
+    lib().orc_spec_rownorm(_p(s), H, W, N, _p(out))
+    return out.reshape(np.shape(spec), order="F")
+
+
+def time2idx(t):
+    return lib().orc_time2idx(float(t))
+
+
+def aud_samples(width, Tw_ms=25.0, fs=16000.0):
+    return lib().orc_aud_samples(int(width), float(Tw_ms), float(fs))
+
+
+def aggregate_logits(lg, first, last, agg="max"):
+    lg = F(lg)
+    Fr, E = lg.shape
+    out = np.zeros(E, np.float32)
+    lib().orc_aggregate_logits(_p(lg), Fr, E, int(first), int(last), {"max": 0, "mean": 1}[agg],
+                               _p(out))
+    return out
+
+
+def normalize_face(rgb, avg3):
+    rgb = F(rgb)
+    H, W, c3, N = _shape4(rgb)
+    assert c3 == 3
+    out = np.zeros((H, W, 3, N), np.float32, order="F")
+    a = F(np.ravel(avg3))
+    lib().orc_normalize_face(_p(rgb), H, W, N, _p(a), _p(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,792 @@
+/*
+ * xm_oracle.c -- CPU restatement of the MatConvNet / mcnExtraLayers operator
+ * semantics that albanie/mcnCrossModalEmotions drives on its hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it, and only as the
+ * checker.  The product path (libxmodal_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED.  The reference repo is MATLAB driver code only; every
+ * operator below lives in un-vendored third-party modules that are absent from
+ * /root/reference and carry no version pin there:
+ *     vlfeat/matconvnet      (contemporaneous release v1.0-beta25)
+ *     albanie/mcnExtraLayers (HEAD at install time, setup_mcnCrossModalEmotions.m:9)
+ * The reference holds no tests / golden vectors for them, and neither MATLAB nor
+ * Octave exists in the build image, so the functions here restate the PUBLISHED
+ * algorithms (MatConvNet manual, "Convolutional blocks" / "Pooling" /
+ * "Normalization" chapters and the nnconv/nnpooling/nnbnorm CPU implementations:
+ * im2row + SGEMM per image, direct-loop pooling, two-pass bnorm) and are anchored
+ * on the reference's call sites:
+ *     conv/pool/bnorm/relu via dag.eval        emoVoxCeleb/fetch_emovoxceleb_imdb.m:129
+ *                                              external/compute_audio_feats.m:126
+ *     loss  SoftmaxCELoss(T=2,logitTargets)    emoVoxCeleb/emoVoxZoo.m:152
+ *     loss  softmaxlog / classerror            emoVoxCeleb/emoVoxZoo.m:149,160
+ *     softmaxt                                 emoVoxCeleb/student_stats.m:95
+ *     spectrogram row normalisation            emoVoxCeleb/getBatchEmoVoxCeleb.m:164-169
+ *     time2idx + logit aggregation             emoVoxCeleb/getBatchEmoVoxCeleb.m:145-158,179-188,210-214
+ *     face normalisation                       emoVoxCeleb/fetch_emovoxceleb_imdb.m:176-193
+ *     SGD-momentum (cnn_train_dag defaults)    emoVoxCeleb/run_distillation.m:170-182
+ * The handful of numerical pins the reference *does* hold (pool6 bucket table,
+ * time2idx closed form, audSamp, class order) are checked in tests/test_pins.py.
+ *
+ * Layout everywhere: MATLAB single, H x W x C x N, column-major (H fastest).
+ * Every entry point has an `acc64` flag: 0 = fp32 arithmetic in MatConvNet's
+ * algorithm shape (also the timed "MatConvNet-CPU-equivalent" baseline),
+ * 1 = same maths with fp64 accumulators (error-budget ground truth).
+ */
+#include <float.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define XI(h, w, c, n, H, W, C) \
+  ((size_t)(h) + (size_t)(H) * ((size_t)(w) + (size_t)(W) * ((size_t)(c) + (size_t)(C) * (size_t)(n))))
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static int out_size(int in, int pa, int pb, int f, int dil, int s) {
+  int feff = (f - 1) * dil + 1;
+  int t = in + pa + pb - feff;
+  if (t < 0) return 0;
+  return t / s + 1;
+}
+
+int orc_conv_out_size(int in, int pad_a, int pad_b, int f, int dilate, int stride) {
+  return out_size(in, pad_a, pad_b, f, dilate, stride);
+}
+
+/* ------------------------------------------------------------------ */
+/* small blocked SGEMM pieces (no system BLAS in the image)            */
+/* ------------------------------------------------------------------ */
+
+/* C[m + ldc*n] (+)= sum_k A[m + lda*k] * B[k*bks + n*bns]   (fp32 chain over k) */
+static void gemm_nn(int M, int N, int K, const float *A, int lda, const float *B, size_t bks,
+                    size_t bns, float *C, int ldc, int accumulate) {
+  enum { MB = 16, NB = 4 };
+  int nmb = (M + MB - 1) / MB, nnb = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int ib = 0; ib < nmb; ++ib)
+    for (int jb = 0; jb < nnb; ++jb) {
+      int m0 = ib * MB, n0 = jb * NB;
+      int mb = M - m0 < MB ? M - m0 : MB, nb = N - n0 < NB ? N - n0 : NB;
+      float acc[NB][MB];
+      for (int j = 0; j < NB; ++j)
+        for (int i = 0; i < MB; ++i)
+          acc[j][i] = (accumulate && j < nb && i < mb) ? C[m0 + i + (size_t)ldc * (n0 + j)] : 0.f;
+      if (mb == MB && nb == NB) {
+        for (int k = 0; k < K; ++k) {
+          const float *a = A + m0 + (size_t)lda * k;
+          for (int j = 0; j < NB; ++j) {
+            float bj = B[k * bks + (n0 + j) * bns];
+            for (int i = 0; i < MB; ++i) acc[j][i] += a[i] * bj;
+          }
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          const float *a = A + m0 + (size_t)lda * k;
+          for (int j = 0; j < nb; ++j) {
+            float bj = B[k * bks + (n0 + j) * bns];
+            for (int i = 0; i < mb; ++i) acc[j][i] += a[i] * bj;
+          }
+        }
+      }
+      for (int j = 0; j < nb; ++j)
+        for (int i = 0; i < mb; ++i) C[m0 + i + (size_t)ldc * (n0 + j)] = acc[j][i];
+    }
+}
+
+/* C[r + ldc*n] += sum_p A[p + lda*r] * B[p + ldb*n]   (A^T B, reduction over contiguous p) */
+static void gemm_tn_acc(int R, int N, int P, const float *A, int lda, const float *B, int ldb,
+                        float *C, int ldc) {
+  enum { RB = 4, NB = 2, V = 8 };
+  int nrb = (R + RB - 1) / RB, nnb = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int ib = 0; ib < nrb; ++ib)
+    for (int jb = 0; jb < nnb; ++jb) {
+      int r0 = ib * RB, n0 = jb * NB;
+      int rb = R - r0 < RB ? R - r0 : RB, nb = N - n0 < NB ? N - n0 : NB;
+      float acc[NB][RB][V];
+      memset(acc, 0, sizeof acc);
+      int p = 0;
+      for (; p + V <= P; p += V)
+        for (int j = 0; j < nb; ++j)
+          for (int i = 0; i < rb; ++i) {
+            const float *a = A + p + (size_t)lda * (r0 + i);
+            const float *b = B + p + (size_t)ldb * (n0 + j);
+            for (int v = 0; v < V; ++v) acc[j][i][v] += a[v] * b[v];
+          }
+      for (int j = 0; j < nb; ++j)
+        for (int i = 0; i < rb; ++i) {
+          float s = 0.f;
+          for (int v = 0; v < V; ++v) s += acc[j][i][v];
+          for (int q = p; q < P; ++q)
+            s += A[q + (size_t)lda * (r0 + i)] * B[q + (size_t)ldb * (n0 + j)];
+          C[r0 + i + (size_t)ldc * (n0 + j)] += s;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* vl_nnconv                                                           */
+/* ------------------------------------------------------------------ */
+
+/* im2row of one image / one filter group: col[p + P*(u + FH*(v + FW*c))] */
+static void im2row(const float *x, int H, int W, int FC, int FH, int FW, int sy, int sx, int pt,
+                   int pl, int dy, int dx, int Ho, int Wo, float *col) {
+  size_t P = (size_t)Ho * Wo;
+  int R = FH * FW * FC;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < R; ++r) {
+    int u = r % FH, v = (r / FH) % FW, c = r / (FH * FW);
+    float *dst = col + P * r;
+    for (int wo = 0; wo < Wo; ++wo) {
+      int wi = wo * sx - pl + v * dx;
+      for (int ho = 0; ho < Ho; ++ho) {
+        int hi = ho * sy - pt + u * dy;
+        float val = 0.f;
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) val = x[XI(hi, wi, c, 0, H, W, FC)];
+        dst[ho + (size_t)Ho * wo] = val;
+      }
+    }
+  }
+}
+
+/* row2im: scatter-add dcol back into dx (one image / one group) */
+static void row2im_add(const float *col, int H, int W, int FC, int FH, int FW, int sy, int sx,
+                       int pt, int pl, int dy, int dx, int Ho, int Wo, float *xg) {
+  size_t P = (size_t)Ho * Wo;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < FC; ++c)
+    for (int v = 0; v < FW; ++v)
+      for (int u = 0; u < FH; ++u) {
+        const float *src = col + P * (u + FH * (v + FW * c));
+        for (int wo = 0; wo < Wo; ++wo) {
+          int wi = wo * sx - pl + v * dx;
+          if (wi < 0 || wi >= W) continue;
+          for (int ho = 0; ho < Ho; ++ho) {
+            int hi = ho * sy - pt + u * dy;
+            if (hi < 0 || hi >= H) continue;
+            xg[XI(hi, wi, c, 0, H, W, FC)] += src[ho + (size_t)Ho * wo];
+          }
+        }
+      }
+}
+
+/*
+ * Y = vl_nnconv(X, F, B, 'stride', [sy sx], 'pad', [pt pb pl pr], 'dilate', [dy dx])
+ * X: H x W x C x N, F: FH x FW x FC x K (groups G = C / FC), B: K (may be NULL).
+ * Cross-correlation, zero padding.  Returns 0, or -1 on a shape error.
+ */
+int orc_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                       int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                       int pl, int pr, int dy, int dx, int acc64) {
+  if (FC <= 0 || C % FC) return -1;
+  int G = C / FC;
+  if (K % G) return -1;
+  int Kg = K / G;
+  int Ho = out_size(H, pt, pb, FH, dy, sy), Wo = out_size(W, pl, pr, FW, dx, sx);
+  if (Ho <= 0 || Wo <= 0) return -1;
+  size_t P = (size_t)Ho * Wo;
+  int R = FH * FW * FC;
+  if (acc64) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) {
+        int g = k / Kg;
+        for (int wo = 0; wo < Wo; ++wo)
+          for (int ho = 0; ho < Ho; ++ho) {
+            double acc = b ? (double)b[k] : 0.0;
+            for (int c = 0; c < FC; ++c)
+              for (int v = 0; v < FW; ++v) {
+                int wi = wo * sx - pl + v * dx;
+                if (wi < 0 || wi >= W) continue;
+                for (int u = 0; u < FH; ++u) {
+                  int hi = ho * sy - pt + u * dy;
+                  if (hi < 0 || hi >= H) continue;
+                  acc += (double)x[XI(hi, wi, g * FC + c, n, H, W, C)] *
+                         (double)f[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))];
+                }
+              }
+            y[XI(ho, wo, k, n, Ho, Wo, K)] = (float)acc;
+          }
+      }
+    return 0;
+  }
+  float *col = (float *)malloc(sizeof(float) * P * R);
+  if (!col) return -2;
+  for (int n = 0; n < N; ++n)
+    for (int g = 0; g < G; ++g) {
+      im2row(x + XI(0, 0, g * FC, n, H, W, C), H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
+             col);
+      float *yg = y + XI(0, 0, g * Kg, n, Ho, Wo, K);
+      /* bias first (MatConvNet: rank-1 GEMM with a ones vector), then accumulate */
+      for (int k = 0; k < Kg; ++k) {
+        float bv = b ? b[g * Kg + k] : 0.f;
+        float *yk = yg + P * k;
+        for (size_t p = 0; p < P; ++p) yk[p] = bv;
+      }
+      gemm_nn((int)P, Kg, R, col, (int)P, f + (size_t)R * g * Kg, 1, (size_t)R, yg, (int)P, 1);
+    }
+  free(col);
+  return 0;
+}
+
+/*
+ * [DX, DF, DB] = vl_nnconv(X, F, B, DZDY, ...).  Any of dxo/dfo/dbo may be NULL
+ * (NoDerData / NoDerFilters / NoDerBiases).
+ */
+int orc_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                        int FC, int K, const float *dzdy, float *dxo, float *dfo, float *dbo,
+                        int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx,
+                        int acc64) {
+  if (FC <= 0 || C % FC) return -1;
+  int G = C / FC;
+  if (K % G) return -1;
+  int Kg = K / G;
+  int Ho = out_size(H, pt, pb, FH, dy, sy), Wo = out_size(W, pl, pr, FW, dx, sx);
+  if (Ho <= 0 || Wo <= 0) return -1;
+  size_t P = (size_t)Ho * Wo;
+  int R = FH * FW * FC;
+  if (dbo) {
+    for (int k = 0; k < K; ++k) {
+      if (acc64) {
+        double s = 0;
+        for (int n = 0; n < N; ++n) {
+          const float *d = dzdy + XI(0, 0, k, n, Ho, Wo, K);
+          for (size_t p = 0; p < P; ++p) s += d[p];
+        }
+        dbo[k] = (float)s;
+      } else {
+        float s = 0;
+        for (int n = 0; n < N; ++n) {
+          const float *d = dzdy + XI(0, 0, k, n, Ho, Wo, K);
+          float si = 0;
+          for (size_t p = 0; p < P; ++p) si += d[p];
+          s += si;
+        }
+        dbo[k] = s;
+      }
+    }
+  }
+  if (acc64) {
+    if (dfo) {
+#pragma omp parallel for collapse(2) schedule(static)
+      for (int k = 0; k < K; ++k)
+        for (int c = 0; c < FC; ++c) {
+          int g = k / Kg;
+          for (int v = 0; v < FW; ++v)
+            for (int u = 0; u < FH; ++u) {
+              double acc = 0;
+              for (int n = 0; n < N; ++n)
+                for (int wo = 0; wo < Wo; ++wo) {
+                  int wi = wo * sx - pl + v * dx;
+                  if (wi < 0 || wi >= W) continue;
+                  for (int ho = 0; ho < Ho; ++ho) {
+                    int hi = ho * sy - pt + u * dy;
+                    if (hi < 0 || hi >= H) continue;
+                    acc += (double)x[XI(hi, wi, g * FC + c, n, H, W, C)] *
+                           (double)dzdy[XI(ho, wo, k, n, Ho, Wo, K)];
+                  }
+                }
+              dfo[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))] = (float)acc;
+            }
+        }
+    }
+    if (dxo) {
+#pragma omp parallel for collapse(2) schedule(static)
+      for (int n = 0; n < N; ++n)
+        for (int ci = 0; ci < C; ++ci) {
+          int g = ci / FC, c = ci % FC;
+          for (int wi = 0; wi < W; ++wi)
+            for (int hi = 0; hi < H; ++hi) {
+              double acc = 0;
+              for (int kk = 0; kk < Kg; ++kk) {
+                int k = g * Kg + kk;
+                for (int v = 0; v < FW; ++v) {
+                  int tw = wi + pl - v * dx;
+                  if (tw < 0 || tw % sx) continue;
+                  int wo = tw / sx;
+                  if (wo >= Wo) continue;
+                  for (int u = 0; u < FH; ++u) {
+                    int th = hi + pt - u * dy;
+                    if (th < 0 || th % sy) continue;
+                    int ho = th / sy;
+                    if (ho >= Ho) continue;
+                    acc += (double)dzdy[XI(ho, wo, k, n, Ho, Wo, K)] *
+                           (double)f[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))];
+                  }
+                }
+              }
+              dxo[XI(hi, wi, ci, n, H, W, C)] = (float)acc;
+            }
+        }
+    }
+    return 0;
+  }
+  float *col = (float *)malloc(sizeof(float) * P * R);
+  if (!col) return -2;
+  if (dfo) memset(dfo, 0, sizeof(float) * (size_t)R * K);
+  if (dxo) memset(dxo, 0, sizeof(float) * (size_t)H * W * C * N);
+  for (int n = 0; n < N; ++n)
+    for (int g = 0; g < G; ++g) {
+      const float *dyg = dzdy + XI(0, 0, g * Kg, n, Ho, Wo, K);
+      if (dfo) {
+        im2row(x + XI(0, 0, g * FC, n, H, W, C), H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
+               col);
+        gemm_tn_acc(R, Kg, (int)P, col, (int)P, dyg, (int)P, dfo + (size_t)R * g * Kg, R);
+      }
+      if (dxo) {
+        /* dcol[p, r] = sum_k dy[p, k] * f[r, k] */
+        gemm_nn((int)P, R, Kg, dyg, (int)P, f + (size_t)R * g * Kg, (size_t)R, 1, col, (int)P, 0);
+        row2im_add(col, H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
+                   dxo + XI(0, 0, g * FC, n, H, W, C));
+      }
+    }
+  free(col);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* vl_nnpool                                                           */
+/* ------------------------------------------------------------------ */
+/* method: 0 = max (padding = -inf), 1 = avg (divide by the CLIPPED window area).
+ * Window scan order is column-major (w outer, h inner) as in MatConvNet's
+ * pooling_cpu; max-backward routes to the FIRST maximum in that order. */
+int orc_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                       int pt, int pb, int pl, int pr, int method, float *y) {
+  int Ho = out_size(H, pt, pb, ph, 1, sy), Wo = out_size(W, pl, pr, pw, 1, sx);
+  if (Ho <= 0 || Wo <= 0) return -1;
+#pragma omp parallel for schedule(static)
+  for (long cn = 0; cn < (long)C * N; ++cn) {
+    const float *xp = x + (size_t)H * W * cn;
+    float *yp = y + (size_t)Ho * Wo * cn;
+    for (int wo = 0; wo < Wo; ++wo)
+      for (int ho = 0; ho < Ho; ++ho) {
+        int w1 = wo * sx - pl, h1 = ho * sy - pt;
+        int w2 = w1 + pw < W ? w1 + pw : W, h2 = h1 + ph < H ? h1 + ph : H;
+        if (w1 < 0) w1 = 0;
+        if (h1 < 0) h1 = 0;
+        if (method == 0) {
+          float m = -INFINITY;
+          for (int w = w1; w < w2; ++w)
+            for (int h = h1; h < h2; ++h) {
+              float v = xp[h + (size_t)H * w];
+              if (v > m) m = v;
+            }
+          yp[ho + (size_t)Ho * wo] = m;
+        } else {
+          float s = 0.f;
+          for (int w = w1; w < w2; ++w)
+            for (int h = h1; h < h2; ++h) s += xp[h + (size_t)H * w];
+          yp[ho + (size_t)Ho * wo] = s * (1.0f / (float)((h2 - h1) * (w2 - w1)));
+        }
+      }
+  }
+  return 0;
+}
+
+int orc_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                        int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dxo) {
+  int Ho = out_size(H, pt, pb, ph, 1, sy), Wo = out_size(W, pl, pr, pw, 1, sx);
+  if (Ho <= 0 || Wo <= 0) return -1;
+  memset(dxo, 0, sizeof(float) * (size_t)H * W * C * N);
+#pragma omp parallel for schedule(static)
+  for (long cn = 0; cn < (long)C * N; ++cn) {
+    const float *xp = x + (size_t)H * W * cn;
+    const float *dp = dzdy + (size_t)Ho * Wo * cn;
+    float *gp = dxo + (size_t)H * W * cn;
+    for (int wo = 0; wo < Wo; ++wo)
+      for (int ho = 0; ho < Ho; ++ho) {
+        int w1 = wo * sx - pl, h1 = ho * sy - pt;
+        int w2 = w1 + pw < W ? w1 + pw : W, h2 = h1 + ph < H ? h1 + ph : H;
+        if (w1 < 0) w1 = 0;
+        if (h1 < 0) h1 = 0;
+        float d = dp[ho + (size_t)Ho * wo];
+        if (method == 0) {
+          float m = -INFINITY;
+          long arg = -1;
+          for (int w = w1; w < w2; ++w)
+            for (int h = h1; h < h2; ++h) {
+              float v = xp[h + (size_t)H * w];
+              if (v > m) {
+                m = v;
+                arg = h + (long)H * w;
+              }
+            }
+          if (arg >= 0) gp[arg] += d;
+        } else {
+          float sc = d * (1.0f / (float)((h2 - h1) * (w2 - w1)));
+          for (int w = w1; w < w2; ++w)
+            for (int h = h1; h < h2; ++h) gp[h + (size_t)H * w] += sc;
+        }
+      }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* vl_nnbnorm                                                          */
+/* ------------------------------------------------------------------ */
+/* moments: C x 2 column-major = [mean(0..C-1), sigma(0..C-1)], sigma = sqrt(var_biased + eps).
+ * moments_in == NULL  -> train mode (batch moments, returned through moments_out if non-NULL)
+ * moments_in != NULL  -> test mode  (stored moments used as constants) */
+static void bn_moments(const float *x, size_t HW, int C, int N, float eps, int acc64, float *mom) {
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < C; ++c) {
+    double m = (double)HW * N;
+    if (acc64) {
+      double s = 0, ss = 0;
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        for (size_t i = 0; i < HW; ++i) s += p[i];
+      }
+      double mu = s / m;
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        for (size_t i = 0; i < HW; ++i) ss += ((double)p[i] - mu) * ((double)p[i] - mu);
+      }
+      mom[c] = (float)mu;
+      mom[C + c] = (float)sqrt(ss / m + (double)eps);
+    } else {
+      /* MatConvNet CPU: accumulate sum and sum of squares in one pass, fp32 */
+      float s = 0.f, ss = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        float si = 0.f, ssi = 0.f;
+        for (size_t i = 0; i < HW; ++i) {
+          si += p[i];
+          ssi += p[i] * p[i];
+        }
+        s += si;
+        ss += ssi;
+      }
+      float mu = s / (float)m;
+      float var = ss / (float)m - mu * mu;
+      if (var < 0.f) var = 0.f;
+      mom[c] = mu;
+      mom[C + c] = sqrtf(var + eps);
+    }
+  }
+}
+
+int orc_nnbnorm_forward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                        float eps, const float *moments_in, float *y, float *moments_out,
+                        int acc64) {
+  size_t HW = (size_t)H * W;
+  float *mom = (float *)malloc(sizeof(float) * 2 * C);
+  if (moments_in)
+    memcpy(mom, moments_in, sizeof(float) * 2 * C);
+  else
+    bn_moments(x, HW, C, N, eps, acc64, mom);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      const float *p = x + HW * ((size_t)c + (size_t)C * n);
+      float *q = y + HW * ((size_t)c + (size_t)C * n);
+      if (acc64) {
+        double sc = (double)g[c] / (double)mom[C + c], mu = mom[c], bb = b[c];
+        for (size_t i = 0; i < HW; ++i) q[i] = (float)(sc * ((double)p[i] - mu) + bb);
+      } else {
+        float sc = g[c] / mom[C + c], mu = mom[c], bb = b[c];
+        for (size_t i = 0; i < HW; ++i) q[i] = sc * (p[i] - mu) + bb;
+      }
+    }
+  if (moments_out) memcpy(moments_out, mom, sizeof(float) * 2 * C);
+  free(mom);
+  return 0;
+}
+
+int orc_nnbnorm_backward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                         const float *dzdy, float eps, const float *moments_in, float *dxo,
+                         float *dgo, float *dbo, float *moments_out, int acc64) {
+  (void)b;
+  size_t HW = (size_t)H * W;
+  double m = (double)HW * N;
+  float *mom = (float *)malloc(sizeof(float) * 2 * C);
+  if (moments_in)
+    memcpy(mom, moments_in, sizeof(float) * 2 * C);
+  else
+    bn_moments(x, HW, C, N, eps, acc64, mom);
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < C; ++c) {
+    double mu = mom[c], sg = mom[C + c];
+    double sdy = 0, sdyx = 0;
+    if (acc64) {
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        const float *d = dzdy + HW * ((size_t)c + (size_t)C * n);
+        for (size_t i = 0; i < HW; ++i) {
+          sdy += d[i];
+          sdyx += (double)d[i] * ((double)p[i] - mu);
+        }
+      }
+    } else {
+      float fs = 0.f, fsx = 0.f, fmu = mom[c];
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        const float *d = dzdy + HW * ((size_t)c + (size_t)C * n);
+        float a = 0.f, bx = 0.f;
+        for (size_t i = 0; i < HW; ++i) {
+          a += d[i];
+          bx += d[i] * (p[i] - fmu);
+        }
+        fs += a;
+        fsx += bx;
+      }
+      sdy = fs;
+      sdyx = fsx;
+    }
+    double dg = sdyx / sg; /* sum dzdy * xhat */
+    if (dgo) dgo[c] = (float)dg;
+    if (dbo) dbo[c] = (float)sdy;
+    if (dxo) {
+      double gs = (double)g[c] / sg;
+      for (int n = 0; n < N; ++n) {
+        const float *p = x + HW * ((size_t)c + (size_t)C * n);
+        const float *d = dzdy + HW * ((size_t)c + (size_t)C * n);
+        float *q = dxo + HW * ((size_t)c + (size_t)C * n);
+        if (moments_in) {
+          for (size_t i = 0; i < HW; ++i) q[i] = (float)(gs * (double)d[i]);
+        } else if (acc64) {
+          for (size_t i = 0; i < HW; ++i) {
+            double xh = ((double)p[i] - mu) / sg;
+            q[i] = (float)(gs * ((double)d[i] - sdy / m - xh * dg / m));
+          }
+        } else {
+          float fgs = (float)gs, c1 = (float)(sdy / m), c2 = (float)(dg / (m * sg)), fmu = mom[c];
+          for (size_t i = 0; i < HW; ++i) q[i] = fgs * (d[i] - c1 - (p[i] - fmu) * c2);
+        }
+      }
+    }
+  }
+  if (moments_out) memcpy(moments_out, mom, sizeof(float) * 2 * C);
+  free(mom);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, SE scale / axpy     */
+/* ------------------------------------------------------------------ */
+void orc_nnrelu(const float *x, size_t n, float leak, const float *dzdy, float *y) {
+  if (!dzdy)
+    for (size_t i = 0; i < n; ++i) y[i] = x[i] > 0.f ? x[i] : leak * x[i];
+  else
+    for (size_t i = 0; i < n; ++i) y[i] = x[i] > 0.f ? dzdy[i] : leak * dzdy[i];
+}
+
+void orc_nnsigmoid(const float *x, size_t n, const float *dzdy, float *y) {
+  for (size_t i = 0; i < n; ++i) {
+    float s = 1.f / (1.f + expf(-x[i]));
+    y[i] = dzdy ? dzdy[i] * s * (1.f - s) : s;
+  }
+}
+
+/* y = sum_i x_i  (dagnn.Sum with two inputs), optional fused relu */
+void orc_sum2(const float *a, const float *b, size_t n, int relu, float *y) {
+  for (size_t i = 0; i < n; ++i) {
+    float v = a[i] + b[i];
+    y[i] = (relu && v < 0.f) ? 0.f : v;
+  }
+}
+
+/* SE excite: y(h,w,c,n) = a(c,n) * x(h,w,c,n) [+ r(h,w,c,n)] [relu]   (mcnExtraLayers Scale / Axpy) */
+void orc_scale_axpy(const float *x, size_t HW, size_t CN, const float *a, const float *r, int relu,
+                    float *y) {
+  for (size_t j = 0; j < CN; ++j)
+    for (size_t i = 0; i < HW; ++i) {
+      float v = a[j] * x[HW * j + i] + (r ? r[HW * j + i] : 0.f);
+      y[HW * j + i] = (relu && v < 0.f) ? 0.f : v;
+    }
+}
+
+/* backward of y = a .* x (+ r): dx = a .* dy ; da(c,n) = sum_hw dy .* x ; dr = dy */
+void orc_scale_backward(const float *x, size_t HW, size_t CN, const float *a, const float *dzdy,
+                        float *dxo, float *dao) {
+  for (size_t j = 0; j < CN; ++j) {
+    double s = 0;
+    for (size_t i = 0; i < HW; ++i) {
+      if (dxo) dxo[HW * j + i] = a[j] * dzdy[HW * j + i];
+      s += (double)dzdy[HW * j + i] * (double)x[HW * j + i];
+    }
+    if (dao) dao[j] = (float)s;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* softmax family (dim 3 = channels), losses                           */
+/* ------------------------------------------------------------------ */
+/* vl_nnsoftmaxt(X, 'temperature', T) along channels; x: HW x C x N viewed as [i + HW*(c + C*n)] */
+void orc_nnsoftmaxt(const float *x, size_t HW, int C, int N, float T, float *y) {
+  for (int n = 0; n < N; ++n)
+    for (size_t i = 0; i < HW; ++i) {
+      const float *p = x + i + HW * (size_t)C * n;
+      float *q = y + i + HW * (size_t)C * n;
+      double mx = -INFINITY, s = 0;
+      for (int c = 0; c < C; ++c)
+        if (p[HW * c] / T > mx) mx = p[HW * c] / T;
+      for (int c = 0; c < C; ++c) s += exp((double)p[HW * c] / T - mx);
+      for (int c = 0; c < C; ++c) q[HW * c] = (float)(exp((double)p[HW * c] / T - mx) / s);
+    }
+}
+
+/*
+ * vl_nnsoftmaxceloss(X, P, [DZDY], 'temperature', T, 'logitTargets', tf, 'instanceWeights', w)
+ * X, P: 1 x 1 x C x N.   q = softmax(X/T);  p = logitTargets ? softmax(P/T) : P
+ *   forward : Y = sum_n w_n * ( -sum_c p_c log q_c )          (summed over the batch)
+ *   backward: dX = dzdy * w_n * (q - p * sum_c p_c... ) / T   -- with sum_c p_c = 1: (q - p)/T
+ * (SURVEY Appendix A.6 decision: sum over batch, 1/T in the gradient, no T^2, log-sum-exp form)
+ */
+void orc_nnsoftmaxceloss(const float *x, const float *p, int C, int N, float T, int logit_targets,
+                         const float *w, const float *dzdy, float *y /* 1 value or C*N grads */) {
+  double total = 0;
+  for (int n = 0; n < N; ++n) {
+    const float *xn = x + (size_t)C * n, *pn = p + (size_t)C * n;
+    double pt[64], mx = -INFINITY, s = 0, psum = 0;
+    if (logit_targets) {
+      double mp = -INFINITY, sp = 0;
+      for (int c = 0; c < C; ++c)
+        if (pn[c] / T > mp) mp = pn[c] / T;
+      for (int c = 0; c < C; ++c) sp += exp((double)pn[c] / T - mp);
+      for (int c = 0; c < C; ++c) pt[c] = exp((double)pn[c] / T - mp) / sp;
+    } else
+      for (int c = 0; c < C; ++c) pt[c] = pn[c];
+    for (int c = 0; c < C; ++c) {
+      if (xn[c] / T > mx) mx = xn[c] / T;
+      psum += pt[c];
+    }
+    for (int c = 0; c < C; ++c) s += exp((double)xn[c] / T - mx);
+    double lse = mx + log(s);
+    double wn = w ? w[n] : 1.0;
+    if (!dzdy) {
+      double l = 0;
+      for (int c = 0; c < C; ++c) l += pt[c] * (lse - (double)xn[c] / T);
+      total += wn * l;
+    } else {
+      for (int c = 0; c < C; ++c) {
+        double q = exp((double)xn[c] / T - lse);
+        y[(size_t)C * n + c] = (float)((double)dzdy[0] * wn * (q * psum - pt[c]) / T);
+      }
+    }
+  }
+  if (!dzdy) y[0] = (float)total;
+}
+
+/* vl_nnloss(X, c, [DZDY], 'loss', 'softmaxlog' (0) | 'classerror' (1)); labels are 1-based */
+void orc_nnloss(const float *x, const float *labels, int C, int N, int loss, const float *dzdy,
+                float *y) {
+  double total = 0;
+  for (int n = 0; n < N; ++n) {
+    const float *xn = x + (size_t)C * n;
+    int c0 = (int)labels[n] - 1;
+    double mx = -INFINITY, s = 0;
+    int arg = 0;
+    for (int c = 0; c < C; ++c)
+      if (xn[c] > mx) {
+        mx = xn[c];
+        arg = c;
+      }
+    for (int c = 0; c < C; ++c) s += exp((double)xn[c] - mx);
+    if (loss == 0) {
+      if (!dzdy)
+        total += mx + log(s) - (double)xn[c0];
+      else
+        for (int c = 0; c < C; ++c)
+          y[(size_t)C * n + c] =
+              (float)((double)dzdy[0] * (exp((double)xn[c] - mx) / s - (c == c0 ? 1.0 : 0.0)));
+    } else {
+      if (!dzdy)
+        total += (arg != c0);
+      else
+        for (int c = 0; c < C; ++c) y[(size_t)C * n + c] = 0.f;
+    }
+  }
+  if (!dzdy) y[0] = (float)total;
+}
+
+/* ------------------------------------------------------------------ */
+/* cnn_train_dag accumulateGradients (solver = [], SGD with momentum)   */
+/* ------------------------------------------------------------------ */
+/* m <- mu*m - (wd*w + der/B) ;  w <- w + lr*m          (trainMethod 'gradient')
+ * w <- (1-lr)*w + lr*der/nworkers                        (trainMethod 'average', BN moments) */
+void orc_sgd_update(float *w, float *m, const float *der, size_t n, float lr, float momentum,
+                    float wd, float batch) {
+  for (size_t i = 0; i < n; ++i) {
+    m[i] = momentum * m[i] - (wd * w[i] + der[i] / batch);
+    w[i] = w[i] + lr * m[i];
+  }
+}
+
+void orc_average_update(float *w, const float *der, size_t n, float lr, float nworkers) {
+  for (size_t i = 0; i < n; ++i) w[i] = (1.f - lr) * w[i] + lr * (der[i] / nworkers);
+}
+
+/* ------------------------------------------------------------------ */
+/* batch-provider maths (the parts of getBatchEmoVoxCeleb that are arithmetic) */
+/* ------------------------------------------------------------------ */
+/* getBatchEmoVoxCeleb.m:164-169: per-row (frequency) mean / UNBIASED std over time */
+void orc_spec_rownorm(const float *spec, int H, int W, int N, float *out) {
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h) {
+      const float *p = spec + h + (size_t)H * W * n;
+      float *q = out + h + (size_t)H * W * n;
+      double s = 0, ss = 0;
+      for (int w = 0; w < W; ++w) s += p[(size_t)H * w];
+      double mu = s / W;
+      for (int w = 0; w < W; ++w) ss += (p[(size_t)H * w] - mu) * (p[(size_t)H * w] - mu);
+      double sd = sqrt(ss / (W - 1));
+      for (int w = 0; w < W; ++w) q[(size_t)H * w] = (float)(((double)p[(size_t)H * w] - mu) / sd);
+    }
+}
+
+/* getBatchEmoVoxCeleb.m:210-214 */
+int orc_time2idx(double t) {
+  double v = t * 25.0 - 1.0;
+  if (v < 0) v = 0;
+  return (int)floor(v / 6.0) + 1;
+}
+
+/* getBatchEmoVoxCeleb.m:67-68 */
+double orc_aud_samples(int width, double Tw_ms, double fs) {
+  return (0.01 * width + 0.001 * Tw_ms - 0.001) * fs;
+}
+
+/* getBatchEmoVoxCeleb.m:179-188: aggregate F x E frame logits (column-major) over frames
+ * [first,last] (1-based, inclusive) -> E values; agg 0 = max, 1 = mean */
+void orc_aggregate_logits(const float *lg, int F, int E, int first, int last, int agg, float *out) {
+  if (last > F) last = F;
+  for (int e = 0; e < E; ++e) {
+    double a = agg == 0 ? -INFINITY : 0;
+    for (int fr = first - 1; fr < last; ++fr) {
+      double v = lg[fr + (size_t)F * e];
+      if (agg == 0)
+        a = v > a ? v : a;
+      else
+        a += v;
+    }
+    out[e] = (float)(agg == 0 ? a : a / (last - first + 1));
+  }
+}
+
+/* fetch_emovoxceleb_imdb.m:176-193: rgb2gray -> replicate x3 -> subtract averageImage(c).
+ * rgb: H x W x 3 x N uint8-valued floats. rgb2gray weights 0.2989/0.5870/0.1140, rounded (uint8). */
+void orc_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out) {
+  size_t HW = (size_t)H * W;
+  for (int n = 0; n < N; ++n)
+    for (size_t i = 0; i < HW; ++i) {
+      const float *p = rgb + i + HW * 3 * n;
+      float gr = 0.2989f * p[0] + 0.5870f * p[HW] + 0.1140f * p[2 * HW];
+      gr = floorf(gr + 0.5f);
+      if (gr > 255.f) gr = 255.f;
+      for (int c = 0; c < 3; ++c) out[i + HW * (c + 3 * (size_t)n)] = gr - avg3[c];
+    }
+}

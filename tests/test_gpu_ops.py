@@ -1,0 +1,261 @@
+"""GPU parity: every HIP operator (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (fp32 path, north_star: 1e-4): |hip - oracle| <= TOL * max(1, max|oracle|), where the
+oracle is the fp64-accumulate restatement, so the bound covers the HIP kernel's own fp32
+round-off (an fmaf chain in MFMA k-order) and nothing else.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL, what=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    err = float(np.abs(a - b).max()) if b.size else 0.0
+    assert err <= tol * scale, "%s: max err %.3e > %.1e * %.3g" % (what, err, tol, scale)
+
+
+def rnd(rng, *shape):
+    return O.F(rng.standard_normal(shape))
+
+
+# (H, W, C, N, FH, FW, FC, K, stride, pad, dilate)
+CONV_CASES = [
+    (12, 9, 5, 2, 3, 3, 5, 7, (1, 1), (1, 1, 1, 1), (1, 1)),       # 3x3 same
+    (20, 17, 1, 3, 7, 7, 1, 10, (2, 2), (1, 1, 1, 1), (1, 1)),     # student conv1 shape (C=1)
+    (21, 18, 6, 2, 5, 5, 6, 9, (2, 2), (1, 1, 1, 1), (1, 1)),      # student conv2 shape
+    (9, 8, 16, 4, 9, 1, 16, 40, (1, 1), (0, 0, 0, 0), (1, 1)),     # fc6: 9x1 conv
+    (1, 1, 48, 5, 1, 1, 48, 8, (1, 1), (0, 0, 0, 0), (1, 1)),      # fc7/fc8: 1x1 on 1x1
+    (14, 14, 32, 2, 1, 1, 32, 64, (2, 2), (0, 0, 0, 0), (1, 1)),   # resnet 1x1 stride 2
+    (15, 13, 3, 2, 7, 7, 3, 8, (2, 2), (3, 3, 3, 3), (1, 1)),      # teacher conv1
+    (11, 10, 4, 2, 3, 2, 4, 6, (2, 3), (0, 1, 2, 0), (1, 1)),      # asymmetric everything
+    (13, 12, 4, 2, 3, 3, 4, 6, (1, 1), (2, 2, 2, 2), (2, 2)),      # dilation
+    (10, 9, 8, 2, 3, 3, 4, 6, (1, 1), (1, 1, 1, 1), (1, 1)),       # 2 filter groups
+    (10, 11, 6, 2, 3, 3, 6, 5, (3, 2), (1, 0, 0, 1), (1, 1)),      # stride 3x2
+    (40, 33, 20, 3, 3, 3, 20, 150, (1, 1), (1, 1, 1, 1), (1, 1)),  # multi-tile M and pixels
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward(gpu, case):
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N, FH, FW, FC, K, stride, pad, dil = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, FH, FW, FC, K), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, stride=stride, pad=pad, dilate=dil, acc64=True)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+    y = vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad, dilate=dil)
+    close(vl.to_numpy(y), y_ref, what="conv fwd")
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, df_ref, db_ref = O.vl_nnconv(x, f, b, dzdy, stride=stride, pad=pad, dilate=dil,
+                                         acc64=True)
+    dx, df, db = vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), stride=stride, pad=pad, dilate=dil)
+    close(vl.to_numpy(dx), dx_ref, what="conv dx")
+    close(vl.to_numpy(df), df_ref, what="conv df")
+    close(vl.to_numpy(db).ravel(), db_ref, what="conv db")
+
+
+def test_conv_all_tile_configs(gpu):
+    """every templated tile configuration must give the same answer."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    rng = np.random.default_rng(7)
+    H, W, C, N, K = 19, 15, 12, 3, 100
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, 3, 3, C, K), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, pad=1, acc64=True)
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, df_ref, _ = O.vl_nnconv(x, f, b, dzdy, pad=1, acc64=True)
+    xd, fd, bd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), vl.from_numpy(dzdy)
+    try:
+        for cfg in range(L.xm_debug_num_conv_cfgs()):
+            L.xm_debug_force_conv_cfg(cfg)
+            close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=1)), y_ref, what="cfg%d fwd" % cfg)
+            dx, df, _ = vl.vl_nnconv(xd, fd, bd, dd, pad=1)
+            close(vl.to_numpy(dx), dx_ref, what="cfg%d dx" % cfg)
+            close(vl.to_numpy(df), df_ref, what="cfg%d df" % cfg)
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+
+
+def test_conv_fused_epilogue(gpu):
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(11)
+    H, W, C, N, K = 14, 14, 24, 3, 40
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, 3, 3, C, K), rnd(rng, K)
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    res = rnd(rng, H, W, K, N)
+    y0 = O.vl_nnconv(x, f, b, pad=1, acc64=True)
+    ref = np.maximum(y0 * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1) + res, 0)
+    y = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), pad=1,
+                     scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)),
+                     residual=vl.from_numpy(res), relu=True)
+    close(vl.to_numpy(y), ref, what="fused conv")
+
+
+def test_conv_no_der_flags_and_errors(gpu):
+    from mcncrossmodalemotions_amd import vl, _lib
+    rng = np.random.default_rng(3)
+    x, f = rnd(rng, 8, 8, 4, 2), rnd(rng, 3, 3, 4, 5)
+    xd, fd = vl.from_numpy(x), vl.from_numpy(f)
+    y = vl.vl_nnconv(xd, fd, None)
+    close(vl.to_numpy(y), O.vl_nnconv(x, f, None, acc64=True), what="no bias")
+    dz = vl.from_numpy(rnd(rng, 6, 6, 5, 2))
+    dx, df, db = vl.vl_nnconv(xd, fd, None, dz, no_der_data=True)
+    assert dx is None and db is None and df is not None
+    with pytest.raises(_lib.XmError):  # filter larger than the padded input
+        vl.vl_nnconv(xd, vl.from_numpy(rnd(rng, 9, 9, 4, 5)), None)
+    with pytest.raises(_lib.XmError):  # channel mismatch
+        vl.vl_nnconv(xd, vl.from_numpy(rnd(rng, 3, 3, 3, 5)), None)
+
+
+POOL_CASES = [
+    (13, 11, 5, 3, (3, 3), (2, 2), (0, 0, 0, 0), "max"),     # student mpool1/2
+    (9, 8, 6, 2, (5, 3), (3, 2), (0, 0, 0, 0), "max"),       # student mpool5
+    (12, 12, 4, 2, (3, 3), (2, 2), (0, 1, 0, 1), "max"),     # resnet pool1 (Caffe ceil pad)
+    (1, 8, 16, 3, (1, 8), (1, 1), (0, 0, 0, 0), "avg"),      # student pool6
+    (7, 7, 10, 2, (7, 7), (1, 1), (0, 0, 0, 0), "avg"),      # resnet pool5 / SE global
+    (10, 9, 3, 2, (3, 2), (2, 1), (1, 1, 0, 1), "avg"),      # avg with padding (clipped area)
+    (10, 9, 3, 2, (2, 2), (1, 1), (1, 0, 1, 0), "max"),
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_pool(gpu, case):
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N, pool, stride, pad, method = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rnd(rng, H, W, C, N)
+    x = np.maximum(x, 0)  # post-ReLU inputs: plenty of exact ties for the max-backward rule
+    y_ref = O.vl_nnpool(x, pool, stride=stride, pad=pad, method=method)
+    xd = vl.from_numpy(x)
+    y = vl.vl_nnpool(xd, pool, stride=stride, pad=pad, method=method)
+    close(vl.to_numpy(y), y_ref, 1e-6, "pool fwd")
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref = O.vl_nnpool(x, pool, dzdy, stride=stride, pad=pad, method=method)
+    dx = vl.vl_nnpool(xd, pool, vl.from_numpy(dzdy), stride=stride, pad=pad, method=method)
+    close(vl.to_numpy(dx), dx_ref, 1e-5, "pool bwd")
+
+
+BN_CASES = [(13, 7, 5, 4), (8, 8, 16, 3), (1, 1, 32, 6), (1, 8, 24, 5), (30, 17, 3, 2)]
+
+
+@pytest.mark.parametrize("shape", BN_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_bnorm(gpu, shape, relu):
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N = shape
+    rng = np.random.default_rng(H * 1000 + W * 100 + C * 10 + N)
+    x = O.F(rng.standard_normal(shape) * 2.0 + 3.0)  # non-zero mean: stresses the variance pass
+    g, b = O.F(rng.uniform(0.5, 1.5, C)), rnd(rng, C)
+    y_ref, m_ref = O.vl_nnbnorm(x, g, b, acc64=True)
+    if relu:
+        y_ref = np.maximum(y_ref, 0)
+    xd, gd, bd = vl.from_numpy(x), vl.from_numpy(g.reshape(C, 1)), vl.from_numpy(b.reshape(C, 1))
+    y, m = vl.vl_nnbnorm(xd, gd, bd, relu=relu)
+    close(vl.to_numpy(y), y_ref, what="bn fwd")
+    close(vl.to_numpy(m), m_ref, what="bn moments")
+    dzdy = rnd(rng, *shape)
+    dz_eff = dzdy * (y_ref > 0) if relu else dzdy
+    dx_ref, dg_ref, db_ref, _ = O.vl_nnbnorm(x, g, b, dz_eff, acc64=True)
+    dx, dg, db, _ = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), relu=relu, y=y if relu else None)
+    close(vl.to_numpy(dx), dx_ref, what="bn dx")
+    close(vl.to_numpy(dg).ravel(), dg_ref, what="bn dg")
+    close(vl.to_numpy(db).ravel(), db_ref, what="bn db")
+    # test mode with stored moments
+    mom = O.F(np.stack([rng.standard_normal(C), rng.uniform(0.5, 1.5, C)], 1))
+    yt_ref, _ = O.vl_nnbnorm(x, g, b, moments=mom, acc64=True)
+    yt, _ = vl.vl_nnbnorm(xd, gd, bd, moments=vl.from_numpy(mom))
+    close(vl.to_numpy(yt), yt_ref, what="bn test-mode")
+    dxt_ref, dgt_ref, dbt_ref, _ = O.vl_nnbnorm(x, g, b, dzdy, moments=mom, acc64=True)
+    dxt, dgt, dbt, _ = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), moments=vl.from_numpy(mom))
+    close(vl.to_numpy(dxt), dxt_ref, what="bn test-mode dx")
+    close(vl.to_numpy(dgt).ravel(), dgt_ref, what="bn test-mode dg")
+
+
+def test_elementwise(gpu):
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(5)
+    for shape in [(7, 5, 3, 2), (16, 16, 8, 4), (1, 1, 9, 7)]:
+        x, d, r = rnd(rng, *shape), rnd(rng, *shape), rnd(rng, *shape)
+        xd, dd, rd = vl.from_numpy(x), vl.from_numpy(d), vl.from_numpy(r)
+        close(vl.to_numpy(vl.vl_nnrelu(xd)), O.vl_nnrelu(x), 0, "relu")
+        close(vl.to_numpy(vl.vl_nnrelu(xd, dd)), O.vl_nnrelu(x, d), 0, "relu bwd")
+        close(vl.to_numpy(vl.vl_nnrelu(xd, leak=0.1)), O.vl_nnrelu(x, leak=0.1), 1e-7, "leaky")
+        close(vl.to_numpy(vl.vl_nnsigmoid(xd)), O.vl_nnsigmoid(x), 1e-6, "sigmoid")
+        close(vl.to_numpy(vl.vl_nnsigmoid(xd, dd)), O.vl_nnsigmoid(x, d), 1e-6, "sigmoid bwd")
+        close(vl.to_numpy(vl.sum2(xd, rd, relu=True)), O.sum2(x, r, relu=True), 0, "sum relu")
+        close(vl.to_numpy(vl.sum2(xd, rd)), O.sum2(x, r), 0, "sum")
+        a = rnd(rng, 1, 1, shape[2], shape[3])
+        ad = vl.from_numpy(a)
+        close(vl.to_numpy(vl.scale_axpy(xd, ad, rd, relu=True)), O.scale_axpy(x, a, r, relu=True),
+              1e-6, "axpy")
+        close(vl.to_numpy(vl.scale_axpy(xd, ad)), O.scale_axpy(x, a), 1e-6, "scale")
+        dx_ref, da_ref = O.scale_backward(x, a, d)
+        dx, da = vl.scale_backward(xd, ad, dd)
+        close(vl.to_numpy(dx), dx_ref, 1e-6, "scale dx")
+        close(vl.to_numpy(da), da_ref, 1e-5, "scale da")
+
+
+def test_losses(gpu):
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(9)
+    for N in (1, 5, 64, 300):
+        x, p = rnd(rng, 1, 1, 8, N) * 3, rnd(rng, 1, 1, 8, N) * 3
+        xd, pd = vl.from_numpy(x), vl.from_numpy(p)
+        # the distillation loss as configured at emoVoxZoo.m:152
+        l = vl.vl_nnsoftmaxceloss(xd, pd, temperature=2, logitTargets=True)
+        close(vl.to_numpy(l).ravel()[0], O.vl_nnsoftmaxceloss(x, p, temperature=2, logit_targets=True),
+              1e-6, "softmaxce fwd")
+        g = vl.vl_nnsoftmaxceloss(xd, pd, 1.0, temperature=2, logitTargets=True)
+        close(vl.to_numpy(g), O.vl_nnsoftmaxceloss(x, p, np.ones(1), temperature=2, logit_targets=True),
+              1e-6, "softmaxce bwd")
+        # probability targets + instance weights
+        pr = O.vl_nnsoftmaxt(p, 1.0)
+        w = O.F(rng.uniform(0.5, 2, (1, 1, 1, N)))
+        l2 = vl.vl_nnsoftmaxceloss(xd, vl.from_numpy(pr), instanceWeights=vl.from_numpy(w))
+        close(vl.to_numpy(l2).ravel()[0], O.vl_nnsoftmaxceloss(x, pr, instance_weights=w), 1e-6, "ce w")
+        lab = O.F(rng.integers(1, 9, (1, 1, 1, N)))
+        ld = vl.from_numpy(lab)
+        for loss in ("softmaxlog", "classerror"):
+            close(vl.to_numpy(vl.vl_nnloss(xd, ld, loss=loss)).ravel()[0], O.vl_nnloss(x, lab, loss=loss),
+                  1e-6, loss)
+            close(vl.to_numpy(vl.vl_nnloss(xd, ld, 1.0, loss=loss)), O.vl_nnloss(x, lab, np.ones(1), loss=loss),
+                  1e-6, loss + " bwd")
+        close(vl.to_numpy(vl.vl_nnsoftmaxt(xd, 2.0)), O.vl_nnsoftmaxt(x, 2.0), 1e-6, "softmaxt")
+
+
+def test_sgd_and_batch_math(gpu):
+    from mcncrossmodalemotions_amd import vl
+    import torch
+    rng = np.random.default_rng(13)
+    for n in (5, 1024, 4099):
+        w, m, d = rnd(rng, n, 1), rnd(rng, n, 1), rnd(rng, n, 1)
+        w_ref, m_ref = O.sgd_update(w, m, d, 1e-4, 0.9, 5e-4, 64)
+        wd, md = vl.from_numpy(w), vl.from_numpy(m)
+        vl.sgd_update(wd, md, vl.from_numpy(d), 1e-4, 0.9, 5e-4, 64)
+        close(vl.to_numpy(wd), w_ref, 1e-7, "sgd w")
+        close(vl.to_numpy(md), m_ref, 1e-7, "sgd m")
+        wa = vl.from_numpy(w)
+        vl.average_update(wa, vl.from_numpy(d), 0.1, 2)
+        close(vl.to_numpy(wa), O.average_update(w, d, 0.1, 2), 1e-7, "avg update")
+    spec = O.F(np.abs(rng.standard_normal((64, 30, 1, 3))) * 5 + 1)
+    close(vl.to_numpy(vl.spec_rownorm(vl.from_numpy(spec))), O.spec_rownorm(spec), 1e-5, "rownorm")
+    lg = rnd(rng, 40, 8)
+    first = np.array([1, 3, 30, 40], np.int32)
+    last = np.array([13, 3, 45, 40], np.int32)
+    for agg in ("max", "mean"):
+        out, lab = vl.aggregate_logits(vl.from_numpy(lg), torch.from_numpy(first).cuda(),
+                                       torch.from_numpy(last).cuda(), agg)
+        ref = np.stack([O.aggregate_logits(lg, f, l, agg) for f, l in zip(first, last)], 1)
+        close(vl.to_numpy(out).reshape(8, 4), ref, 1e-6, "aggregate " + agg)
+        close(vl.to_numpy(lab).ravel(), ref.argmax(0) + 1, 0, "maxLabel")
+    rgb = O.F(rng.integers(0, 256, (12, 10, 3, 2)))
+    avg = [131.1, 103.9, 91.5]
+    close(vl.to_numpy(vl.normalize_face(vl.from_numpy(rgb), avg)), O.normalize_face(rgb, avg), 1e-6, "face")
