@@ -1,0 +1,112 @@
+"""Batch providers: getBatchEmoVoxCeleb (student) and getImageBatch (teacher) mirrors.
+
+The reference's providers read wav / jpeg files (emoVoxCeleb/getBatchEmoVoxCeleb.m:76-194,
+emoVoxCeleb/fetch_emovoxceleb_imdb.m:152-193).  File I/O and the FFT front-end (VGGVox runSpec)
+are outside the built path; what is kept is every piece of arithmetic that
+shapes the tensors the hot path consumes, fed from seeded synthetic sources:
+
+    audSamp / crop window        getBatchEmoVoxCeleb.m:67-68,109-119
+    time2idx + logit slicing     getBatchEmoVoxCeleb.m:145-158,210-214
+    aggregation (max | mean)     getBatchEmoVoxCeleb.m:179-188      -> HIP xm_aggregate_logits
+    per-row normalisation ('I')  getBatchEmoVoxCeleb.m:164-169      -> HIP xm_spec_rownorm
+    target selection + maxLabel  getBatchEmoVoxCeleb.m:30-32
+    face normalisation           fetch_emovoxceleb_imdb.m:176-193   -> HIP xm_normalize_face
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import vl
+
+FPS, LOGIT_STRIDE = 25, 6  # getBatchEmoVoxCeleb.m:212
+
+
+def time2idx(t):
+    """getBatchEmoVoxCeleb.m:210-214."""
+    return int(math.floor(max(t * FPS - 1, 0) / LOGIT_STRIDE)) + 1
+
+
+def aud_samples(width, Tw=25, fs=16000):
+    """getBatchEmoVoxCeleb.m:67-68: audSamp = (0.01*W + 0.001*Tw - 0.001) * fs."""
+    return (0.01 * width + 0.001 * Tw - 0.001) * fs
+
+
+class SyntheticEmoVoxImdb:
+    """Stand-in for the imdb of fetch_emovoxceleb_imdb: per-track wav length (samples) and the
+    cached teacher logits imdb.wavLogits{i} (F_i x 8 single, one row per sampled face frame)."""
+
+    def __init__(self, num_tracks=64, seed=0, min_seconds=4.5, max_seconds=9.0, num_emotions=8, fs=16000):
+        rng = np.random.default_rng(seed)
+        self.fs = fs
+        self.num_samples = rng.integers(int(min_seconds * fs), int(max_seconds * fs), num_tracks)
+        self.wavLogits = []
+        for n in self.num_samples:
+            frames = time2idx(n / fs)
+            self.wavLogits.append(np.asfortranarray(rng.standard_normal((frames, num_emotions)).astype(np.float32) * 3))
+        self.set = np.ones(num_tracks, int)
+        self.seed = seed
+        self._dev = None
+
+    def device_logits(self, device):
+        """all tracks' logits concatenated (F_total x E) on the device + row offsets."""
+        if self._dev is None:
+            offs = np.cumsum([0] + [l.shape[0] for l in self.wavLogits])
+            cat = np.asfortranarray(np.concatenate(self.wavLogits, 0))
+            self._dev = (vl.from_numpy(cat, device), offs)
+        return self._dev
+
+
+def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, logitAggregator="max",
+                        lossType="hot-cross-ent", transformation="I", rng=None, spec_source=None,
+                        device=None):
+    """inputs = getBatchEmoVoxCeleb(imdb, batch, ...) -> ['data', im, 'logitTarget', lgo,
+    'maxLabel', maxLabel] (getBatchEmoVoxCeleb.m:31-43).  Spectrogram magnitudes come from
+    `spec_source` (H x W x 1 x N device tensor) or a seeded half-normal generator."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    rng = rng or np.random.default_rng(0)
+    batch = list(batch)
+    N = len(batch)
+    H, W = imageSize
+    audSamp = aud_samples(W)
+    logits, offs = imdb.device_logits(device)
+    first = np.zeros(N, np.int32)
+    last = np.zeros(N, np.int32)
+    for k, ii in enumerate(batch):
+        total = int(imdb.num_samples[ii])
+        wr = int(rng.integers(0, max(total - int(audSamp), 0) + 1))  # random crop start (:109-119)
+        starttime = wr / imdb.fs
+        endtime = (wr + audSamp - 1) / imdb.fs
+        s, e = time2idx(starttime), time2idx(endtime)
+        e = min(e, imdb.wavLogits[ii].shape[0])  # :152
+        first[k], last[k] = offs[ii] + s, offs[ii] + e
+    if spec_source is None:
+        g = torch.Generator(device=device)
+        g.manual_seed(int(rng.integers(0, 2 ** 31)))
+        raw = torch.randn((N, 1, W, H), generator=g, device=device, dtype=torch.float32).abs_()
+        spec_source = raw.permute(3, 2, 1, 0)
+    im = vl.spec_rownorm(spec_source) if "I" in transformation else spec_source
+    lgo, maxLabel = vl.aggregate_logits(logits, torch.from_numpy(first).to(device),
+                                        torch.from_numpy(last).to(device), logitAggregator)
+    if numPredEmotions != lgo.shape[2]:
+        raise NotImplementedError("numPredEmotions < number of cached logits")
+    inputs = ["data", im]
+    if lossType == "softmaxlog":
+        inputs += ["maxLabel", maxLabel]
+    elif lossType == "hot-cross-ent":
+        inputs += ["logitTarget", lgo, "maxLabel", maxLabel]
+    else:
+        raise ValueError("unrecognised loss type: %s" % lossType)
+    return inputs
+
+
+def getImageBatch(num, imageSize=(224, 224), averageImage=(131.0912, 103.8827, 91.4953), seed=1,
+                  device=None):
+    """fetch_emovoxceleb_imdb.m:152-193 on synthetic frames: uint8-valued RGB -> rgb2gray ->
+    replicate x3 -> minus the per-channel averageImage."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rgb = torch.randint(0, 256, (num, 3, imageSize[1], imageSize[0]), generator=g, device=device)
+    rgb = rgb.to(torch.float32).permute(3, 2, 1, 0)
+    return vl.normalize_face(rgb, averageImage)

@@ -1,0 +1,722 @@
+"""Host-side mirror of MatConvNet's dagnn.DagNN / dagnn.Layer for the reference's hot path.
+
+The reference never touches an operator directly: it builds / loads a `dagnn.DagNN`
+(emoVoxCeleb/emoVoxZoo.m:44,199; teacher/ferPlusZoo.m:100,145), edits it with
+addLayer / removeLayer / renameVar / initParams, and calls `dag.eval(inputs)` or hands it to
+cnn_train_dag, which calls `net.eval(inputs, derOutputs)`
+(emoVoxCeleb/fetch_emovoxceleb_imdb.m:129, external/compute_audio_feats.m:126,
+emoVoxCeleb/run_distillation.m:170-182).  This module keeps those names and semantics; each
+block's forward/backward is a thin wrapper over the HIP operators in vl.py, exactly as
+dagnn.Conv.forward wraps vl_nnconv.
+
+MI355X-specific additions (all optional, results identical):
+  * peephole fusion at eval time: BatchNorm -> ReLU pairs run as one kernel (fwd and bwd);
+    in test mode Conv -> BatchNorm [-> Sum] [-> ReLU] chains fold into the conv epilogue;
+  * pack_params(): all parameters / derivatives / momenta live in three flat HBM buffers
+    (grouped by learning-rate / weight-decay multipliers) so the optimiser is a handful of
+    launches and the ParameterServer all-reduce is one RCCL call per bucket.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import vl
+
+
+class Param:
+    def __init__(self, name, value=None, learningRate=1.0, weightDecay=1.0, trainMethod="gradient"):
+        self.name = name
+        self.value = value
+        self.der = None
+        self.learningRate = learningRate
+        self.weightDecay = weightDecay
+        self.trainMethod = trainMethod
+        self.fanout = 0
+
+
+class Var:
+    def __init__(self, name):
+        self.name = name
+        self.value = None
+        self.der = None
+        self.precious = False
+        self.fanin = 0
+        self.fanout = 0
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks (dagnn.Layer subclasses)
+# ---------------------------------------------------------------------------------------------
+class Layer:
+    """dagnn.Layer: forward(inputs, params) -> outputs; backward(...) -> derInputs, derParams."""
+
+    def __init__(self):
+        self.net = None
+        self.layerIndex = -1
+
+    def forward(self, inputs, params):
+        raise NotImplementedError
+
+    def backward(self, inputs, params, derOutputs):
+        raise NotImplementedError
+
+    def getParams(self):
+        return []
+
+    def initParams(self, rng):
+        return []
+
+
+class Conv(Layer):
+    def __init__(self, size, hasBias=True, stride=(1, 1), pad=(0, 0, 0, 0), dilate=(1, 1)):
+        super().__init__()
+        self.size = tuple(int(s) for s in size)  # [FH FW FC K]
+        self.hasBias = hasBias
+        self.stride = tuple(stride) if not np.isscalar(stride) else (stride, stride)
+        self.pad = pad
+        self.dilate = tuple(dilate) if not np.isscalar(dilate) else (dilate, dilate)
+
+    def forward(self, inputs, params):
+        b = params[1] if self.hasBias else None
+        return [vl.vl_nnconv(inputs[0], params[0], b, stride=self.stride, pad=self.pad,
+                             dilate=self.dilate)]
+
+    def backward(self, inputs, params, derOutputs, need_dx=True):
+        b = params[1] if self.hasBias else None
+        dx, df, db = vl.vl_nnconv(inputs[0], params[0], b, derOutputs[0], stride=self.stride,
+                                  pad=self.pad, dilate=self.dilate, no_der_data=not need_dx)
+        return [dx], ([df, db] if self.hasBias else [df])
+
+    def initParams(self, rng):
+        # dagnn.Conv.initParams: He-style sc = sqrt(2 / (h*w*out)); filters randn*sc, biases 0
+        FH, FW, FC, K = self.size
+        sc = np.sqrt(2.0 / (FH * FW * K))
+        p = [np.asfortranarray(rng.standard_normal(self.size).astype(np.float32) * np.float32(sc))]
+        if self.hasBias:
+            p.append(np.zeros((K, 1), np.float32))
+        return p
+
+
+class BatchNorm(Layer):
+    def __init__(self, numChannels, epsilon=1e-4):
+        super().__init__()
+        self.numChannels = int(numChannels)
+        self.epsilon = float(epsilon)
+        self.moments = None  # last batch moments (train mode), the 'der' of the moments param
+
+    def forward(self, inputs, params, relu=False):
+        test = self.net is not None and self.net.mode == "test"
+        y, mom = vl.vl_nnbnorm(inputs[0], params[0], params[1], epsilon=self.epsilon,
+                               moments=params[2] if test else None, relu=relu)
+        self.moments = None if test else mom
+        return [y]
+
+    def backward(self, inputs, params, derOutputs, relu=False, y=None):
+        test = self.net is not None and self.net.mode == "test"
+        dx, dg, db, mom = vl.vl_nnbnorm(inputs[0], params[0], params[1], derOutputs[0],
+                                        epsilon=self.epsilon, moments=params[2] if test else None,
+                                        relu=relu, y=y)
+        # dagnn.BatchNorm: derParams{3} = the batch moments (consumed by trainMethod 'average')
+        return [dx], [dg, db, mom]
+
+    def initParams(self, rng):
+        C = self.numChannels
+        mom = np.zeros((C, 2), np.float32, order="F")
+        mom[:, 1] = 1.0
+        return [np.ones((C, 1), np.float32), np.zeros((C, 1), np.float32), mom]
+
+
+class ReLU(Layer):
+    def __init__(self, leak=0.0):
+        super().__init__()
+        self.leak = leak
+
+    def forward(self, inputs, params):
+        return [vl.vl_nnrelu(inputs[0], leak=self.leak)]
+
+    def backward(self, inputs, params, derOutputs):
+        return [vl.vl_nnrelu(inputs[0], derOutputs[0], leak=self.leak)], []
+
+
+class Sigmoid(Layer):
+    def forward(self, inputs, params):
+        return [vl.vl_nnsigmoid(inputs[0])]
+
+    def backward(self, inputs, params, derOutputs):
+        return [vl.vl_nnsigmoid(inputs[0], derOutputs[0])], []
+
+
+class Pooling(Layer):
+    def __init__(self, poolSize, stride=(1, 1), pad=(0, 0, 0, 0), method="max"):
+        super().__init__()
+        self.poolSize = list(poolSize)
+        self.stride = stride
+        self.pad = pad
+        self.method = method
+
+    def forward(self, inputs, params):
+        return [vl.vl_nnpool(inputs[0], self.poolSize, stride=self.stride, pad=self.pad,
+                             method=self.method)]
+
+    def backward(self, inputs, params, derOutputs):
+        return [vl.vl_nnpool(inputs[0], self.poolSize, derOutputs[0], stride=self.stride,
+                             pad=self.pad, method=self.method)], []
+
+
+class GlobalPooling(Pooling):
+    """mcnExtraLayers dagnn.GlobalPooling (SE squeeze): window = the whole H x W plane."""
+
+    def __init__(self, method="avg"):
+        super().__init__([1, 1], method=method)
+
+    def forward(self, inputs, params):
+        self.poolSize = [int(inputs[0].shape[0]), int(inputs[0].shape[1])]
+        return super().forward(inputs, params)
+
+    def backward(self, inputs, params, derOutputs):
+        self.poolSize = [int(inputs[0].shape[0]), int(inputs[0].shape[1])]
+        return super().backward(inputs, params, derOutputs)
+
+
+class Sum(Layer):
+    def forward(self, inputs, params, relu=False):
+        y = vl.sum2(inputs[0], inputs[1], relu=relu and len(inputs) == 2)
+        for extra in inputs[2:]:
+            y = vl.sum2(y, extra)
+        return [y]
+
+    def backward(self, inputs, params, derOutputs):
+        return [derOutputs[0] for _ in inputs], []
+
+
+class Scale(Layer):
+    """mcnExtraLayers dagnn.Scale as used by SE blocks: inputs {x, a}; y = a(1,1,c,n) .* x."""
+
+    def forward(self, inputs, params):
+        return [vl.scale_axpy(inputs[0], inputs[1])]
+
+    def backward(self, inputs, params, derOutputs):
+        dx, da = vl.scale_backward(inputs[0], inputs[1], derOutputs[0])
+        return [dx, da], []
+
+
+class Axpy(Layer):
+    """mcnExtraLayers dagnn.Axpy (SENet50 Caffe import): inputs {a, x, y}; out = a .* x + y."""
+
+    def forward(self, inputs, params, relu=False):
+        return [vl.scale_axpy(inputs[1], inputs[0], inputs[2], relu=relu)]
+
+    def backward(self, inputs, params, derOutputs):
+        dx, da = vl.scale_backward(inputs[1], inputs[0], derOutputs[0])
+        return [da, dx, derOutputs[0]], []
+
+
+class SoftMax(Layer):
+    def forward(self, inputs, params):
+        return [vl.vl_nnsoftmax(inputs[0])]
+
+
+class DropOut(Layer):
+    """dagnn.DropOut -- identity in test mode; training-time masks are not built (dropout is
+    off by default in the reference: emoVoxZoo.m:18)."""
+
+    def __init__(self, rate=0.5):
+        super().__init__()
+        self.rate = rate
+
+    def forward(self, inputs, params):
+        if self.net is not None and self.net.mode != "test" and self.rate > 0:
+            raise NotImplementedError("dropout > 0 in training mode is outside the built path")
+        return [inputs[0]]
+
+    def backward(self, inputs, params, derOutputs):
+        return [derOutputs[0]], []
+
+
+class LossBase(Layer):
+    def __init__(self):
+        super().__init__()
+        self.average = 0.0
+        self.numAveraged = 0
+
+    def reset(self):
+        self.average = 0.0
+        self.numAveraged = 0
+
+    def _accumulate(self, value, n):
+        # dagnn.Loss keeps a running average of the loss per sample
+        self.lastValue = value
+        self.lastN = n
+
+
+class SoftmaxCELoss(LossBase):
+    """mcnExtraLayers dagnn.SoftmaxCELoss('temperature', T, 'logitTargets', tf)."""
+
+    def __init__(self, temperature=1.0, logitTargets=False):
+        super().__init__()
+        self.temperature = temperature
+        self.logitTargets = logitTargets
+
+    def forward(self, inputs, params):
+        w = inputs[2] if len(inputs) > 2 else None
+        y = vl.vl_nnsoftmaxceloss(inputs[0], inputs[1], temperature=self.temperature,
+                                  logitTargets=self.logitTargets, instanceWeights=w)
+        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        return [y]
+
+    def backward(self, inputs, params, derOutputs):
+        w = inputs[2] if len(inputs) > 2 else None
+        dx = vl.vl_nnsoftmaxceloss(inputs[0], inputs[1], derOutputs[0],
+                                   temperature=self.temperature, logitTargets=self.logitTargets,
+                                   instanceWeights=w)
+        return [dx] + [None] * (len(inputs) - 1), []
+
+
+class Loss(LossBase):
+    """dagnn.Loss('loss', 'softmaxlog' | 'classerror')."""
+
+    def __init__(self, loss="softmaxlog"):
+        super().__init__()
+        self.loss = loss
+
+    def forward(self, inputs, params):
+        y = vl.vl_nnloss(inputs[0], inputs[1], loss=self.loss)
+        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        return [y]
+
+    def backward(self, inputs, params, derOutputs):
+        return [vl.vl_nnloss(inputs[0], inputs[1], derOutputs[0], loss=self.loss), None], []
+
+
+class VerboseLoss(Loss):
+    """mcnExtraLayers dagnn.VerboseLoss: a dagnn.Loss that also prints; same arithmetic."""
+
+
+class ErrorStats(LossBase):
+    """mcnExtraLayers dagnn.ErrorStats: per-class accuracy bookkeeping (host side, argmax only).
+    emoVoxZoo.m:165-169; read back by extractStats (run_distillation.m:186-207)."""
+
+    def __init__(self, numClasses=8):
+        super().__init__()
+        self.numClasses = numClasses
+        self.correct = np.zeros(numClasses)
+        self.population = np.zeros(numClasses)
+
+    def forward(self, inputs, params):
+        y = vl.vl_nnloss(inputs[0], inputs[1], loss="classerror")
+        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        return [y]
+
+    def update_host_stats(self, prediction, labels):
+        pred = vl.to_numpy(prediction).reshape(self.numClasses, -1).argmax(0) + 1
+        lab = vl.to_numpy(labels).ravel().astype(int)
+        for c in range(1, self.numClasses + 1):
+            self.population[c - 1] += np.sum(lab == c)
+            self.correct[c - 1] += np.sum((lab == c) & (pred == c))
+
+    def backward(self, inputs, params, derOutputs):
+        return [None, None], []
+
+
+# ---------------------------------------------------------------------------------------------
+# the graph
+# ---------------------------------------------------------------------------------------------
+class _LayerRec:
+    def __init__(self, name, block, inputs, outputs, params):
+        self.name = name
+        self.block = block
+        self.inputs = list(inputs)
+        self.outputs = list(outputs)
+        self.params = list(params)
+
+
+class DagNN:
+    """dagnn.DagNN subset: addLayer, removeLayer, renameVar, getVarIndex, getParamIndex,
+    getLayerIndex, getInputs, initParams, rebuild, move, eval, mode, vars, params, layers, meta."""
+
+    def __init__(self):
+        self.layers = []
+        self.vars = OrderedDict()
+        self.params = OrderedDict()
+        self.meta = {}
+        self.mode = "normal"
+        self.conserveMemory = True
+        self.accumulateParamDers = False
+        self.fuse = True  # MI355X peephole fusion (results identical)
+        self.device = None
+        self._flat = None
+
+    # ---- construction -------------------------------------------------------------------
+    def addLayer(self, name, block, inputs, outputs, params=()):
+        if isinstance(inputs, str):
+            inputs = [inputs]
+        if isinstance(outputs, str):
+            outputs = [outputs]
+        if isinstance(params, str):
+            params = [params]
+        if any(l.name == name for l in self.layers):
+            raise ValueError("There is already a layer with name '%s'." % name)
+        block.net = self
+        self.layers.append(_LayerRec(name, block, inputs, outputs, params))
+        for p in params:
+            if p not in self.params:
+                self.params[p] = Param(p)
+        self.rebuild()
+        return self
+
+    def removeLayer(self, name):
+        names = [name] if isinstance(name, str) else list(name)
+        self.layers = [l for l in self.layers if l.name not in names]
+        self.rebuild()
+
+    def renameVar(self, old, new):
+        for l in self.layers:
+            l.inputs = [new if v == old else v for v in l.inputs]
+            l.outputs = [new if v == old else v for v in l.outputs]
+        self.rebuild()
+
+    def rebuild(self):
+        old = self.vars
+        self.vars = OrderedDict()
+        for p in self.params.values():
+            p.fanout = 0
+        for i, l in enumerate(self.layers):
+            l.block.layerIndex = i
+            l.block.net = self
+            for v in l.inputs:
+                self.vars.setdefault(v, old.get(v) or Var(v))
+            for v in l.outputs:
+                self.vars.setdefault(v, old.get(v) or Var(v))
+        for v in self.vars.values():
+            v.fanin = v.fanout = 0
+        for l in self.layers:
+            for v in l.inputs:
+                self.vars[v].fanout += 1
+            for v in l.outputs:
+                self.vars[v].fanin += 1
+            for p in l.params:
+                self.params[p].fanout += 1
+        used = {p for l in self.layers for p in l.params}
+        for p in list(self.params):
+            if p not in used:
+                del self.params[p]
+
+    def getLayerIndex(self, name):
+        for i, l in enumerate(self.layers):
+            if l.name == name:
+                return i
+        return None
+
+    def getLayer(self, name):
+        i = self.getLayerIndex(name)
+        return None if i is None else self.layers[i]
+
+    def getVarIndex(self, name):
+        return list(self.vars).index(name) if name in self.vars else None
+
+    def getParamIndex(self, name):
+        return list(self.params).index(name) if name in self.params else None
+
+    def getInputs(self):
+        return [v.name for v in self.vars.values() if v.fanin == 0]
+
+    def getOutputs(self):
+        return [v.name for v in self.vars.values() if v.fanout == 0]
+
+    def initParams(self, seed=0):
+        """dag.initParams(): re-randomise every parameter (emoVoxZoo.m:54)."""
+        rng = np.random.default_rng(seed)
+        for l in self.layers:
+            vals = l.block.initParams(rng)
+            for pname, v in zip(l.params, vals):
+                self.params[pname].value = v  # host array until move('gpu')
+                if isinstance(l.block, BatchNorm):
+                    k = l.params.index(pname)
+                    p = self.params[pname]
+                    # [EXT] MatConvNet convention for BN params: g lr 2, b lr 1, moments 'average' 0.1
+                    p.weightDecay = 0.0
+                    p.learningRate = (2.0, 1.0, 0.1)[k]
+                    p.trainMethod = "average" if k == 2 else "gradient"
+                elif isinstance(l.block, Conv) and l.params.index(pname) == 1:
+                    self.params[pname].weightDecay = 0.0
+                    self.params[pname].learningRate = 2.0
+        self._flat = None
+
+    def move(self, device="gpu"):
+        """dag.move('gpu'): upload parameters (fetch_emovoxceleb_imdb.m:108)."""
+        if device != "gpu":
+            raise RuntimeError("this build has no CPU path (dag.move('cpu'))")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        for p in self.params.values():
+            if p.value is not None and not isinstance(p.value, torch.Tensor):
+                p.value = vl.from_numpy(p.value, self.device)
+        return self
+
+    # ---- flat parameter storage -----------------------------------------------------------
+    def pack_params(self):
+        """Re-home all parameters into flat value / der / momentum buffers grouped by
+        (trainMethod, lr multiplier, wd multiplier).  Returns the FlatParams record."""
+        self.move("gpu")
+        groups = OrderedDict()
+        for p in self.params.values():
+            key = (p.trainMethod, float(p.learningRate), float(p.weightDecay))
+            groups.setdefault(key, []).append(p)
+        total = sum(int(p.value.numel() + 3) // 4 * 4 for ps in groups.values() for p in ps)
+        val = torch.zeros(total, dtype=torch.float32, device=self.device)
+        der = torch.zeros(total, dtype=torch.float32, device=self.device)
+        mom = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        segs = []
+        for key, ps in groups.items():
+            start = off
+            for p in ps:
+                n = int(p.value.numel())
+                shp = tuple(int(s) for s in p.value.shape)
+                view = val[off:off + n].view(tuple(reversed(shp))).permute(*reversed(range(len(shp))))
+                view.copy_(p.value)
+                p.value = view
+                p.der = der[off:off + n].view(tuple(reversed(shp))).permute(*reversed(range(len(shp))))
+                p._flat_off = off
+                off += (n + 3) // 4 * 4
+            segs.append((key, start, off))
+        self._flat = FlatParams(val, der, mom, segs)
+        return self._flat
+
+    # ---- evaluation -----------------------------------------------------------------------
+    def eval(self, inputs, derOutputs=None):
+        """net.eval(inputs) / net.eval(inputs, derOutputs).
+
+        inputs:     ['name', tensor, ...] (the cell array of getBatch) or a dict
+        derOutputs: ['objective', 1] or a dict; None -> forward only."""
+        if not isinstance(inputs, dict):
+            inputs = {inputs[i]: inputs[i + 1] for i in range(0, len(inputs), 2)}
+        if derOutputs is not None and not isinstance(derOutputs, dict):
+            derOutputs = {derOutputs[i]: derOutputs[i + 1] for i in range(0, len(derOutputs), 2)}
+        for v in self.vars.values():
+            if not v.precious:
+                v.value = None
+            v.der = None
+        for k, t in inputs.items():
+            if k not in self.vars:
+                continue  # MatConvNet ignores unused inputs with a warning
+            self.vars[k].value = t
+        plan = self._plan(derOutputs is not None)
+        for step in plan:
+            step.forward(self)
+        if derOutputs is None:
+            return
+        for k, d in derOutputs.items():
+            if not isinstance(d, torch.Tensor):
+                d = vl.from_numpy(np.array([[float(d)]], np.float32), self.device)
+            self.vars[k].der = d
+        if not self.accumulateParamDers and self._flat is None:
+            for p in self.params.values():
+                p.der = None
+        self._pending_param_ders = {}
+        for step in reversed(plan):
+            step.backward(self)
+
+    # helpers used by the plan steps
+    def _set_var_der(self, name, d):
+        if d is None:
+            return
+        v = self.vars[name]
+        if v.der is None:
+            v.der = d
+        else:
+            v.der = vl.sum2(v.der, d)  # fan-out > 1: derivatives add (dagnn accumulates)
+
+    def _set_param_der(self, name, d):
+        if d is None:
+            return
+        p = self.params[name]
+        seen = self._pending_param_ders.get(name, 0)
+        self._pending_param_ders[name] = seen + 1
+        if self._flat is not None:
+            if seen == 0 and not self.accumulateParamDers:
+                p.der.copy_(d)
+            else:
+                p.der.add_(d)  # shared parameter (fanout > 1) -- not on the built path
+        else:
+            p.der = d if (p.der is None or seen == 0 and not self.accumulateParamDers) else vl.sum2(p.der, d)
+
+    def _plan(self, training):
+        key = (training, self.mode, self.fuse, len(self.layers))
+        if getattr(self, "_plan_key", None) == key and getattr(self, "_plan_layers", None) == [
+                id(l) for l in self.layers]:
+            return self._plan_cache
+        steps = build_plan(self, training)
+        self._plan_key, self._plan_cache = key, steps
+        self._plan_layers = [id(l) for l in self.layers]
+        return steps
+
+
+class FlatParams:
+    def __init__(self, val, der, mom, segments):
+        self.val, self.der, self.mom, self.segments = val, der, mom, segments
+
+
+# ---------------------------------------------------------------------------------------------
+# execution plan with peephole fusion
+# ---------------------------------------------------------------------------------------------
+class _Step:
+    """plain step: one dagnn layer."""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    def _params(self, net):
+        return [net.params[p].value for p in self.rec.params]
+
+    def forward(self, net):
+        r = self.rec
+        ins = [net.vars[v].value for v in r.inputs]
+        outs = r.block.forward(ins, self._params(net))
+        for v, t in zip(r.outputs, outs):
+            net.vars[v].value = t
+
+    def backward(self, net):
+        r = self.rec
+        douts = [net.vars[v].der for v in r.outputs]
+        if all(d is None for d in douts):
+            return
+        ins = [net.vars[v].value for v in r.inputs]
+        if isinstance(r.block, Conv):
+            need_dx = net.vars[r.inputs[0]].fanin > 0  # network inputs need no derivative
+            dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx)
+        else:
+            dins, dpar = r.block.backward(ins, self._params(net), douts)
+        for v, d in zip(r.inputs, dins):
+            net._set_var_der(v, d)
+        for p, d in zip(r.params, dpar):
+            net._set_param_der(p, d)
+        if net.conserveMemory:
+            for v in r.outputs:
+                if not net.vars[v].precious:
+                    net.vars[v].der = None
+
+
+class _BnReluStep(_Step):
+    """BatchNorm -> ReLU executed as one kernel each way (train or test mode)."""
+
+    def __init__(self, bn_rec, relu_rec):
+        super().__init__(bn_rec)
+        self.relu_rec = relu_rec
+
+    def forward(self, net):
+        r = self.rec
+        ins = [net.vars[v].value for v in r.inputs]
+        y = r.block.forward(ins, self._params(net), relu=True)[0]
+        net.vars[self.relu_rec.outputs[0]].value = y
+
+    def backward(self, net):
+        r = self.rec
+        out = net.vars[self.relu_rec.outputs[0]]
+        if out.der is None:
+            return
+        ins = [net.vars[v].value for v in r.inputs]
+        dins, dpar = r.block.backward(ins, self._params(net), [out.der], relu=True, y=out.value)
+        net._set_var_der(r.inputs[0], dins[0])
+        for p, d in zip(r.params, dpar):
+            net._set_param_der(p, d)
+        if net.conserveMemory and not out.precious:
+            out.der = None
+
+
+class _ConvFoldStep(_Step):
+    """test mode only: Conv -> BatchNorm [-> Sum(shortcut)] [-> ReLU] in the conv epilogue.
+    scale_k = g_k / sigma_k, shift_k = b_k - mu_k * scale_k  (frozen moments)."""
+
+    def __init__(self, conv_rec, bn_rec, sum_rec, relu_rec, out_name):
+        super().__init__(conv_rec)
+        self.bn_rec, self.sum_rec, self.relu_rec, self.out_name = bn_rec, sum_rec, relu_rec, out_name
+        self._folded = None
+
+    def _fold(self, net):
+        g, b, mom = [net.params[p].value for p in self.bn_rec.params]
+        key = (g.data_ptr(), b.data_ptr(), mom.data_ptr(), g._version, b._version, mom._version)
+        if self._folded is None or self._folded[0] != key:
+            gn, bn_, mn = vl.to_numpy(g).ravel(), vl.to_numpy(b).ravel(), vl.to_numpy(mom)
+            sc = (gn / mn[:, 1]).astype(np.float32)
+            sh = (bn_ - mn[:, 0] * sc).astype(np.float32)
+            self._folded = (key, vl.from_numpy(sc.reshape(-1, 1), g.device),
+                            vl.from_numpy(sh.reshape(-1, 1), g.device))
+        return self._folded[1], self._folded[2]
+
+    def forward(self, net):
+        r = self.rec
+        blk = r.block
+        x = net.vars[r.inputs[0]].value
+        prm = self._params(net)
+        sc, sh = self._fold(net)
+        resid = None
+        if self.sum_rec is not None:
+            other = [v for v in self.sum_rec.inputs if v != self.bn_rec.outputs[0]][0]
+            resid = net.vars[other].value
+        y = vl.vl_nnconv(x, prm[0], prm[1] if blk.hasBias else None, stride=blk.stride, pad=blk.pad,
+                         dilate=blk.dilate, scale=sc, shift=sh, residual=resid,
+                         relu=self.relu_rec is not None)
+        net.vars[self.out_name].value = y
+
+    def backward(self, net):
+        raise RuntimeError("folded conv+bn steps exist only in forward-only test-mode plans")
+
+
+def build_plan(net, training):
+    recs = net.layers
+    if not net.fuse:
+        return [_Step(r) for r in recs]
+    consumers = {}
+    for r in recs:
+        for v in r.inputs:
+            consumers.setdefault(v, []).append(r)
+    produced_before = {}
+    order = {id(r): i for i, r in enumerate(recs)}
+
+    def sole_consumer(var, cls):
+        cs = consumers.get(var, [])
+        if len(cs) == 1 and isinstance(cs[0].block, cls) and not net.vars[var].precious:
+            return cs[0]
+        return None
+
+    steps, skip = [], set()
+    fold_ok = (not training) and net.mode == "test"
+    for r in recs:
+        if id(r) in skip:
+            continue
+        if fold_ok and isinstance(r.block, Conv):
+            bn = sole_consumer(r.outputs[0], BatchNorm)
+            if bn is not None:
+                out = bn.outputs[0]
+                sm = sole_consumer(out, Sum)
+                # the shortcut operand must already be computed when the conv runs
+                if sm is not None and len(sm.inputs) == 2:
+                    other = [v for v in sm.inputs if v != out][0]
+                    prod = [q for q in recs if other in q.outputs]
+                    ready = (not prod) or all(order[id(q)] < order[id(r)] for q in prod)
+                    if ready:
+                        out = sm.outputs[0]
+                    else:
+                        sm = None
+                else:
+                    sm = None
+                rl = sole_consumer(out, ReLU)
+                if rl is not None and rl.block.leak == 0.0:
+                    out = rl.outputs[0]
+                else:
+                    rl = None
+                steps.append(_ConvFoldStep(r, bn, sm, rl, out))
+                skip.update(id(q) for q in (bn, sm, rl) if q is not None)
+                continue
+        if isinstance(r.block, BatchNorm):
+            rl = sole_consumer(r.outputs[0], ReLU)
+            if rl is not None and rl.block.leak == 0.0:
+                steps.append(_BnReluStep(r, rl))
+                skip.add(id(rl))
+                continue
+        steps.append(_Step(r))
+    # a fused step may now sit before the producer of one of its operands is scheduled; the
+    # `ready` test above guarantees producers precede the conv, so plain order is still valid.
+    del produced_before
+    return steps

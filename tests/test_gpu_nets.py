@@ -1,0 +1,150 @@
+"""GPU end-to-end parity: whole graphs (student step, teachers) through the dagnn mirror over the
+HIP C ABI vs the same graphs executed by the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import oracle_net
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, "%s: max err %.3e > %.1e * %.3g" % (what, err, tol, scale)
+
+
+def _student_inputs(rng, W, N):
+    spec = np.abs(rng.standard_normal((512, W, 1, N))).astype(np.float32)
+    data = O.spec_rownorm(O.F(spec))
+    lgo = O.F(rng.standard_normal((1, 1, 8, N)) * 3)
+    lab = O.F(lgo.reshape(8, N).argmax(0).reshape(1, 1, 1, N) + 1)
+    return data, lgo, lab
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_student_step_matches_oracle(gpu, fuse):
+    """VGGVox student (1/8 width, full 512x100 geometry): forward, loss, every parameter
+    derivative and the SGD update against the oracle (fp64-accumulate)."""
+    from mcncrossmodalemotions_amd import vl, zoo, train
+    rng = np.random.default_rng(21)
+    N, W = 4, 100
+    net = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=5)
+    net.fuse = fuse
+    P0 = oracle_net.host_params(net)
+    data, lgo, lab = _student_inputs(rng, W, N)
+    V = oracle_net.forward(net, {"data": data, "logitTarget": lgo, "maxLabel": lab}, P0, mode="normal")
+    _, DP = oracle_net.backward(net, V, {"objective": np.float32(1)}, P0, mode="normal")
+    net.pack_params()
+    inputs = ["data", vl.from_numpy(data), "logitTarget", vl.from_numpy(lgo), "maxLabel", vl.from_numpy(lab)]
+    net.vars["prediction"].precious = True
+    net.mode = "normal"
+    net.eval(inputs, ["objective", 1])
+    close(vl.to_numpy(net.vars["prediction"].value), V["prediction"], 1e-4, "prediction")
+    close(vl.to_numpy(net.vars["objective"].value).ravel()[0], V["objective"], 1e-5, "objective")
+    close(vl.to_numpy(net.vars["classerror"].value).ravel()[0], V["classerror"], 0, "classerror")
+    for name, ref in DP.items():
+        got = vl.to_numpy(net.params[name].der)
+        # gradients: relative to the largest entry of that parameter's gradient
+        close(got.reshape(ref.shape, order="F"), ref, 2e-4, "der " + name)
+    # SGD step (cnn_train_dag defaults): compare updated weights
+    opts = train.TrainOpts(batchSize=N)
+    train.accumulate_gradients(net, opts, 1e-4, N, 1)
+    for name, p in net.params.items():
+        if p.trainMethod == "average":
+            ref = O.average_update(P0[name], DP[name], p.learningRate, 1)
+        else:
+            ref, _ = O.sgd_update(P0[name], np.zeros_like(P0[name]), DP[name].reshape(P0[name].shape, order="F"),
+                                  1e-4 * p.learningRate, 0.9, 5e-4 * p.weightDecay, N)
+        close(vl.to_numpy(p.value), ref, 1e-5, "sgd " + name)
+
+
+def test_pool6_buckets_on_device(gpu):
+    """emoVoxZoo.m:258-259: every clip width bucket yields a 1 x 1 x C pool6 output."""
+    from mcncrossmodalemotions_amd import vl, zoo
+    rng = np.random.default_rng(2)
+    for W in (100, 300, 700, 1000):
+        net = zoo.emoVoxZoo(numSeconds=W / 100, width_mult=0.0625, scratch=0)
+        net.move("gpu")
+        net.mode = "test"
+        net.vars["x_pool6"].precious = True
+        net.eval(["data", vl.from_numpy(O.F(rng.standard_normal((512, W, 1, 1))))])
+        assert tuple(net.vars["x_pool6"].value.shape[:2]) == (1, 1), W
+
+
+@pytest.mark.parametrize("name", ["resnet50-ferplus", "senet50-ferplus"])
+def test_teacher_forward_matches_oracle(gpu, name):
+    """Frozen teacher in test mode (fetch_emovoxceleb_imdb.m:98-131), 1/8 width, one block per
+    stage, 64x64 input; folded conv+bn+sum+relu plan vs unfused plan vs oracle."""
+    from mcncrossmodalemotions_amd import vl, zoo
+    rng = np.random.default_rng(33)
+    net = zoo.ferPlusZoo(name, seed=7, width_mult=0.125, blocks=(2, 1, 1, 1))
+    zoo.strip_losses(net)
+    # 64x64 input -> pool5 sees 2x2: shrink the window like a smaller imageSize would
+    net.getLayer("pool5").block.poolSize = [2, 2]
+    net.mode = "test"
+    x = O.F(rng.standard_normal((64, 64, 3, 3)) * 40)
+    V = oracle_net.forward(net, {"data": x}, mode="test")
+    net.move("gpu")
+    net.vars["prediction"].precious = True
+    outs = {}
+    for fuse in (False, True):
+        net.fuse = fuse
+        net._plan_key = None
+        net.eval(["data", vl.from_numpy(x)])
+        outs[fuse] = vl.to_numpy(net.vars["prediction"].value)
+        close(outs[fuse], V["prediction"], 1e-4, "%s logits fuse=%s" % (name, fuse))
+    close(outs[True], outs[False], 1e-5, "fused vs unfused")
+
+
+def test_teacher_training_backward(gpu):
+    """config-5 precedent (ferplus_baselines.m:140): SE teacher fwd+bwd in train mode."""
+    from mcncrossmodalemotions_amd import vl, zoo
+    rng = np.random.default_rng(44)
+    net = zoo.ferPlusZoo("senet50-ferplus", seed=9, width_mult=0.125, blocks=(1, 1, 1, 1))
+    net.removeLayer("top1error")
+    net.getLayer("pool5").block.poolSize = [2, 2]
+    x = O.F(rng.standard_normal((64, 64, 3, 4)) * 40)
+    lab = O.F(rng.integers(1, 9, (1, 1, 1, 4)))
+    P0 = oracle_net.host_params(net)
+    V = oracle_net.forward(net, {"data": x, "label": lab}, P0, mode="normal")
+    _, DP = oracle_net.backward(net, V, {"objective": np.float32(1)}, P0, mode="normal")
+    net.pack_params()
+    net.mode = "normal"
+    net.eval(["data", vl.from_numpy(x), "label", vl.from_numpy(lab)], ["objective", 1])
+    close(vl.to_numpy(net.vars["objective"].value).ravel()[0], V["objective"], 1e-4, "objective")
+    for name, ref in DP.items():
+        got = vl.to_numpy(net.params[name].der)
+        close(got.reshape(ref.shape, order="F"), ref, 5e-4, "der " + name)
+
+
+def test_batch_provider(gpu):
+    from mcncrossmodalemotions_amd import vl, batch
+    imdb = batch.SyntheticEmoVoxImdb(num_tracks=16, seed=3)
+    rng = np.random.default_rng(0)
+    inputs = batch.getBatchEmoVoxCeleb(imdb, range(8), imageSize=(512, 300), rng=rng)
+    d = dict(zip(inputs[::2], inputs[1::2]))
+    assert tuple(d["data"].shape) == (512, 300, 1, 8)
+    assert tuple(d["logitTarget"].shape) == (1, 1, 8, 8) and tuple(d["maxLabel"].shape) == (1, 1, 1, 8)
+    data = vl.to_numpy(d["data"])
+    # rows are zero-mean / unit (unbiased) std over time: getBatchEmoVoxCeleb.m:164-169
+    assert np.abs(data.mean(1)).max() < 1e-4 and np.abs(data.std(1, ddof=1) - 1).max() < 1e-3
+    # replay the host-side window arithmetic and check the aggregated targets against the oracle
+    rng = np.random.default_rng(0)
+    lg = vl.to_numpy(d["logitTarget"]).reshape(8, 8)
+    for k in range(8):
+        total = int(imdb.num_samples[k])
+        aud = batch.aud_samples(300)
+        wr = int(rng.integers(0, max(total - int(aud), 0) + 1))
+        s, e = O.time2idx(wr / 16000), O.time2idx((wr + aud - 1) / 16000)
+        ref = O.aggregate_logits(imdb.wavLogits[k], s, e, "max")
+        rng.integers(0, 2 ** 31) if k == 7 else None
+        assert np.abs(lg[:, k] - ref).max() < 1e-6
+    faces = batch.getImageBatch(4)
+    f = vl.to_numpy(faces)
+    assert f.shape == (224, 224, 3, 4)
+    # the three channels differ only by the mean offset (fetch_emovoxceleb_imdb.m:176-193)
+    assert np.abs((f[:, :, 0] - f[:, :, 1]) - (103.8827 - 131.0912)).max() < 1e-3
