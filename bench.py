@@ -1,0 +1,287 @@
+#!/usr/bin/env python
+"""bench.py -- distillation-step throughput (face + audio pairs / s) on MI355X.
+
+Metric (BASELINE.json): "distillation-step samples/sec (face+audio pair) at 1/2/4/8 MI355X".
+One step = one pass of the hot path over one synthetic minibatch that is already resident in HBM:
+
+  workload "distill" (default; BASELINE config 4 sharded as 32 pairs per GPU, weak scaling):
+      frozen ResNet50 teacher forward (test-mode BN folded into the conv epilogues)
+        -> logits -> logitTarget / maxLabel
+      VGGVox student forward + soft-target CE (T = 2) + backward
+      ParameterServer: one RCCL sum-all-reduce of the 66.6 MB gradient buffer (N > 1)
+      SGD-momentum update (cnn_train_dag defaults), BN moments moving average
+  workload "student"  : BASELINE config 2 (student fwd + bwd + update, 64 x 512x300, 1 GPU)
+  workload "teacher"  : BASELINE config 3 (SE-ResNet50 teacher forward, batch 128, 1 GPU)
+  workload "joint"    : BASELINE config 5 shard (SE-ResNet50 fwd+bwd + student fwd+bwd, 64 / GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     -- dominant convolution kernel: algorithmic FLOPs of its launches / their summed
+                  durations, measured with HIP events on the launch stream in a second pass of
+                  the same K steps (the first pass, without events, gives `value`);
+  cpu_baseline -- the CPU oracle (oracle/, "port" of MatConvNet's CPU algorithm) timed on the
+                  host cores over a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, fp32 in/out
+
+# algorithmic GFLOP per unit (conv + FC MACs x 2)
+GFLOP = {"student_fwd_bwd_300": 16.633, "resnet50_fwd": 7.712, "senet50_fwd": 7.717,
+         "senet50_fwd_bwd": 22.915}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="distill", choices=["distill", "student", "teacher", "joint"])
+    ap.add_argument("--per-gpu-batch", type=int, default=0)
+    ap.add_argument("--width", type=int, default=300, help="spectrogram width (3 s clips)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--parserv", default="torch", choices=["torch", "rccl-capi"])
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from mcncrossmodalemotions_amd import _lib, vl, zoo, train, batch as xbatch, dagnn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    L = _lib.load()
+
+    wl = args.workload
+    nb = args.per_gpu_batch or {"distill": 32, "student": 64, "teacher": 128, "joint": 64}[wl]
+    W = args.width
+    seed = 4 + rank
+
+    # ---- networks ------------------------------------------------------------------------
+    teacher = student = None
+    if wl in ("distill", "teacher", "joint"):
+        tname = "resnet50-ferplus" if wl == "distill" else "senet50-ferplus"
+        teacher = zoo.ferPlusZoo(tname, seed=100 if wl == "distill" else 300)
+        if wl == "joint":
+            teacher.removeLayer("top1error")
+            teacher.pack_params()
+        else:
+            zoo.strip_losses(teacher)  # fetch_emovoxceleb_imdb.m:101-106
+            teacher.move("gpu")
+            teacher.vars["prediction"].precious = True
+    if wl in ("distill", "student", "joint"):
+        student = zoo.emoVoxZoo("emovoxceleb-student", scratch=1, lossType="hot-cross-ent",
+                                numSeconds=W / 100.0, numOutputs=8, seed=200)
+        student.pack_params()
+    parserv = train.ParameterServer(args.parserv)
+    parserv.start()
+    opts = train.TrainOpts(batchSize=nb * world)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ------------------------
+    faces = spec = lgo = lab = flab = None
+    if teacher is not None:
+        faces = xbatch.getImageBatch(nb, seed=seed, device=dev)
+        calib = xbatch.getImageBatch(min(nb, 16), seed=999, device=dev)
+        zoo.calibrate_moments(teacher, ["data", calib])  # realistic stored moments
+        teacher.mode = "test" if wl != "joint" else "normal"
+        if wl == "joint":
+            rng = np.random.default_rng(seed)
+            flab = vl.from_numpy(rng.integers(1, 9, (1, 1, 1, nb)).astype(np.float32), dev)
+    if student is not None:
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        raw = torch.randn((nb, 1, W, 512), generator=g, device=dev, dtype=torch.float32).abs_()
+        spec = vl.spec_rownorm(raw.permute(3, 2, 1, 0))  # getBatchEmoVoxCeleb.m:164-169
+        if wl == "student":
+            rng = np.random.default_rng(seed)
+            lgo = vl.from_numpy((rng.standard_normal((1, 1, 8, nb)) * 3).astype(np.float32), dev)
+            lab = vl.max_label(lgo)
+
+    def step(it):
+        if wl == "teacher":
+            teacher.eval(["data", faces])
+            return
+        if wl == "student":
+            train.train_step(student, ["data", spec, "logitTarget", lgo, "maxLabel", lab], opts, it,
+                             parserv, nb * world)
+            return
+        if wl == "distill":
+            teacher.eval(["data", faces])
+            tl = teacher.vars["prediction"].value      # 1 x 1 x 8 x nb teacher logits
+            ml = vl.max_label(tl)                       # getBatchEmoVoxCeleb.m:32
+            train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
+                             parserv, nb * world)
+            return
+        # joint: teacher fwd+bwd (hard-label CE head, ferPlusZoo.m:240-249) + student distillation
+        teacher.vars["prediction"].precious = True
+        train.train_step(teacher, ["data", faces, "label", flab], opts, it, parserv, nb * world)
+        tl = teacher.vars["prediction"].value
+        ml = vl.max_label(tl)
+        train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it, parserv,
+                         nb * world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(args.warmup + it)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    units = nb * world
+    value = units * args.steps / dt
+
+    # ---- roofline leg: same K steps again with HIP events around every conv launch ---------
+    roofline = None
+    if not args.no_roofline:
+        L.xm_prof_enable(1)
+        for it in range(args.steps):
+            step(args.warmup + args.steps + it)
+        torch.cuda.synchronize()
+        L.xm_prof_enable(0)
+        cap = 64
+        keys = (C.c_int * cap)()
+        ms = (C.c_double * cap)()
+        fl = (C.c_double * cap)()
+        cnt = (C.c_longlong * cap)()
+        n = L.xm_prof_collect(cap, keys, ms, fl, cnt)
+        rows = []
+        for i in range(min(n, cap)):
+            buf = C.create_string_buffer(128)
+            L.xm_prof_kernel_name(keys[i], buf, 128)
+            rows.append({"kernel": buf.value.decode(), "ms": ms[i], "flops": fl[i], "launches": int(cnt[i])})
+        rows.sort(key=lambda r: -r["ms"])
+        if rows:
+            d = rows[0]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            conv_ms = sum(r["ms"] for r in rows)
+            conv_fl = sum(r["flops"] for r in rows)
+            roofline = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(ach, 2),
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                        "flop_per_launch": d["flops"] / d["launches"],
+                        "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                             "ms_per_step": round(conv_ms / args.steps, 3)},
+                        "per_kernel": [{"kernel": r["kernel"], "ms_per_step": round(r["ms"] / args.steps, 3),
+                                        "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                        "launches_per_step": r["launches"] // args.steps} for r in rows[:8]]}
+
+    # ---- CPU baseline leg (rank 0, N = 1): the oracle on a bounded sample ------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl, args.cpu_pairs, W)
+
+    if wl == "distill":
+        gflop_unit = GFLOP["resnet50_fwd"] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
+    elif wl == "student":
+        gflop_unit = GFLOP["student_fwd_bwd_300"]
+    elif wl == "teacher":
+        gflop_unit = GFLOP["senet50_fwd"]
+    else:
+        gflop_unit = GFLOP["senet50_fwd_bwd"] + GFLOP["student_fwd_bwd_300"]
+
+    if rank == 0:
+        out = {
+            "metric": "distillation-step samples/sec (face+audio pair)" if wl in ("distill", "joint")
+                      else ("student fwd+bwd samples/sec" if wl == "student" else "teacher fwd images/sec"),
+            "value": round(value, 2), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"distill": "run_distillation step: frozen resnet50-ferplus teacher fwd -> "
+                                               "VGGVox student fwd+bwd, soft-target CE T=2, SGD (BASELINE config 4 shard)",
+                                    "student": "VGGVox student fwd+bwd+update (BASELINE config 2)",
+                                    "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",
+                                    "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
+                       "per_gpu_batch": nb, "global_batch": units, "face": "224x224x3",
+                       "spectrogram": "512x%dx1" % W, "parallelism": "dp%d" % world,
+                       "weights": "random-init (seeded)", "parameter_server": args.parserv},
+            "model_tflops_per_gpu": round(value / world * gflop_unit / 1e3, 2),
+            "model_frac_of_fp32_mfma_peak": round(value / world * gflop_unit / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        parserv.stop()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl, pairs, W):
+    """MatConvNet-CPU-equivalent restatement (oracle fp32 path: im2row + SGEMM per image, OpenMP)
+    on `pairs` samples of the same workload.  Checker code used as a timed baseline only."""
+    from mcncrossmodalemotions_amd import zoo
+    from oracle import oracle as O, oracle_net
+    rng = np.random.default_rng(0)
+    t_total = 0.0
+    if wl in ("distill", "teacher", "joint"):
+        name = "resnet50-ferplus" if wl == "distill" else "senet50-ferplus"
+        tnet = zoo.ferPlusZoo(name, seed=100)
+        if wl != "joint":
+            zoo.strip_losses(tnet)
+        else:
+            tnet.removeLayer("top1error")
+        x = O.F(rng.standard_normal((224, 224, 3, pairs)) * 40)
+        ins = {"data": x}
+        if wl == "joint":
+            ins["label"] = O.F(rng.integers(1, 9, (1, 1, 1, pairs)))
+        P = oracle_net.host_params(tnet)
+        t0 = time.perf_counter()
+        V = oracle_net.forward(tnet, ins, P, acc64=False, mode="test" if wl != "joint" else "normal")
+        if wl == "joint":
+            oracle_net.backward(tnet, V, {"objective": np.float32(1)}, P, acc64=False, mode="normal")
+        t_total += time.perf_counter() - t0
+    if wl in ("distill", "student", "joint"):
+        snet = zoo.emoVoxZoo(numSeconds=W / 100.0, seed=200)
+        spec = O.spec_rownorm(O.F(np.abs(rng.standard_normal((512, W, 1, pairs)))))
+        lgo = O.F(rng.standard_normal((1, 1, 8, pairs)) * 3)
+        lab = O.F(lgo.reshape(8, pairs).argmax(0).reshape(1, 1, 1, pairs) + 1)
+        P = oracle_net.host_params(snet)
+        t0 = time.perf_counter()
+        V = oracle_net.forward(snet, {"data": spec, "logitTarget": lgo, "maxLabel": lab}, P, acc64=False,
+                               mode="normal")
+        _, DP = oracle_net.backward(snet, V, {"objective": np.float32(1)}, P, acc64=False, mode="normal")
+        for k, d in DP.items():
+            if snet.params[k].trainMethod == "gradient":
+                O.sgd_update(P[k], np.zeros_like(P[k]), d.reshape(P[k].shape, order="F"), 1e-4, 0.9, 5e-4, pairs)
+        t_total += time.perf_counter() - t0
+    return {"value": round(pairs / t_total, 4), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",
+            "cores": O.num_threads(), "kind": "port",
+            "sample": "%d unit(s) of the same workload, oracle fp32 path (im2row + blocked SGEMM, OpenMP), %.1f s"
+                      % (pairs, t_total)}
+
+
+if __name__ == "__main__":
+    main()

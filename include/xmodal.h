@@ -83,6 +83,12 @@ int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int p
                        int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
                        void *stream);
 
+/* Extension: same, reusing the forward output y = vl_nnpool(x, ...) (saves the recomputation
+ * of the window maxima; results identical). */
+int xm_nnpool_backward_y(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
+                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
+                         const float *dzdy, float *dx_out, void *stream);
+
 /* ---- vl_nnbnorm  (matlab/vl_nnbnorm.m) -----------------------------------------------------
  * Y = vl_nnbnorm(X, G, B, 'epsilon', e [, 'moments', M]); M is C x 2 = [mean, sqrt(var+e)].
  * moments_in == NULL: train mode (batch moments, biased variance); they are written to
@@ -157,6 +163,8 @@ int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *st
 int xm_aggregate_logits(const float *frame_logits, int F_total, int E, const int *first,
                         const int *last, int N, int agg, float *out, float *max_label,
                         void *stream);
+/* getBatchEmoVoxCeleb.m:32: [~, maxLabel] = max(lgo, [], 3); x is 1 x 1 x C x N, labels 1-based */
+int xm_max_label(const float *x, int C, int N, float *labels, void *stream);
 /* fetch_emovoxceleb_imdb.m:176-193: rgb2gray -> replicate x3 -> minus averageImage(c).
  * avg3 is a HOST pointer to the three per-channel means (meta.normalization.averageImage). */
 int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,

@@ -1,0 +1,26 @@
+/*
+ * xmodal_prof.h -- measurement hooks of libxmodal_hip.so (NOT part of the drop-in operator ABI).
+ * bench.py uses them to time each convolution kernel instantiation with HIP events recorded on
+ * the stream the kernel is launched on, and to attach the algorithmic FLOPs of every launch
+ * (2 * M * pixels * taps, un-padded), so that roofline.achieved is measured live.
+ */
+#ifndef XMODAL_PROF_H
+#define XMODAL_PROF_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* on != 0: start recording (drops previous records); on == 0: stop recording, keep records */
+int xm_prof_enable(int on);
+/* after the stream has been synchronised: per-kernel totals; returns #distinct kernels */
+int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, long long *launches);
+/* name of a key, identical to the kernel name rocprofv3 --kernel-trace prints (sans namespace) */
+int xm_prof_kernel_name(int key, char *buf, int len);
+/* test hooks: force one tile configuration for every convolution launch (-1 = automatic) */
+int xm_debug_force_conv_cfg(int cfg);
+int xm_debug_num_conv_cfgs(void);
+/* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
+int xm_debug_force_conv_splits(int splits);
+#ifdef __cplusplus
+}
+#endif
+#endif

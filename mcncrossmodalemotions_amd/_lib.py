@@ -27,6 +27,7 @@ SIGNATURES = {
                           [_i] * 8 + [_vp],
     "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
+    "xm_nnpool_backward_y": [c_fp, c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
     "xm_nnbnorm_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _vp],
     "xm_nnbnorm_forward_fused": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnbnorm_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp,
@@ -49,11 +50,18 @@ SIGNATURES = {
     "xm_comm_destroy": [],
     "xm_spec_rownorm": [c_fp, _i, _i, _i, c_fp, _vp],
     "xm_aggregate_logits": [c_fp, _i, _i, c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],
+    "xm_max_label": [c_fp, _i, _i, c_fp, _vp],
     "xm_normalize_face": [c_fp, _i, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
 }
 _RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
 # test hooks (not part of include/xmodal.h)
-_DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": []}
+_DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
+          "xm_debug_force_conv_splits": [_i],
+          # include/xmodal_prof.h
+          "xm_prof_enable": [_i],
+          "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                              C.POINTER(C.c_longlong)],
+          "xm_prof_kernel_name": [_i, C.c_char_p, _i]}
 
 _lib = None
 

@@ -49,20 +49,40 @@ __global__ void reduce_splits_kernel(const float *__restrict__ part, float *__re
   out[i] = s;
 }
 
-// dzdb(k) = sum over pixels and samples of dzdy(:,:,k,:) : one block per channel
+// dzdb(k) = sum over pixels and samples of dzdy(:,:,k,:): grid (K, S) partial sums, then a
+// fixed-order finalize (deterministic)
 __global__ void __launch_bounds__(256)
-bias_grad_kernel(const float *__restrict__ dy, float *__restrict__ db, int HW, int K, int N) {
-  int k = blockIdx.x;
+bias_grad_partial_kernel(const float *__restrict__ dy, float *__restrict__ part, int HW, int K, int N,
+                         int S) {
+  int k = blockIdx.x, sp = blockIdx.y;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) {
+  const bool vec = (HW & 3) == 0;
+  for (int n = sp; n < N; n += S) {
     const float *p = dy + (size_t)HW * (k + (size_t)K * n);
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    if (vec) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(p);
+      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+        float4 v = p4[i];
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
   }
   __shared__ float red[4];
   s = xm_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) db[k] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) part[(size_t)k * S + sp] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void bias_grad_finalize_kernel(const float *__restrict__ part, float *__restrict__ db, int K,
+                                          int S) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int i = 0; i < S; ++i) s += part[(size_t)k * S + i];
+  db[k] = s;
 }
 
 // ---- tile configuration ---------------------------------------------------------------------
@@ -82,20 +102,21 @@ static const Cfg kCfgs[] = {
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// crude cost model: padded MACs per CU-wave, with a mild bonus for bigger wave tiles
+// cost model: time ~ rounds(occ) * occ * BM*BN * eff, where `occ` blocks share a CU's MFMA pipes
+// (each then runs occ x slower) and rounds = ceil(tiles / (256 CUs * occ)).
 static int pick_cfg(long long M, long long NP) {
   double best = 1e300;
   int bi = 0;
   for (int i = 0; i < kNumCfg; ++i) {
     const Cfg &c = kCfgs[i];
     long long tiles = ((M + c.bm() - 1) / c.bm()) * ((NP + c.bn() - 1) / c.bn());
-    int per_cu = c.bm() * c.bn() >= 128 * 128 ? 2 : 3;  // co-resident blocks that overlap
-    long long slots = 256LL * per_cu;
-    long long rounds = (tiles + slots - 1) / slots;
-    double eff = (c.tm * c.tn >= 4) ? 1.0 : (c.tm * c.tn >= 2 ? 1.15 : 1.35);
-    double cost = (double)rounds * slots / per_cu * c.bm() * c.bn() * eff;
-    // when everything fits in one round the padded tile work itself is what matters
-    if (rounds == 1) cost = (double)tiles * c.bm() * c.bn() * eff / std::min<long long>(tiles, 256) * 1.0;
+    double eff = (c.tm * c.tn >= 4) ? 1.0 : (c.tm * c.tn >= 2 ? 1.12 : 1.3);
+    double t = 1e300;
+    for (int occ = 1; occ <= 3; ++occ) {
+      long long rounds = (tiles + 256LL * occ - 1) / (256LL * occ);
+      t = std::min(t, (double)rounds * occ);
+    }
+    double cost = t * c.bm() * c.bn() * eff;
     if (cost < best) {
       best = cost;
       bi = i;
@@ -104,34 +125,110 @@ static int pick_cfg(long long M, long long NP) {
   return bi;
 }
 
-template <bool CHECK>
-static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, int nblk, hipStream_t st) {
-  dim3 grid(nblk), block(256);
+template <int MODE>
+static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_t st) {
+  dim3 block(256);
   switch (ci) {
-    case 0: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 2, CHECK>), grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 4, CHECK>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((conv_gemm_kernel<3, 1, 1, 4, CHECK>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 2, 2, CHECK>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 2, 2, CHECK>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 4, 1, CHECK>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 1, 4, CHECK>), grid, block, 0, st, a); break;
+    case 0: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 2, MODE>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 4, MODE>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_kernel<3, 1, 1, 4, MODE>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 2, 2, MODE>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 2, 2, MODE>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 4, 1, MODE>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 1, 4, MODE>), grid, block, 0, st, a); break;
   }
 }
 
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
 
-static int launch_gemm(ConvGemmArgs &a, bool check, hipStream_t st) {
-  int ci = g_force_cfg >= 0 ? g_force_cfg : pick_cfg(a.M, a.NP);
+// ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) --------
+struct ProfRec {
+  hipEvent_t start, stop;
+  int key;  // kind * 100 + cfg * 2 + check
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(int key, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    r.key = key;
+    r.flops = flops;
+    r.start = prof_event();
+    r.stop = prof_event();
+    (void)hipEventRecord(r.start, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.stop, st);
+    g_prof.push_back(r);
+  }
+};
+
+static int g_force_splits = 0;  // test hook
+
+// Launches the implicit GEMM (a.nkt K-stages).  With few output tiles the reduction is split over
+// grid.y and combined by conv_splitk_epilogue_kernel; `ws` must have room (see gemm_slab_bytes).
+static int pick_splits(int tiles, int nkt) {
+  if (g_force_splits > 0) return std::max(1, std::min(g_force_splits, nkt));
+  if (tiles >= 384 || nkt < 16) return 1;
+  int s = (512 + tiles - 1) / tiles;       // aim at ~2 blocks per CU
+  s = std::min(s, nkt / 8);                // keep >= 8 stages per split
+  return std::max(1, std::min(s, 64));
+}
+
+static size_t gemm_slab_floats(const ConvGemmArgs &a, int ci, int *splits_out) {
+  const Cfg &c = kCfgs[ci];
+  int nbm = (a.M + c.bm() - 1) / c.bm(), nbn = (a.NP + c.bn() - 1) / c.bn();
+  int splits = pick_splits(nbm * nbn, a.Rp / kBK);
+  *splits_out = splits;
+  return splits > 1 ? (size_t)splits * a.M * ((a.NP + 3) & ~3) : 0;
+}
+
+static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *slab, hipStream_t st) {
   const Cfg &c = kCfgs[ci];
   a.nbm = (a.M + c.bm() - 1) / c.bm();
   a.nbn = (a.NP + c.bn() - 1) / c.bn();
-  int nblk = a.nbm * a.nbn;
-  if (check)
-    launch_gemm_cfg<true>(ci, a, nblk, st);
-  else
-    launch_gemm_cfg<false>(ci, a, nblk, st);
+  a.nkt = a.Rp / kBK;
+  a.tilesPerSplit = (a.nkt + splits - 1) / splits;
+  splits = (a.nkt + a.tilesPerSplit - 1) / a.tilesPerSplit;
+  a.NPs = (a.NP + 3) & ~3;
+  a.slab = splits > 1 ? slab : nullptr;
+  dim3 grid(a.nbm * a.nbn, splits);
+  {
+    ProfScope ps(0 * 100 + ci * 2 + mode, 2.0 * a.M * (double)a.NP * a.Rtrue, st);
+    if (mode)
+      launch_gemm_cfg<1>(ci, a, grid, st);
+    else
+      launch_gemm_cfg<0>(ci, a, grid, st);
+  }
   XM_LAUNCH_CHECK();
+  if (splits > 1) {
+    size_t n = (size_t)a.M * a.NP;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       a, splits);
+    XM_LAUNCH_CHECK();
+  }
   return XM_OK;
+}
+
+static int choose_cfg(long long M, long long NP) {
+  return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP);
 }
 
 static void launch_wgrad_cfg(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
@@ -167,19 +264,36 @@ static int make_geo(Geo &g, int H, int W, int C, int N, int FH, int FW, int FC, 
   if (Ho <= 0 || Wo <= 0)
     return fail(XM_EINVAL, "vl_nnconv: filter (%dx%d, dilate %dx%d) larger than padded input (%dx%d)",
                 FH, FW, dy, dx, H + pt + pb, W + pl + pr);
-  if (too_big(H, W, C, N) || too_big(Ho, Wo, K, N) || too_big(FH, FW, FC, K))
-    return fail(XM_ETOOBIG, "vl_nnconv: tensor with >= 2^31 elements");
+  // gathers go through 32-bit-offset buffer descriptors: every tensor must stay below 4 GiB
+  if ((long long)H * W * C * N >= (1LL << 30) || (long long)Ho * Wo * K * N >= (1LL << 30) ||
+      (long long)FH * FW * FC * K >= (1LL << 30))
+    return fail(XM_ETOOBIG, "vl_nnconv: tensor with >= 2^30 elements (4 GiB)");
   g = Geo{H, W, C, N, FH, FW, FC, K, G, K / G, Ho, Wo, FH * FW * FC, sy, sx, pt, pb, pl, pr, dy, dx};
   return XM_OK;
 }
 
-// forward tap table: r = u + FH*(v + FW*c)  ->  {offset in X, u*dy, v*dx}
+// forward tap table for the implicit GEMM: r = u + FH*(v + FW*c) -> {byte offset in X, (u,v) index}
+static const int2 *fwd_taps2(const Geo &g, int Rp) {
+  int count = Rp + 2 * kBK;  // kernels fetch the table two stages ahead
+  std::vector<int2> t(count);
+  for (int r = 0; r < count; ++r) {
+    if (r < g.R) {
+      int u = r % g.FH, v = (r / g.FH) % g.FW, c = r / (g.FH * g.FW);
+      t[r] = make_int2(4 * (u * g.dy + g.H * (v * g.dx) + g.H * g.W * c), u + g.FH * v);
+    } else {
+      t[r] = make_int2(0, 63);
+    }
+  }
+  return (const int2 *)cached_device_table(t.data(), t.size() * sizeof(int2));
+}
+
+// wgrad tap table: {byte offset in X, u*dy, v*dx}
 static const int4 *fwd_taps(const Geo &g, int count) {
   std::vector<int4> t(count);
   for (int r = 0; r < count; ++r) {
     if (r < g.R) {
       int u = r % g.FH, v = (r / g.FH) % g.FW, c = r / (g.FH * g.FW);
-      t[r] = make_int4(u * g.dy + g.H * (v * g.dx) + g.H * g.W * c, u * g.dy, v * g.dx, 0);
+      t[r] = make_int4(4 * (u * g.dy + g.H * (v * g.dx) + g.H * g.W * c), u * g.dy, v * g.dx, 0);
     } else {
       t[r] = make_int4(0, -(1 << 28), 0, 0);
     }
@@ -190,14 +304,23 @@ static const int4 *fwd_taps(const Geo &g, int count) {
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st) {
+  if (g.FH * g.FW > 63)
+    return fail(XM_ENOTSUP, "vl_nnconv: filters with more than 63 spatial taps (%dx%d) are not built",
+                g.FH, g.FW);
   const int Rp = (g.R + kBK - 1) / kBK * kBK;
   const bool need_pad = (g.R % kBK) != 0 || ((uintptr_t)f & 15);
+  const int mode = ((g.pt | g.pb | g.pl | g.pr) != 0 || Rp != g.R) ? 1 : 0;
+  const int ci = choose_cfg(g.Kg, (long long)g.Ho * g.Wo * g.N);
+  ConvGemmArgs proto{};
+  proto.M = g.Kg;
+  proto.NP = g.Ho * g.Wo * g.N;
+  proto.Rp = Rp;
+  int splits = 1;
+  size_t slabf = gemm_slab_floats(proto, ci, &splits);
   WsCarver ws;
-  if (need_pad) {
-    int rc = ws.init(WsCarver::need((size_t)g.K * Rp, 4));
-    if (rc) return rc;
-  }
-  const int4 *taps = fwd_taps(g, Rp);
+  int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4));
+  if (rc) return rc;
+  const int2 *taps = fwd_taps2(g, Rp);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
   const float *A = f;
   int lda = g.R;
@@ -210,11 +333,14 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     A = Ap;
     lda = Rp;
   }
-  const bool check = (g.pt | g.pb | g.pl | g.pr) != 0 || Rp != g.R;
+  float *slab = slabf ? ws.take<float>(slabf) : nullptr;
+  const size_t xTotal = (size_t)g.H * g.W * g.C * g.N;
   for (int grp = 0; grp < g.G; ++grp) {
     ConvGemmArgs a{};
     a.A = A + (size_t)grp * g.Kg * lda;
-    a.X = x + (size_t)grp * g.FC * g.H * g.W;
+    size_t xoff = (size_t)grp * g.FC * g.H * g.W;
+    a.X = x + xoff;
+    a.xBytes = (unsigned)((xTotal - xoff) * 4);
     a.Y = y + (size_t)grp * g.Kg * g.Ho * g.Wo;
     a.taps = taps;
     a.bias = b ? b + grp * g.Kg : nullptr;
@@ -225,6 +351,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.lda = lda;
     a.M = g.Kg;
     a.Rp = Rp;
+    a.Rtrue = g.R;
     a.PI = g.Ho;
     a.PJ = g.Wo;
     a.NP = g.Ho * g.Wo * g.N;
@@ -237,6 +364,12 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.LimH = g.H;
     a.LimW = g.W;
     a.xSampleStride = g.H * g.W * g.C;
+    a.nU = g.FH;
+    a.nV = g.FW;
+    a.du0 = 0;
+    a.dus = g.dy;
+    a.dv0 = 0;
+    a.dvs = g.dx;
     a.osy = 1;
     a.osx = 1;
     a.oh0 = 0;
@@ -244,7 +377,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.OH = g.Ho;
     a.oChanStride = g.Ho * g.Wo;
     a.oSampleStride = g.Ho * g.Wo * g.K;
-    int rc = launch_gemm(a, check, st);
+    rc = launch_gemm(a, mode, ci, splits, slab, st);
     if (rc) return rc;
   }
   return XM_OK;
@@ -304,23 +437,41 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   if (!covers_all || cls.empty())
     XM_HIP(hipMemsetAsync(dxo, 0, sizeof(float) * (size_t)g.H * g.W * g.C * g.N, st));
   if (cls.empty()) return XM_OK;
+  // tile configuration / split-K per class (slab sized for the largest class)
+  size_t slab_max = 0;
+  std::vector<int> cls_cfg(cls.size()), cls_splits(cls.size());
+  for (size_t i = 0; i < cls.size(); ++i) {
+    const Cls &c = cls[i];
+    ConvGemmArgs proto{};
+    proto.M = g.FC;
+    proto.NP = c.PI * c.PJ * g.N;
+    proto.Rp = c.Rp;
+    cls_cfg[i] = choose_cfg(proto.M, proto.NP);
+    slab_max = std::max(slab_max, gemm_slab_floats(proto, cls_cfg[i], &cls_splits[i]));
+  }
   WsCarver ws;
-  int rc = ws.init(abytes);
+  int rc = ws.init(abytes + WsCarver::need(slab_max, 4));
   if (rc) return rc;
-  for (const Cls &c : cls) {
+  float *slab = slab_max ? (float *)(ws.base + abytes) : nullptr;
+  const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
+  for (size_t ic = 0; ic < cls.size(); ++ic) {
+    const Cls &c = cls[ic];
+    if (c.nU * c.nV > 63)
+      return fail(XM_ENOTSUP, "vl_nnconv: more than 63 spatial taps per stride class is not built");
     // tap table in dY space: r' = iu + nU*(iv + nV*k); u' = (u*dy - a)/sy; ho = i' - u'
-    std::vector<int4> t(c.Rp);
-    for (int r = 0; r < c.Rp; ++r) {
+    const int up0 = ((c.u0 * g.dy) - c.a) / g.sy, ups = c.ustep * g.dy / g.sy;
+    const int vp0 = ((c.v0 * g.dx) - c.b) / g.sx, vps = c.vstep * g.dx / g.sx;
+    std::vector<int2> t(c.Rp + 2 * kBK);
+    for (int r = 0; r < c.Rp + 2 * kBK; ++r) {
       if (r < c.Rc) {
         int iu = r % c.nU, iv = (r / c.nU) % c.nV, k = r / (c.nU * c.nV);
-        int up = ((c.u0 + iu * c.ustep) * g.dy - c.a) / g.sy;
-        int vp = ((c.v0 + iv * c.vstep) * g.dx - c.b) / g.sx;
-        t[r] = make_int4(-up - g.Ho * vp + g.Ho * g.Wo * k, -up, -vp, 0);
+        int up = up0 + iu * ups, vp = vp0 + iv * vps;
+        t[r] = make_int2(4 * (-up - g.Ho * vp + g.Ho * g.Wo * k), iu + c.nU * iv);
       } else {
-        t[r] = make_int4(0, -(1 << 28), 0, 0);
+        t[r] = make_int2(0, 63);
       }
     }
-    const int4 *taps = (const int4 *)cached_device_table(t.data(), t.size() * sizeof(int4));
+    const int2 *taps = (const int2 *)cached_device_table(t.data(), t.size() * sizeof(int2));
     if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
     float *At = (float *)(ws.base + c.aoff);
     for (int grp = 0; grp < g.G; ++grp) {
@@ -333,11 +484,14 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       ConvGemmArgs a{};
       a.A = Ag;
       a.lda = c.Rp;
-      a.X = dzdy + (size_t)grp * g.Kg * g.Ho * g.Wo;
+      size_t xoff = (size_t)grp * g.Kg * g.Ho * g.Wo;
+      a.X = dzdy + xoff;
+      a.xBytes = (unsigned)((dyTotal - xoff) * 4);
       a.Y = dxo + (size_t)grp * g.FC * g.H * g.W;
       a.taps = taps;
       a.M = g.FC;
       a.Rp = c.Rp;
+      a.Rtrue = c.Rc;
       a.PI = c.PI;
       a.PJ = c.PJ;
       a.NP = c.PI * c.PJ * g.N;
@@ -350,6 +504,12 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.LimH = g.Ho;
       a.LimW = g.Wo;
       a.xSampleStride = g.Ho * g.Wo * g.K;
+      a.nU = c.nU;
+      a.nV = c.nV;
+      a.du0 = -up0;
+      a.dus = -ups;
+      a.dv0 = -vp0;
+      a.dvs = -vps;
       a.osy = g.sy;
       a.osx = g.sx;
       a.oh0 = c.hi0;
@@ -357,7 +517,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.OH = g.H;
       a.oChanStride = g.H * g.W;
       a.oSampleStride = g.H * g.W * g.C;
-      rc = launch_gemm(a, true, st);
+      rc = launch_gemm(a, 1, cls_cfg[ic], cls_splits[ic], slab, st);
       if (rc) return rc;
     }
   }
@@ -365,7 +525,20 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
 }
 
 static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
-  int ci = g_force_cfg >= 0 ? g_force_cfg : pick_cfg(g.Kg, g.R);
+  int ci = g_force_cfg;
+  if (ci < 0) {
+    double best = 1e300;
+    for (int i = 0; i < kNumCfg; ++i) {
+      const Cfg &cc = kCfgs[i];
+      double eff = (cc.tm * cc.tn >= 4) ? 1.0 : (cc.tm * cc.tn >= 2 ? 1.12 : 1.3);
+      double cost = (double)((g.Kg + cc.bm() - 1) / cc.bm() * cc.bm()) *
+                    ((g.R + cc.bn() - 1) / cc.bn() * cc.bn()) * eff;
+      if (cost < best) {
+        best = cost;
+        ci = i;
+      }
+    }
+  }
   const Cfg &c = kCfgs[ci];
   const int NP = g.Ho * g.Wo * g.N;
   const int nkt = (NP + kBK - 1) / kBK;
@@ -374,7 +547,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   // split the pixel reduction until the grid fills the chip about twice
   int tiles = nbm * nbn;
   int splits = std::max(1, std::min(nkt / 8, (512 + tiles - 1) / tiles));
-  splits = std::min(splits, 64);
+  splits = std::min(splits, 256);
   int tps = (nkt + splits - 1) / splits;
   splits = (nkt + tps - 1) / tps;
   const int4 *taps = fwd_taps(g, Rn);
@@ -394,6 +567,11 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
     float *dst = dfo + (size_t)grp * g.Kg * g.R;
     a.out = splits > 1 ? part : dst;
     a.taps = taps;
+    {
+      size_t xoff = (size_t)grp * g.FC * g.H * g.W, doff = (size_t)grp * g.Kg * g.Ho * g.Wo;
+      a.xBytes = (unsigned)(((size_t)g.H * g.W * g.C * g.N - xoff) * 4);
+      a.dyBytes = (unsigned)(((size_t)g.Ho * g.Wo * g.K * g.N - doff) * 4);
+    }
     a.M = g.Kg;
     a.R = g.R;
     a.Rn = Rn;
@@ -417,7 +595,10 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
     a.tilesPerSplit = tps;
     a.nkt = nkt;
     a.splitStride = slab;
-    launch_wgrad_cfg(ci, a, dim3(nbm * nbn, splits), st);
+    {
+      ProfScope ps(1 * 100 + ci * 2, 2.0 * g.Kg * (double)NP * g.R, st);
+      launch_wgrad_cfg(ci, a, dim3(nbm * nbn, splits), st);
+    }
     XM_LAUNCH_CHECK();
     if (splits > 1) {
       hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st,
@@ -440,6 +621,67 @@ int xm_debug_force_conv_cfg(int cfg) {
   return old;
 }
 int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
+int xm_debug_force_conv_splits(int splits) {
+  int old = g_force_splits;
+  g_force_splits = splits > 0 ? splits : 0;
+  return old;
+}
+
+// ---- include/xmodal_prof.h ------------------------------------------------------------------
+int xm_prof_enable(int on) {
+  if (on) {
+    for (auto &r : g_prof) {
+      g_event_pool.push_back(r.start);
+      g_event_pool.push_back(r.stop);
+    }
+    g_prof.clear();
+  }
+  g_prof_on = on != 0;
+  return XM_OK;
+}
+
+// Aggregates the recorded launches by kernel instantiation.  Caller must have synchronised the
+// stream(s).  Returns the number of distinct kernels; fills up to `cap` entries.
+int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, long long *launches) {
+  std::vector<int> ks;
+  std::vector<double> ms, fl;
+  std::vector<long long> cnt;
+  for (auto &r : g_prof) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) continue;
+    size_t i = 0;
+    for (; i < ks.size(); ++i)
+      if (ks[i] == r.key) break;
+    if (i == ks.size()) {
+      ks.push_back(r.key);
+      ms.push_back(0);
+      fl.push_back(0);
+      cnt.push_back(0);
+    }
+    ms[i] += t;
+    fl[i] += r.flops;
+    cnt[i] += 1;
+  }
+  for (size_t i = 0; i < ks.size() && (int)i < cap; ++i) {
+    keys[i] = ks[i];
+    total_ms[i] = ms[i];
+    total_flops[i] = fl[i];
+    launches[i] = cnt[i];
+  }
+  return (int)ks.size();
+}
+
+// human-readable kernel name of a profiler key, matching the rocprofv3 kernel-trace name
+int xm_prof_kernel_name(int key, char *buf, int len) {
+  int kind = key / 100, ci = (key % 100) / 2, check = key % 2;
+  if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
+  const Cfg &c = kCfgs[ci];
+  if (kind == 0)
+    snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, check);
+  else
+    snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn);
+  return XM_OK;
+}
 
 int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const float *f, int FH,
                             int FW, int FC, int K, const float *b, float *y, int sy, int sx,
@@ -472,7 +714,17 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
   if (!dzdy) return fail(XM_EINVAL, "vl_nnconv: DZDY is NULL in backward mode");
   hipStream_t st = (hipStream_t)stream;
   if (db_out) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(K), dim3(256), 0, st, dzdy, db_out, g.Ho * g.Wo, K, N);
+    int S = std::max(1, std::min(N, 2048 / K));
+    if ((long long)g.Ho * g.Wo < 1024) S = 1;
+    WsCarver ws;
+    rc = ws.init(WsCarver::need((size_t)K * S, 4));
+    if (rc) return rc;
+    float *part = ws.take<float>((size_t)K * S);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(K, S), dim3(256), 0, st, dzdy, part, g.Ho * g.Wo,
+                       K, N, S);
+    XM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part, db_out,
+                       K, S);
     XM_LAUNCH_CHECK();
   }
   if (df_out) {

@@ -8,33 +8,51 @@
 //             A = the filter bank itself (FH x FW x FC x K column-major == [K][R] row-major)
 //   dgrad   : m = input channel,  p = input pixel of one stride-parity class, r = (u',v',k)
 //             A = transposed / parity-split filters (prep_dgrad_filter)
+//   wgrad   : m = output channel, p = filter tap, reduction over output pixels
 //   G(p, r) = X[base(p) + off(r)] if the tap lands inside the source image, else 0 -- an
 //             im2col that only ever exists as LDS tiles (never in HBM).
 // MATLAB layout is H-fastest, so pixels are the contiguous axis of both the gather source and
 // the destination: pixels go on the MFMA "column" (lane & 31) axis, which makes every global
 // access of a wave a run of consecutive addresses along H.
+//
+// CDNA4 specifics used here
+//   * gathers are raw buffer loads: an out-of-image tap gets byte offset 0xFFFFFFFF, the buffer
+//     bounds check returns 0.0f -- no select, no branch, no mask in the staging path;
+//   * validity of a tap depends only on its (u,v) for a given pixel: each thread computes a
+//     64-bit "invalid (u,v)" mask once, a tap then costs bfe + or + add;
+//   * the K loop is unrolled x2 so that every LDS address is base + immediate;
+//   * sched_group_barrier interleaves the next stage's address arithmetic and buffer loads
+//     between the current stage's MFMAs (the MFMA pipe is busy 64 cycles per instruction, the
+//     wave can issue ~15 other instructions meanwhile), so one wave per SIMD already overlaps;
+//   * split-K (grid.y) for layers with few output tiles; partial slabs are combined in a fixed
+//     order by conv_splitk_epilogue_kernel (deterministic, no atomics).
 #pragma once
 #include "xm_common.h"
 
 namespace xm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvGemmArgs {
   const float *A;     // [M][lda], lda % 4 == 0, 16-byte aligned, zero padded to Rp columns
   const float *X;     // gather source
   float *Y;           // destination
-  const int4 *taps;   // Rp entries {off, du, dv, 0}; padding entries have du = -2^28
+  float *slab;        // splits > 1: [splits][M][NPs] raw partial sums
+  const int2 *taps;   // Rp + 2*kBK entries {byte offset, (u,v) index}; padding entries use index 63
   const float *bias, *scale, *shift, *resid;
   int relu;
-  int lda, M, Rp;
-  int PI, PJ, NP;     // pixel grid (i fastest) and total pixel count PI*PJ*N
+  unsigned xBytes;    // size of the gather source in bytes (buffer bounds check)
+  int lda, M, Rp, Rtrue;
+  int PI, PJ, NP, NPs;  // pixel grid (i fastest), total pixel count PI*PJ*N, slab row pitch
   FastDiv divPIJ, divPI;
   int gsy, gsx, gh0, gw0;  // gather origin of pixel (i,j): (i*gsy + gh0, j*gsx + gw0)
   int LimH, LimW, xSampleStride;
-  int osy, osx, oh0, ow0, OH;  // destination position of pixel (i,j): (oh0 + i*osy, ow0 + j*osx)
+  int nU, nV, du0, dus, dv0, dvs;  // tap (iu,iv) sits at (du0 + iu*dus, dv0 + iv*dvs) from the origin
+  int osy, osx, oh0, ow0, OH;      // destination of pixel (i,j): (oh0 + i*osy, ow0 + j*osx)
   int oChanStride, oSampleStride;
   int nbm, nbn;       // tile counts
+  int tilesPerSplit, nkt;
 };
 
 // XCD-aware, bijective block remap: consecutive logical tiles (which share the same pixel tile)
@@ -51,12 +69,52 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 constexpr int kBK = 16;  // reduction depth per LDS stage
 constexpr int kNG = 4;   // float4 groups per stage (kBK / 4)
 
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// sched_group_barrier masks
+#define XM_SGB_VALU 0x002
+#define XM_SGB_MFMA 0x008
+#define XM_SGB_VMEM_RD 0x020
+#define XM_SGB_DS_RD 0x100
+#define XM_SGB_DS_WR 0x200
+
 // LDS image of both operands: [stage][group g = k/4][row][k%4] so that one ds_read_b128 hands a
 // lane four consecutive k of its row.  MFMA 32x32x2 takes k from lane>>5, so lanes 0-31 read
 // group 2s and lanes 32-63 group 2s+1; the e-th MFMA of a chunk then sums k = 8s+e and 8s+4+e
 // -- A and B use the same assignment, so the dot product is complete and exact.
-template <int TM, int TN, int WGM, int WGN, bool CHECK>
-__global__ void __launch_bounds__(256)
+#define XM_COMPUTE(CUR)                                                        \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                           \
+    f32x4 af[TM], bf[TN];                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
+      af[i] = *reinterpret_cast<const f32x4 *>(sAr + ((CUR) * kNG + 2 * s_) * PLA + i * 128); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                             \
+      bf[j] = *reinterpret_cast<const f32x4 *>(sBr + ((CUR) * kNG + 2 * s_) * PLB + j * 128); \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0); \
+      }                                                                        \
+  }
+
+// interleave recipe for one stage: per 8-k chunk, the fragment reads, then each MFMA followed by a
+// few VALU and one buffer load of the next stage
+#define XM_INTERLEAVE(NVALU)                                                   \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                           \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, TM + TN, 0);            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {               \
+      __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(XM_SGB_VALU, NVALU, 0);             \
+      __builtin_amdgcn_sched_group_barrier(XM_SGB_VMEM_RD, 1, 0);              \
+    }                                                                          \
+  }
+
+// MODE 0: every tap is inside the image (pad == 0, Rp == R);  MODE 1: (u,v) validity mask.
+template <int TM, int TN, int WGM, int WGN, int MODE>
+__global__ void __launch_bounds__(256, 2)
 conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(WGM * WGN == 4, "4 waves per block");
@@ -73,78 +131,120 @@ conv_gemm_kernel(const ConvGemmArgs a) {
   const int wm = wave % WGM, wn = wave / WGM;
   const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
   const int bm = tile % a.nbm, bn = tile / a.nbm;
+  const int split = blockIdx.y;
+  const int kt0 = split * a.tilesPerSplit;
+  const int kt1 = min(a.nkt, kt0 + a.tilesPerSplit);
 
   // ---- per-thread gather geometry (fixed for the whole reduction) ----
   const int pl = t % BN, gB0 = t / BN;
-  int ph, pw, xbase;
+  unsigned xbase4;            // byte offset of the pixel's gather origin (may wrap below zero)
+  unsigned inv_lo = 0, inv_hi = 0x80000000u;  // bit (u,v) set <=> that tap is outside the image
   {
     int p = bn * BN + pl;
-    bool pvalid = p < a.NP;
-    uint32_t pc = pvalid ? p : a.NP - 1;
+    uint32_t pc = p < a.NP ? p : a.NP - 1;  // clamp: columns >= NP are never stored
     uint32_t n = xm_div(pc, a.divPIJ);
     uint32_t q = pc - n * a.divPIJ.d;
     uint32_t j = xm_div(q, a.divPI);
     uint32_t i = q - j * a.divPI.d;
-    ph = (int)i * a.gsy + a.gh0;
-    pw = (int)j * a.gsx + a.gw0;
-    xbase = ph + a.LimH * pw + (int)n * a.xSampleStride;
-    if (CHECK && !pvalid) ph = -(1 << 28);
-  }
-  const float *__restrict__ X = a.X;
-  const float *__restrict__ A = a.A;
-  const int4 *__restrict__ taps = a.taps;
-
-  float4 ra[NUA], rb[NUB];
-
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NUA; ++i) {
-      int u = t + 256 * i;
-      int g = u % kNG, m = u / kNG;
-      int gm = bm * BM + m;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((kNG * BM % 256 == 0 || u < kNG * BM) && gm < a.M)
-        v = *reinterpret_cast<const float4 *>(A + (size_t)gm * a.lda + kt * kBK + g * 4);
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NUB; ++i) {
-      int g = gB0 + i * (256 / BN);
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (kNG * BN % 256 == 0 || g < kNG) {
-        int r0 = kt * kBK + g * 4;
-        if (UNIFORM) r0 = __builtin_amdgcn_readfirstlane(r0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int4 tp = taps[r0 + e];
-          if (CHECK) {
-            bool ok = (unsigned)(ph + tp.y) < (unsigned)a.LimH &&
-                      (unsigned)(pw + tp.z) < (unsigned)a.LimW;
-            if (ok) v[e] = X[xbase + tp.x];
-          } else {
-            v[e] = X[xbase + tp.x];
-          }
+    int ph = (int)i * a.gsy + a.gh0;
+    int pw = (int)j * a.gsx + a.gw0;
+    xbase4 = (unsigned)(ph + a.LimH * pw + (int)n * a.xSampleStride) * 4u;
+    if (MODE == 1) {
+      int uv = 0;
+      for (int iv = 0; iv < a.nV; ++iv) {
+        bool okw = (unsigned)(pw + a.dv0 + iv * a.dvs) < (unsigned)a.LimW;
+        for (int iu = 0; iu < a.nU; ++iu, ++uv) {
+          bool ok = okw & ((unsigned)(ph + a.du0 + iu * a.dus) < (unsigned)a.LimH);
+          unsigned bit = ok ? 0u : 1u;
+          if (uv < 32) inv_lo |= bit << uv;
+          else inv_hi |= bit << (uv - 32);
         }
       }
-      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
-  };
-  auto store_tile = [&](int buf) {
+  }
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  const int2 *__restrict__ taps = a.taps;
+
+  // A operand: per-unit row pointer (rows >= M clamped: they only feed rows never stored)
+  const float *aptr[NUA];
 #pragma unroll
-    for (int i = 0; i < NUA; ++i) {
-      int u = t + 256 * i;
-      if (kNG * BM % 256 == 0 || u < kNG * BM) {
-        int g = u % kNG, m = u / kNG;
-        *reinterpret_cast<float4 *>(sA + (buf * kNG + g) * PLA + m * 4) = ra[i];
-      }
-    }
+  for (int i = 0; i < NUA; ++i) {
+    int u = t + 256 * i;
+    if (kNG * BM % 256 != 0 && u >= kNG * BM) u = kNG * BM - 1;
+    int g = u % kNG, m = u / kNG;
+    int gm = min(bm * BM + m, a.M - 1);
+    aptr[i] = a.A + (size_t)gm * a.lda + g * 4;
+  }
+  // LDS addresses: everything below is base + compile-time immediate
+  float *sAw[NUA], *sBw[NUB];
 #pragma unroll
-    for (int i = 0; i < NUB; ++i) {
-      int g = gB0 + i * (256 / BN);
-      if (kNG * BN % 256 == 0 || g < kNG)
-        *reinterpret_cast<float4 *>(sB + (buf * kNG + g) * PLB + pl * 4) = rb[i];
-    }
-  };
+  for (int i = 0; i < NUA; ++i) {
+    int u = t + 256 * i;
+    int g = u % kNG, m = u / kNG;
+    sAw[i] = sA + g * PLA + m * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < NUB; ++i) {
+    int g = gB0 + i * (256 / BN);
+    sBw[i] = sB + g * PLB + pl * 4;
+  }
+  const int half = lane >> 5, l31 = lane & 31;
+  const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
+  const float *sBr = sB + half * PLB + (wn * TN * 32 + l31) * 4;
+
+  f32x4 ra[NUA], rb[NUB];
+  int tpo[NUB * 4], tpi[NUB * 4];  // next tile's tap entries
+
+#define XM_FETCH_TAPS(KT)                                                      \
+  _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
+    int g_ = gB0 + i * (256 / BN);                                             \
+    if (kNG * BN % 256 != 0) g_ = min(g_, kNG - 1);                            \
+    int r0_ = (KT) * kBK + g_ * 4;                                             \
+    if (UNIFORM) r0_ = __builtin_amdgcn_readfirstlane(r0_);                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
+      int2 t_ = taps[r0_ + e];                                                 \
+      tpo[4 * i + e] = t_.x;                                                   \
+      tpi[4 * i + e] = t_.y;                                                   \
+    }                                                                          \
+  }
+
+#define XM_LOAD_TILE(KT)                                                       \
+  _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
+    ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + (KT) * kBK);            \
+  _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
+    unsigned off_[4];                                                          \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
+      off_[e] = xbase4 + (unsigned)tpo[4 * i + e];                             \
+      if (MODE == 1) {                                                         \
+        int idx_ = tpi[4 * i + e];                                             \
+        unsigned w_ = idx_ >= 32 ? inv_hi : inv_lo;                            \
+        off_[e] |= (unsigned)(((int)(w_ << (31 - (idx_ & 31)))) >> 31);        \
+      }                                                                        \
+    }                                                                          \
+    rb[i].x = buf_load(xrsrc, off_[0]);                                        \
+    rb[i].y = buf_load(xrsrc, off_[1]);                                        \
+    rb[i].z = buf_load(xrsrc, off_[2]);                                        \
+    rb[i].w = buf_load(xrsrc, off_[3]);                                        \
+  }
+
+#define XM_STORE_TILE(BUF)                                                     \
+  _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
+    if (kNG * BM % 256 == 0 || t + 256 * i < kNG * BM)                         \
+      *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = ra[i];          \
+  _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
+    if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
+      *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = rb[i];
+
+  // one pipeline stage: issue stage KT+1's loads, compute stage CUR from LDS, park KT+1 in LDS
+#define XM_STAGE(KT, CUR)                                                      \
+  XM_LOAD_TILE((KT) + 1)                                                       \
+  XM_FETCH_TAPS((KT) + 2)                                                      \
+  XM_COMPUTE(CUR)                                                              \
+  XM_INTERLEAVE(MODE == 1 ? 3 : 2)                                             \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  XM_STORE_TILE((CUR) ^ 1)                                                     \
+  __syncthreads();
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -154,42 +254,49 @@ conv_gemm_kernel(const ConvGemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = a.Rp / kBK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  const int half = lane >> 5, l31 = lane & 31;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  // the tap table carries 2*kBK padding entries, so fetching ahead is always legal
+  if (kt0 < kt1) {
+    XM_FETCH_TAPS(kt0)
+    XM_LOAD_TILE(kt0)
+    XM_FETCH_TAPS(kt0 + 1)
+    XM_STORE_TILE(0)
+    __syncthreads();
+    int kt = kt0;
+    for (; kt + 2 < kt1; kt += 2) {
+      XM_STAGE(kt, 0)
+      XM_STAGE(kt + 1, 1)
+    }
+    if (kt + 2 == kt1) {
+      XM_STAGE(kt, 0)
+      XM_COMPUTE(1)
+    } else {
+      XM_COMPUTE(0)
+    }
+  }
+#undef XM_FETCH_TAPS
+#undef XM_LOAD_TILE
+#undef XM_STORE_TILE
+#undef XM_STAGE
+
+  // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (a.slab) {
+    // split-K: raw partial sums, [split][m][p] with p contiguous
+    float *out = a.slab + (size_t)split * a.M * a.NPs;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int g = 2 * s + half;
-      float4 af[TM], bf[TN];
+    for (int j = 0; j < TN; ++j) {
+      int p = bn * BN + (wn * TN + j) * 32 + l31;
+      if (p >= a.NP) continue;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const float4 *>(sA + (cur * kNG + g) * PLA +
-                                                  ((wm * TM + i) * 32 + l31) * 4);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const float4 *>(sB + (cur * kNG + g) * PLB +
-                                                  ((wn * TN + j) * 32 + l31) * 4);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          int m = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < a.M) out[(size_t)m * a.NPs + p] = acc[i][j][r];
         }
     }
-    if (kt + 1 < nkt) store_tile(cur ^ 1);
-    __syncthreads();
+    return;
   }
-
   // ---- epilogue: bias -> per-channel affine -> residual -> relu -> store ----
-  // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     int p = bn * BN + (wn * TN + j) * 32 + l31;
@@ -219,16 +326,42 @@ conv_gemm_kernel(const ConvGemmArgs a) {
   }
 }
 
+// combine split-K slabs in split order and apply the fused epilogue; one thread per (m, p)
+__global__ void __launch_bounds__(256)
+conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits) {
+  size_t idx = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (idx >= (size_t)a.M * a.NP) return;
+  int m = (int)(idx / a.NP);
+  int p = (int)(idx - (size_t)m * a.NP);
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + p];
+  uint32_t n = xm_div((uint32_t)p, a.divPIJ);
+  uint32_t q = (uint32_t)p - n * a.divPIJ.d;
+  uint32_t jj = xm_div(q, a.divPI);
+  uint32_t ii = q - jj * a.divPI.d;
+  int off = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride +
+            m * a.oChanStride;
+  if (a.bias) v += a.bias[m];
+  if (a.scale) v = v * a.scale[m] + a.shift[m];
+  if (a.resid) v += a.resid[off];
+  if (a.relu) v = fmaxf(v, 0.f);
+  a.Y[off] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // wgrad:  dF[k][r] = sum_p dY[k][p] * G(p, r)      (p = flat output pixel (ho, wo, n))
 // MFMA rows = output channel k, MFMA cols = tap r (contiguous in dF), reduction = pixels.
+// A stage covers 16 consecutive flat pixels; the 4-pixel group a wave stages is wave-uniform, so
+// its (n, wo, ho) decode runs on the scalar unit.  Each thread owns one tap for the whole kernel:
+// validity of (pixel, tap) = ho in [holo, hohi) and wo in [wolo, wohi), precomputed per thread.
 // Split over the pixel range (grid.y); partials go to a workspace slab per split and are summed
 // by reduce_splits_kernel in a fixed order (deterministic, no atomics).
 struct WgradArgs {
   const float *dY;   // [Ho*Wo][K][N]
   const float *X;    // gather source (forward input)
   float *out;        // [splits][M][ldo]
-  const int4 *taps;  // Rn entries (forward tap table), padded entries du = -2^28
+  const int4 *taps;  // Rn entries {byte offset, du, dv, 0}; padded entries du = -2^28
+  unsigned xBytes, dyBytes;
   int M, R, Rn, ldo;  // Rn = taps rounded up to BN
   int Ho, Wo, NP;     // output pixel grid, NP = Ho*Wo*N
   FastDiv divHW, divHo;
@@ -240,7 +373,7 @@ struct WgradArgs {
 };
 
 template <int TM, int TN, int WGM, int WGN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 conv_wgrad_kernel(const WgradArgs a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(WGM * WGN == 4, "4 waves per block");
@@ -248,6 +381,8 @@ conv_wgrad_kernel(const WgradArgs a) {
   constexpr int PLA = BM * 4 + 4, PLB = BN * 4 + 4;
   constexpr int NUA = (kNG * BM + 255) / 256;
   constexpr int NUB = (kNG * BN + 255) / 256;
+  // a wave's 64 lanes stay inside one pixel group when the row count is a multiple of 64
+  constexpr bool UNI_A = BM % 64 == 0, UNI_B = BN % 64 == 0;
   __shared__ __attribute__((aligned(16))) float smem[2 * kNG * (PLA + PLB)];
   float *sA = smem;
   float *sB = smem + 2 * kNG * PLA;
@@ -260,82 +395,119 @@ conv_wgrad_kernel(const WgradArgs a) {
   const int kt0 = split * a.tilesPerSplit;
   const int kt1 = min(a.nkt, kt0 + a.tilesPerSplit);
 
-  // the thread's tap (fixed for the whole reduction): B units are (tap = pl, pixel group g)
-  const int pl = t % BN, gB0 = t / BN;
-  const int4 tp = a.taps[bn * BN + pl];
-  const float *__restrict__ X = a.X;
-  const float *__restrict__ dY = a.dY;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
 
-  float4 ra[NUA], rb[NUB];
+  // B: the thread's tap (fixed) and the pixel ranges for which it lands inside the image
+  const int plB = t % BN, gB0 = t / BN;
+  const int4 tp = a.taps[bn * BN + plB];
+  int holo, hon, wolo, won;  // valid ho in [holo, holo + hon), same for wo (unsigned compare)
+  {
+    // hi = ho*sy - pt + du in [0, H)  <=>  ho in [ceil((pt-du)/sy), floor((H-1+pt-du)/sy)]
+    int lo = a.pt - tp.y, hi = a.H - 1 + a.pt - tp.y;
+    holo = lo <= 0 ? 0 : (lo + a.sy - 1) / a.sy;
+    int hohi = hi < 0 ? -1 : hi / a.sy;
+    hohi = min(hohi, a.Ho - 1);
+    hon = max(hohi - holo + 1, 0);
+    lo = a.pl_ - tp.z;
+    hi = a.W - 1 + a.pl_ - tp.z;
+    wolo = lo <= 0 ? 0 : (lo + a.sx - 1) / a.sx;
+    int wohi = hi < 0 ? -1 : hi / a.sx;
+    wohi = min(wohi, a.Wo - 1);
+    won = max(wohi - wolo + 1, 0);
+  }
+  // A: unit u -> (row m = u % BM, pixel group g = u / BM): lanes run along channel rows
+  unsigned arow4[NUA];
+#pragma unroll
+  for (int i = 0; i < NUA; ++i) {
+    int u = t + 256 * i;
+    if (kNG * BM % 256 != 0 && u >= kNG * BM) u = kNG * BM - 1;
+    int m = u % BM;
+    int gm = min(bm * BM + m, a.M - 1);
+    arow4[i] = (unsigned)(gm * a.dyChanStride) * 4u;
+  }
+  float *sAw[NUA], *sBw[NUB];
+#pragma unroll
+  for (int i = 0; i < NUA; ++i) {
+    int u = t + 256 * i;
+    int m = u % BM, g = u / BM;
+    sAw[i] = sA + g * PLA + m * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < NUB; ++i) {
+    int g = gB0 + i * (256 / BN);
+    sBw[i] = sB + g * PLB + plB * 4;
+  }
+  const int half = lane >> 5, l31 = lane & 31;
+  const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
+  const float *sBr = sB + half * PLB + (wn * TN * 32 + l31) * 4;
 
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NUA; ++i) {
-      int u = t + 256 * i;
-      int g = u % kNG, m = u / kNG;
-      int gm = bm * BM + m;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if ((kNG * BM % 256 == 0 || u < kNG * BM) && gm < a.M) {
-        uint32_t p = (uint32_t)(kt * kBK + g * 4);
-        uint32_t n = xm_div(p, a.divHW);
-        uint32_t q = p - n * a.divHW.d;
-        int base = gm * a.dyChanStride;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if ((int)p + e < a.NP) v[e] = dY[base + (int)q + (int)n * a.dySampleStride];
-          if (++q == a.divHW.d) {
-            q = 0;
-            ++n;
-          }
-        }
-      }
-      ra[i] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-#pragma unroll
-    for (int i = 0; i < NUB; ++i) {
-      int g = gB0 + i * (256 / BN);
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (kNG * BN % 256 == 0 || g < kNG) {
-        uint32_t p = (uint32_t)(kt * kBK + g * 4);
-        uint32_t n = xm_div(p, a.divHW);
-        uint32_t q = p - n * a.divHW.d;
-        uint32_t wo = xm_div(q, a.divHo);
-        uint32_t ho = q - wo * a.divHo.d;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int hi = (int)ho * a.sy - a.pt + tp.y;
-          int wi = (int)wo * a.sx - a.pl_ + tp.z;
-          bool ok = (int)p + e < a.NP && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-          if (ok) v[e] = X[((int)ho * a.sy - a.pt) + a.H * ((int)wo * a.sx - a.pl_) +
-                           (int)n * a.xSampleStride + tp.x];
-          if (++ho == a.divHo.d) {
-            ho = 0;
-            if (++wo == (uint32_t)a.Wo) {
-              wo = 0;
-              ++n;
-            }
-          }
-        }
-      }
-      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NUA; ++i) {
-      int u = t + 256 * i;
-      if (kNG * BM % 256 == 0 || u < kNG * BM) {
-        int g = u % kNG, m = u / kNG;
-        *reinterpret_cast<float4 *>(sA + (buf * kNG + g) * PLA + m * 4) = ra[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NUB; ++i) {
-      int g = gB0 + i * (256 / BN);
-      if (kNG * BN % 256 == 0 || g < kNG)
-        *reinterpret_cast<float4 *>(sB + (buf * kNG + g) * PLB + pl * 4) = rb[i];
-    }
-  };
+  f32x4 ra[NUA], rb[NUB];
+
+  // decode 4 consecutive flat pixels starting at P0 (wave-uniform when UNI): per pixel the dY
+  // byte offset (sans channel row) and the x byte offset of the gather origin, plus ho / wo
+#define XM_WLOAD_TILE(KT)                                                      \
+  _Pragma("unroll") for (int i = 0; i < NUA; ++i) {                            \
+    int u_ = t + 256 * i;                                                      \
+    if (kNG * BM % 256 != 0 && u_ >= kNG * BM) u_ = kNG * BM - 1;              \
+    int g_ = u_ / BM;                                                          \
+    if (UNI_A) g_ = __builtin_amdgcn_readfirstlane(g_);                        \
+    unsigned off_[4];                                                          \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
+      uint32_t p_ = (uint32_t)((KT) * kBK + g_ * 4 + e);                       \
+      uint32_t n_ = xm_div(p_, a.divHW);                                       \
+      uint32_t q_ = p_ - n_ * a.divHW.d;                                       \
+      unsigned o_ = (q_ + n_ * (unsigned)a.dySampleStride) * 4u;               \
+      unsigned m_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu;                         \
+      off_[e] = (arow4[i] + o_) | m_;                                          \
+    }                                                                          \
+    ra[i].x = buf_load(dyrsrc, off_[0]);                                       \
+    ra[i].y = buf_load(dyrsrc, off_[1]);                                       \
+    ra[i].z = buf_load(dyrsrc, off_[2]);                                       \
+    ra[i].w = buf_load(dyrsrc, off_[3]);                                       \
+  }                                                                            \
+  _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
+    int g_ = gB0 + i * (256 / BN);                                             \
+    if (kNG * BN % 256 != 0) g_ = min(g_, kNG - 1);                            \
+    if (UNI_B) g_ = __builtin_amdgcn_readfirstlane(g_);                        \
+    unsigned off_[4];                                                          \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
+      uint32_t p_ = (uint32_t)((KT) * kBK + g_ * 4 + e);                       \
+      uint32_t n_ = xm_div(p_, a.divHW);                                       \
+      uint32_t q_ = p_ - n_ * a.divHW.d;                                       \
+      uint32_t wo_ = xm_div(q_, a.divHo);                                      \
+      uint32_t ho_ = q_ - wo_ * a.divHo.d;                                     \
+      int pix_ = ((int)ho_ * a.sy - a.pt) + a.H * ((int)wo_ * a.sx - a.pl_) +  \
+                 (int)n_ * a.xSampleStride;                                    \
+      unsigned pm_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu;                        \
+      bool ok_ = ((unsigned)((int)ho_ - holo) < (unsigned)hon) &               \
+                 ((unsigned)((int)wo_ - wolo) < (unsigned)won);                \
+      unsigned o_ = ((unsigned)pix_ * 4u + (unsigned)tp.x) | pm_;              \
+      off_[e] = ok_ ? o_ : 0xFFFFFFFFu;                                        \
+    }                                                                          \
+    rb[i].x = buf_load(xrsrc, off_[0]);                                        \
+    rb[i].y = buf_load(xrsrc, off_[1]);                                        \
+    rb[i].z = buf_load(xrsrc, off_[2]);                                        \
+    rb[i].w = buf_load(xrsrc, off_[3]);                                        \
+  }
+
+#define XM_WSTORE_TILE(BUF)                                                    \
+  _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
+    if (kNG * BM % 256 == 0 || t + 256 * i < kNG * BM)                         \
+      *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = ra[i];          \
+  _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
+    if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
+      *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = rb[i];
+
+#define XM_WSTAGE(KT, CUR)                                                     \
+  XM_WLOAD_TILE((KT) + 1)                                                      \
+  XM_COMPUTE(CUR)                                                              \
+  XM_INTERLEAVE(4)                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  XM_WSTORE_TILE((CUR) ^ 1)                                                    \
+  __syncthreads();
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -345,40 +517,25 @@ conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int half = lane >> 5, l31 = lane & 31;
   if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile(kt + 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int g = 2 * s + half;
-      float4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const float4 *>(sA + (cur * kNG + g) * PLA +
-                                                  ((wm * TM + i) * 32 + l31) * 4);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const float4 *>(sB + (cur * kNG + g) * PLB +
-                                                  ((wn * TN + j) * 32 + l31) * 4);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (kt + 1 < kt1) store_tile(cur ^ 1);
+    XM_WLOAD_TILE(kt0)
+    XM_WSTORE_TILE(0)
     __syncthreads();
+    int kt = kt0;
+    for (; kt + 2 < kt1; kt += 2) {
+      XM_WSTAGE(kt, 0)
+      XM_WSTAGE(kt + 1, 1)
+    }
+    if (kt + 2 == kt1) {
+      XM_WSTAGE(kt, 0)
+      XM_COMPUTE(1)
+    } else {
+      XM_COMPUTE(0)
+    }
   }
+#undef XM_WLOAD_TILE
+#undef XM_WSTORE_TILE
+#undef XM_WSTAGE
 
   float *out = a.out + (size_t)split * a.splitStride;
 #pragma unroll
@@ -394,5 +551,8 @@ conv_wgrad_kernel(const WgradArgs a) {
       }
   }
 }
+
+#undef XM_COMPUTE
+#undef XM_INTERLEAVE
 
 }  // namespace xm

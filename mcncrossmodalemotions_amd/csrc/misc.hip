@@ -289,6 +289,22 @@ __global__ void aggregate_logits_kernel(const float *__restrict__ lg, int F, int
   if (max_label) max_label[n] = (float)(arg + 1);
 }
 
+// [~, maxLabel] = max(lgo, [], 3)   (getBatchEmoVoxCeleb.m:32); x is 1 x 1 x C x N
+__global__ void max_label_kernel(const float *__restrict__ x, int C, int N, float *__restrict__ lab) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float best = -INFINITY;
+  int arg = 0;
+  for (int c = 0; c < C; ++c) {
+    float v = x[(size_t)C * n + c];
+    if (v > best) {
+      best = v;
+      arg = c;
+    }
+  }
+  lab[n] = (float)(arg + 1);
+}
+
 __global__ void normalize_face_kernel(const float *__restrict__ rgb, float *__restrict__ out, int HW,
                                       int N, float a0, float a1, float a2) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -420,6 +436,15 @@ int xm_aggregate_logits(const float *frame_logits, int F_total, int E, const int
     return fail(XM_EINVAL, "unrecognised aggregator %d", agg);
   hipLaunchKernelGGL(aggregate_logits_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                      frame_logits, F_total, E, first, last, N, agg, out, max_label);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_max_label(const float *x, int C, int N, float *labels, void *stream) {
+  if (C <= 0 || N <= 0) return fail(XM_EINVAL, "max_label: empty input");
+  if (!x || !labels) return fail(XM_EINVAL, "max_label: NULL tensor");
+  hipLaunchKernelGGL(max_label_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, C, N,
+                     labels);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -377,11 +377,14 @@ pool_global_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, i
 }
 
 // backward as a gather: one thread per INPUT element visits the <= ceil(ph/sy)*ceil(pw/sx)
-// windows that contain it.  max: the element receives dzdy(window) iff it is the first maximum
-// of that window in column-major scan order (MatConvNet CPU tie rule).  No atomics.
+// windows that contain it.  max: the element receives dzdy(window) iff it equals the window
+// maximum y(window) and no element scanned earlier (column-major order, MatConvNet's CPU tie
+// rule) does.  Typical cost: 1 load of x + 1 load of y per covering window; the tie scan only
+// runs for the ~1-in-(ph*pw) elements that equal their window maximum.  No atomics.
 __global__ void __launch_bounds__(256)
-pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx,
-                PoolGeo g, FastDiv divHW, FastDiv divH, size_t total, int method) {
+pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                const float *__restrict__ dy, float *__restrict__ dx, PoolGeo g, FastDiv divHW,
+                FastDiv divH, size_t total, int method) {
   size_t stride = (size_t)gridDim.x * 256;
   for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
     uint32_t plane = xm_div((uint32_t)idx, divHW);
@@ -390,6 +393,7 @@ pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float
     int h = (int)q - w * (int)divH.d;
     const float *p = x + (size_t)plane * g.H * g.W;
     const float *d = dy + (size_t)plane * g.Ho * g.Wo;
+    const float *yp = y + (size_t)plane * g.Ho * g.Wo;
     // windows ho with ho*sy - pt <= h < ho*sy - pt + ph
     int ho_lo = h + g.pt - g.ph + 1;
     ho_lo = ho_lo <= 0 ? 0 : (ho_lo + g.sy - 1) / g.sy;
@@ -398,30 +402,29 @@ pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float
     wo_lo = wo_lo <= 0 ? 0 : (wo_lo + g.sx - 1) / g.sx;
     int wo_hi = min((w + g.pl) / g.sx, g.Wo - 1);
     float acc = 0.f;
-    float xv = p[h + g.H * w];
+    float xv = method == XM_POOL_MAX ? p[h + g.H * w] : 0.f;
     for (int wo = wo_lo; wo <= wo_hi; ++wo)
       for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-        int w1 = wo * g.sx - g.pl, h1 = ho * g.sy - g.pt;
-        int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
-        w1 = max(w1, 0);
-        h1 = max(h1, 0);
-        float dv = d[ho + g.Ho * wo];
         if (method == XM_POOL_MAX) {
-          // am I the first maximum?  every element scanned before me must be < xv (strictly),
-          // every element after me must be <= xv.
-          bool win = true;
-          for (int ww = w1; ww < w2 && win; ++ww)
-            for (int hh = h1; hh < h2; ++hh) {
-              float o = p[hh + g.H * ww];
-              bool before = (ww < w) || (ww == w && hh < h);
-              if (before ? !(o < xv) : (o > xv)) {
-                win = false;
+          if (xv != yp[ho + g.Ho * wo]) continue;
+          int w1 = max(wo * g.sx - g.pl, 0), h1 = max(ho * g.sy - g.pt, 0);
+          int h2 = min(ho * g.sy - g.pt + g.ph, g.H);
+          bool first = true;
+          for (int ww = w1; ww <= w && first; ++ww) {
+            int hend = ww == w ? h : h2;
+            for (int hh = h1; hh < hend; ++hh)
+              if (p[hh + g.H * ww] == xv) {
+                first = false;
                 break;
               }
-            }
-          if (win) acc += dv;
+          }
+          if (first) acc += d[ho + g.Ho * wo];
         } else {
-          acc += dv * (1.0f / (float)((h2 - h1) * (w2 - w1)));
+          int w1 = wo * g.sx - g.pl, h1 = ho * g.sy - g.pt;
+          int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
+          w1 = max(w1, 0);
+          h1 = max(h1, 0);
+          acc += d[ho + g.Ho * wo] * (1.0f / (float)((h2 - h1) * (w2 - w1)));
         }
       }
     dx[idx] = acc;
@@ -505,18 +508,43 @@ int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw
   return XM_OK;
 }
 
-int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
-                       int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
-                       void *stream) {
+static int pool_backward(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
+                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
+                         const float *dzdy, float *dx_out, hipStream_t st) {
   PoolGeo g;
   int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
   if (rc) return rc;
   if (!x || !dzdy || !dx_out) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
   size_t total = (size_t)H * W * C * N;
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dzdy,
+  if (method == XM_POOL_MAX && !y) {
+    // plain MatConvNet signature: recompute the forward maxima into scratch first
+    size_t ny = (size_t)g.Ho * g.Wo * C * N;
+    WsCarver ws;
+    rc = ws.init(WsCarver::need(ny, 4));
+    if (rc) return rc;
+    float *yw = ws.take<float>(ny);
+    rc = xm_nnpool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, yw, st);
+    if (rc) return rc;
+    y = yw;
+  }
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y ? y : dzdy, dzdy,
                      dx_out, g, make_fastdiv((uint32_t)(H * W)), make_fastdiv((uint32_t)H), total,
                      method);
   XM_LAUNCH_CHECK();
   return XM_OK;
+}
+
+int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                       int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
+                       void *stream) {
+  return pool_backward(x, nullptr, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, dzdy, dx_out,
+                       (hipStream_t)stream);
+}
+
+int xm_nnpool_backward_y(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
+                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
+                         const float *dzdy, float *dx_out, void *stream) {
+  return pool_backward(x, y, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, dzdy, dx_out,
+                       (hipStream_t)stream);
 }
 }

@@ -159,9 +159,10 @@ class Pooling(Layer):
         return [vl.vl_nnpool(inputs[0], self.poolSize, stride=self.stride, pad=self.pad,
                              method=self.method)]
 
-    def backward(self, inputs, params, derOutputs):
+    def backward(self, inputs, params, derOutputs, outputs=None):
+        y = outputs[0] if outputs else None
         return [vl.vl_nnpool(inputs[0], self.poolSize, derOutputs[0], stride=self.stride,
-                             pad=self.pad, method=self.method)], []
+                             pad=self.pad, method=self.method, y=y)], []
 
 
 class GlobalPooling(Pooling):
@@ -174,9 +175,9 @@ class GlobalPooling(Pooling):
         self.poolSize = [int(inputs[0].shape[0]), int(inputs[0].shape[1])]
         return super().forward(inputs, params)
 
-    def backward(self, inputs, params, derOutputs):
+    def backward(self, inputs, params, derOutputs, outputs=None):
         self.poolSize = [int(inputs[0].shape[0]), int(inputs[0].shape[1])]
-        return super().backward(inputs, params, derOutputs)
+        return super().backward(inputs, params, derOutputs, outputs)
 
 
 class Sum(Layer):
@@ -585,6 +586,10 @@ class _Step:
         if isinstance(r.block, Conv):
             need_dx = net.vars[r.inputs[0]].fanin > 0  # network inputs need no derivative
             dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx)
+        elif isinstance(r.block, Pooling):
+            outs = [net.vars[v].value for v in r.outputs]
+            dins, dpar = r.block.backward(ins, self._params(net), douts,
+                                          outputs=outs if outs[0] is not None else None)
         else:
             dins, dpar = r.block.backward(ins, self._params(net), douts)
         for v, d in zip(r.inputs, dins):

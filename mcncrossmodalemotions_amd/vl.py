@@ -179,8 +179,9 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
 _METHOD = {"max": 0, "avg": 1}
 
 
-def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max"):
-    """Y = VL_NNPOOL(X, POOL) / DX = VL_NNPOOL(X, POOL, DZDY)."""
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", y=None):
+    """Y = VL_NNPOOL(X, POOL) / DX = VL_NNPOOL(X, POOL, DZDY).
+    `y` (optional, backward only): the forward output, reused instead of recomputed."""
     x = _chk(x, "X")
     if method not in _METHOD:
         raise ValueError("vl_nnpool: unknown METHOD '%s'" % method)
@@ -200,8 +201,13 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max"):
     if _shape4(dzdy) != [Ho, Wo, Cc, N]:
         raise ValueError("vl_nnpool: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, Cc, N)))
     dxo = mat_empty(H, W, Cc, N, device=x.device)
-    _lib.check(L.xm_nnpool_backward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
-                                    _METHOD[method], _ptr(dzdy), _ptr(dxo), _stream()))
+    if y is not None:
+        _lib.check(L.xm_nnpool_backward_y(_ptr(x), _ptr(_chk(y, "Y")), H, W, Cc, N, ph, pw, sy, sx,
+                                          pt, pb, pl, pr, _METHOD[method], _ptr(dzdy), _ptr(dxo),
+                                          _stream()))
+    else:
+        _lib.check(L.xm_nnpool_backward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
+                                        _METHOD[method], _ptr(dzdy), _ptr(dxo), _stream()))
     return dxo
 
 
@@ -421,6 +427,15 @@ def aggregate_logits(frame_logits, first, last, agg="max"):
                                         C.c_void_p(last.data_ptr()), N, 0 if agg == "max" else 1,
                                         _ptr(out), _ptr(lab), _stream()))
     return out, lab
+
+
+def max_label(lgo):
+    """[~, maxLabel] = max(lgo, [], 3) -- getBatchEmoVoxCeleb.m:32; lgo is 1 x 1 x C x N."""
+    lgo = _chk(lgo, "LGO")
+    H, W, Cc, N = _shape4(lgo)
+    lab = mat_empty(1, 1, 1, N, device=lgo.device)
+    _lib.check(_L().xm_max_label(_ptr(lgo), Cc, N, _ptr(lab), _stream()))
+    return lab
 
 
 def normalize_face(rgb, average_image):

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Micro-benchmark of vl_nnconv on the layer geometries of the hot path (per-GPU batch 32).
+usage: python tools/conv_bench.py [--n 32] [--reps 20] [case ...]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcncrossmodalemotions_amd import vl  # noqa: E402
+
+# name: (H, W, C, FH, FW, K, stride, pad)
+CASES = {
+    "s_conv1": (512, 300, 1, 7, 7, 96, 2, 1),
+    "s_conv2": (126, 73, 96, 5, 5, 256, 2, 1),
+    "s_conv3": (30, 17, 256, 3, 3, 384, 1, 1),
+    "s_conv4": (30, 17, 384, 3, 3, 256, 1, 1),
+    "s_conv5": (30, 17, 256, 3, 3, 256, 1, 1),
+    "s_fc6": (9, 8, 256, 9, 1, 4096, 1, 0),
+    "s_fc7": (1, 1, 4096, 1, 1, 1024, 1, 0),
+    "t_conv1": (224, 224, 3, 7, 7, 64, 2, 3),
+    "t_res2_3x3": (56, 56, 64, 3, 3, 64, 1, 1),
+    "t_res2_1x1a": (56, 56, 256, 1, 1, 64, 1, 0),
+    "t_res2_1x1c": (56, 56, 64, 1, 1, 256, 1, 0),
+    "t_res3_3x3": (28, 28, 128, 3, 3, 128, 1, 1),
+    "t_res3_1x1c": (28, 28, 128, 1, 1, 512, 1, 0),
+    "t_res4_3x3": (14, 14, 256, 3, 3, 256, 1, 1),
+    "t_res4_1x1c": (14, 14, 256, 1, 1, 1024, 1, 0),
+    "t_res5_3x3": (7, 7, 512, 3, 3, 512, 1, 1),
+    "t_res5_1x1c": (7, 7, 512, 1, 1, 2048, 1, 0),
+}
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*")
+    ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dirs", default="fwd,dgrad,wgrad")
+    args = ap.parse_args()
+    names = args.cases or list(CASES)
+    print("%-12s %-6s %9s %9s" % ("case", "dir", "ms", "TFLOP/s"))
+    for nm in names:
+        H, W, C, FH, FW, K, s, p = CASES[nm]
+        N = args.n
+        x = vl.from_numpy(np.random.default_rng(0).standard_normal((H, W, C, N)).astype(np.float32))
+        f = vl.from_numpy(np.random.default_rng(1).standard_normal((FH, FW, C, K)).astype(np.float32))
+        b = vl.from_numpy(np.zeros((K, 1), np.float32))
+        y = vl.vl_nnconv(x, f, b, stride=s, pad=p)
+        dz = vl.from_numpy(np.random.default_rng(2).standard_normal(tuple(y.shape)).astype(np.float32))
+        Ho, Wo = int(y.shape[0]), int(y.shape[1])
+        flops = 2.0 * Ho * Wo * N * K * FH * FW * C
+        for d in args.dirs.split(","):
+            if d == "fwd":
+                ms = timeit(lambda: vl.vl_nnconv(x, f, b, stride=s, pad=p), args.reps)
+            elif d == "dgrad":
+                ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_filters=True), args.reps)
+            else:
+                ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_data=True), args.reps)
+            print("%-12s %-6s %9.3f %9.1f" % (nm, d, ms, flops / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()
