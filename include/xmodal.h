@@ -83,11 +83,15 @@ int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int p
                        int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dx_out,
                        void *stream);
 
-/* Extension: same, reusing the forward output y = vl_nnpool(x, ...) (saves the recomputation
- * of the window maxima; results identical). */
-int xm_nnpool_backward_y(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
-                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
-                         const float *dzdy, float *dx_out, void *stream);
+/* Extension (max pooling): the forward pass also records, per output, the position of the first
+ * maximum inside its window (one byte: dh + ph * dw); the backward pass then routes DZDY from that
+ * table without re-reading X.  Results are identical to xm_nnpool_forward / xm_nnpool_backward. */
+int xm_nnpool_forward_argmax(const float *x, int H, int W, int C, int N, int ph, int pw, int sy,
+                             int sx, int pt, int pb, int pl, int pr, float *y, unsigned char *argmax,
+                             void *stream);
+int xm_nnpool_backward_argmax(const unsigned char *argmax, int H, int W, int C, int N, int ph, int pw,
+                              int sy, int sx, int pt, int pb, int pl, int pr, const float *dzdy,
+                              float *dx_out, void *stream);
 
 /* ---- vl_nnbnorm  (matlab/vl_nnbnorm.m) -----------------------------------------------------
  * Y = vl_nnbnorm(X, G, B, 'epsilon', e [, 'moments', M]); M is C x 2 = [mean, sqrt(var+e)].

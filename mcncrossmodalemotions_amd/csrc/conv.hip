@@ -22,20 +22,38 @@ __global__ void pad_filter_kernel(const float *__restrict__ f, float *__restrict
 
 // dgrad operand for one stride-parity class: At[c][iu + nU*(iv + nV*k)] = F[u(iu), v(iv), c, k]
 // with u(iu) = u0 + iu*ustep (the taps whose u*dil == a mod sy), zero padded to lda columns.
-__global__ void prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int FH,
-                                         int FW, int FC, int Kg, int u0, int ustep, int nU, int v0,
-                                         int vstep, int nV, int lda) {
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)FC * lda) return;
-  int rr = (int)(i % lda);
-  int c = (int)(i / lda);
-  float val = 0.f;
-  if (rr < nU * nV * Kg) {
-    int iu = rr % nU, iv = (rr / nU) % nV, k = rr / (nU * nV);
-    int u = u0 + iu * ustep, v = v0 + iv * vstep;
-    val = f[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))];
+// A (c <-> k) transpose of T-float elements through LDS: reads are contiguous runs of TS*T floats
+// per output channel, writes contiguous runs of TS*nT floats per input channel.
+__global__ void __launch_bounds__(256)
+prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int FH, int FW, int FC,
+                         int Kg, int u0, int ustep, int nU, int v0, int vstep, int nV, int lda,
+                         int TS) {
+  extern __shared__ float tile[];  // [kl][cl][t], kl pitch TS*T + 1
+  const int T = FH * FW, nT = nU * nV;
+  const int c0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
+  const int pitch = TS * T + 1;
+  for (int i = threadIdx.x; i < TS * TS * T; i += 256) {
+    int kl = i / (TS * T), rem = i - kl * (TS * T);
+    int cl = rem / T;
+    int c = c0 + cl, k = k0 + kl;
+    tile[kl * pitch + rem] = (c < FC && k < Kg) ? f[(size_t)rem + (size_t)T * (c0 + (size_t)FC * k)] : 0.f;
   }
-  o[i] = val;
+  __syncthreads();
+  for (int i = threadIdx.x; i < TS * TS * nT; i += 256) {
+    int cl = i / (TS * nT), rem = i - cl * (TS * nT);
+    int kl = rem / nT, tt = rem - kl * nT;
+    int iu = tt % nU, iv = tt / nU;
+    int t = (u0 + iu * ustep) + FH * (v0 + iv * vstep);
+    int c = c0 + cl, k = k0 + kl;
+    if (c < FC && k < Kg) o[(size_t)c * lda + (size_t)nT * k + tt] = tile[kl * pitch + cl * T + t];
+  }
+  if (blockIdx.y == 0) {  // zero the K padding columns [nT*Kg, lda)
+    int padc = lda - nT * Kg;
+    for (int i = threadIdx.x; i < TS * padc; i += 256) {
+      int cl = i / padc, rr = nT * Kg + i % padc;
+      if (c0 + cl < FC) o[(size_t)(c0 + cl) * lda + rr] = 0.f;
+    }
+  }
 }
 
 __global__ void reduce_splits_kernel(const float *__restrict__ part, float *__restrict__ out,
@@ -187,7 +205,7 @@ static int g_force_splits = 0;  // test hook
 static int pick_splits(int tiles, int nkt) {
   if (g_force_splits > 0) return std::max(1, std::min(g_force_splits, nkt));
   if (tiles >= 384 || nkt < 16) return 1;
-  int s = (512 + tiles - 1) / tiles;       // aim at ~2 blocks per CU
+  int s = 512 / tiles;                     // fill 2 blocks per CU in ONE round (no tail)
   s = std::min(s, nkt / 8);                // keep >= 8 stages per split
   return std::max(1, std::min(s, 64));
 }
@@ -476,11 +494,15 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     float *At = (float *)(ws.base + c.aoff);
     for (int grp = 0; grp < g.G; ++grp) {
       float *Ag = At + (size_t)grp * g.FC * c.Rp;
-      size_t n = (size_t)g.FC * c.Rp;
-      hipLaunchKernelGGL(prep_dgrad_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                         st, f + (size_t)g.R * g.Kg * grp, Ag, g.FH, g.FW, g.FC, g.Kg, c.u0, c.ustep,
-                         c.nU, c.v0, c.vstep, c.nV, c.Rp);
-      XM_LAUNCH_CHECK();
+      {
+        const int T = g.FH * g.FW;
+        const int TS = T <= 14 ? 32 : (T <= 56 ? 16 : 8);
+        size_t lds = sizeof(float) * (size_t)TS * (TS * T + 1);
+        hipLaunchKernelGGL(prep_dgrad_filter_kernel, dim3((g.FC + TS - 1) / TS, (g.Kg + TS - 1) / TS),
+                           dim3(256), lds, st, f + (size_t)g.R * g.Kg * grp, Ag, g.FH, g.FW, g.FC, g.Kg,
+                           c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS);
+        XM_LAUNCH_CHECK();
+      }
       ConvGemmArgs a{};
       a.A = Ag;
       a.lda = c.Rp;
@@ -546,7 +568,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   const int Rn = nbn * c.bn();
   // split the pixel reduction until the grid fills the chip about twice
   int tiles = nbm * nbn;
-  int splits = std::max(1, std::min(nkt / 8, (512 + tiles - 1) / tiles));
+  int splits = std::max(1, std::min(nkt / 8, 512 / tiles));  // one full round, no tail
   splits = std::min(splits, 256);
   int tps = (nkt + splits - 1) / splits;
   splits = (nkt + tps - 1) / tps;

@@ -351,9 +351,9 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits) {
 // ------------------------------------------------------------------------------------------
 // wgrad:  dF[k][r] = sum_p dY[k][p] * G(p, r)      (p = flat output pixel (ho, wo, n))
 // MFMA rows = output channel k, MFMA cols = tap r (contiguous in dF), reduction = pixels.
-// A stage covers 16 consecutive flat pixels; the 4-pixel group a wave stages is wave-uniform, so
-// its (n, wo, ho) decode runs on the scalar unit.  Each thread owns one tap for the whole kernel:
-// validity of (pixel, tap) = ho in [holo, hohi) and wo in [wolo, wohi), precomputed per thread.
+// A stage covers 16 consecutive flat pixels; both operands are contiguous in memory along the
+// pixel axis, so staging lanes run along pixels (coalesced) and each thread decodes one pixel per
+// stage; its channel rows / filter taps are fixed for the whole kernel and live in registers.
 // Split over the pixel range (grid.y); partials go to a workspace slab per split and are summed
 // by reduce_splits_kernel in a fixed order (deterministic, no atomics).
 struct WgradArgs {
@@ -377,12 +377,11 @@ __global__ void __launch_bounds__(256, 2)
 conv_wgrad_kernel(const WgradArgs a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(WGM * WGN == 4, "4 waves per block");
-  static_assert(BN == 32 || BN == 64 || BN == 128 || BN == 256, "BN must divide 256");
-  constexpr int PLA = BM * 4 + 4, PLB = BN * 4 + 4;
-  constexpr int NUA = (kNG * BM + 255) / 256;
-  constexpr int NUB = (kNG * BN + 255) / 256;
-  // a wave's 64 lanes stay inside one pixel group when the row count is a multiple of 64
-  constexpr bool UNI_A = BM % 64 == 0, UNI_B = BN % 64 == 0;
+  static_assert(BM % 16 == 0 && BN % 16 == 0, "rows are staged 16 at a time");
+  // plane pitch = rows*4 + 16 floats: the scalar ds_write_b32 staging stores of a wave (16 pixels
+  // x 4 rows) then hit each bank at most twice (free), and ds_read_b128 stays 16-B aligned
+  constexpr int PLA = BM * 4 + 16, PLB = BN * 4 + 16;
+  constexpr int NEA = BM / 16, NEB = BN / 16;  // elements per thread per stage
   __shared__ __attribute__((aligned(16))) float smem[2 * kNG * (PLA + PLB)];
   float *sA = smem;
   float *sB = smem + 2 * kNG * PLA;
@@ -400,106 +399,59 @@ conv_wgrad_kernel(const WgradArgs a) {
   const __amdgpu_buffer_rsrc_t dyrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
 
-  // B: the thread's tap (fixed) and the pixel ranges for which it lands inside the image
-  const int plB = t % BN, gB0 = t / BN;
-  const int4 tp = a.taps[bn * BN + plB];
-  int holo, hon, wolo, won;  // valid ho in [holo, holo + hon), same for wo (unsigned compare)
-  {
-    // hi = ho*sy - pt + du in [0, H)  <=>  ho in [ceil((pt-du)/sy), floor((H-1+pt-du)/sy)]
-    int lo = a.pt - tp.y, hi = a.H - 1 + a.pt - tp.y;
-    holo = lo <= 0 ? 0 : (lo + a.sy - 1) / a.sy;
-    int hohi = hi < 0 ? -1 : hi / a.sy;
-    hohi = min(hohi, a.Ho - 1);
-    hon = max(hohi - holo + 1, 0);
-    lo = a.pl_ - tp.z;
-    hi = a.W - 1 + a.pl_ - tp.z;
-    wolo = lo <= 0 ? 0 : (lo + a.sx - 1) / a.sx;
-    int wohi = hi < 0 ? -1 : hi / a.sx;
-    wohi = min(wohi, a.Wo - 1);
-    won = max(wohi - wolo + 1, 0);
-  }
-  // A: unit u -> (row m = u % BM, pixel group g = u / BM): lanes run along channel rows
-  unsigned arow4[NUA];
+  // Staging map: lane -> pixel.  Thread t owns pixel slot px = t % 16 of every stage and rows
+  // rsub + 16*j: a wave-wide load instruction then reads 4 runs of 16 consecutive pixels
+  // (64 contiguous bytes each for stride 1) instead of 64 scattered addresses.
+  const int px = t & 15, rsub = t >> 4;
+  unsigned arow4[NEA];  // dY byte offset of channel row j (rows >= M clamped: never stored)
 #pragma unroll
-  for (int i = 0; i < NUA; ++i) {
-    int u = t + 256 * i;
-    if (kNG * BM % 256 != 0 && u >= kNG * BM) u = kNG * BM - 1;
-    int m = u % BM;
-    int gm = min(bm * BM + m, a.M - 1);
-    arow4[i] = (unsigned)(gm * a.dyChanStride) * 4u;
+  for (int j = 0; j < NEA; ++j) {
+    int gm = min(bm * BM + rsub + 16 * j, a.M - 1);
+    arow4[j] = (unsigned)(gm * a.dyChanStride) * 4u;
   }
-  float *sAw[NUA], *sBw[NUB];
+  int tpo[NEB], tpy[NEB], tpz[NEB];  // the thread's taps: byte offset, du, dv (fixed all kernel)
 #pragma unroll
-  for (int i = 0; i < NUA; ++i) {
-    int u = t + 256 * i;
-    int m = u % BM, g = u / BM;
-    sAw[i] = sA + g * PLA + m * 4;
+  for (int j = 0; j < NEB; ++j) {
+    int4 tp = a.taps[bn * BN + rsub + 16 * j];
+    tpo[j] = tp.x;
+    tpy[j] = tp.y;
+    tpz[j] = tp.z;
   }
-#pragma unroll
-  for (int i = 0; i < NUB; ++i) {
-    int g = gB0 + i * (256 / BN);
-    sBw[i] = sB + g * PLB + plB * 4;
-  }
+  // LDS: [stage][g = px/4][row][px%4]
+  float *sAw = sA + (px >> 2) * PLA + rsub * 4 + (px & 3);
+  float *sBw = sB + (px >> 2) * PLB + rsub * 4 + (px & 3);
   const int half = lane >> 5, l31 = lane & 31;
   const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
   const float *sBr = sB + half * PLB + (wn * TN * 32 + l31) * 4;
 
-  f32x4 ra[NUA], rb[NUB];
+  float ra[NEA], rb[NEB];
 
-  // decode 4 consecutive flat pixels starting at P0 (wave-uniform when UNI): per pixel the dY
-  // byte offset (sans channel row) and the x byte offset of the gather origin, plus ho / wo
 #define XM_WLOAD_TILE(KT)                                                      \
-  _Pragma("unroll") for (int i = 0; i < NUA; ++i) {                            \
-    int u_ = t + 256 * i;                                                      \
-    if (kNG * BM % 256 != 0 && u_ >= kNG * BM) u_ = kNG * BM - 1;              \
-    int g_ = u_ / BM;                                                          \
-    if (UNI_A) g_ = __builtin_amdgcn_readfirstlane(g_);                        \
-    unsigned off_[4];                                                          \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
-      uint32_t p_ = (uint32_t)((KT) * kBK + g_ * 4 + e);                       \
-      uint32_t n_ = xm_div(p_, a.divHW);                                       \
-      uint32_t q_ = p_ - n_ * a.divHW.d;                                       \
-      unsigned o_ = (q_ + n_ * (unsigned)a.dySampleStride) * 4u;               \
-      unsigned m_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu;                         \
-      off_[e] = (arow4[i] + o_) | m_;                                          \
+  {                                                                            \
+    uint32_t p_ = (uint32_t)((KT) * kBK + px);                                 \
+    uint32_t n_ = xm_div(p_, a.divHW);                                         \
+    uint32_t q_ = p_ - n_ * a.divHW.d;                                         \
+    uint32_t wo_ = xm_div(q_, a.divHo);                                        \
+    uint32_t ho_ = q_ - wo_ * a.divHo.d;                                       \
+    const unsigned pm_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu; /* past the last pixel -> 0 */ \
+    const unsigned dyo_ = ((q_ + n_ * (unsigned)a.dySampleStride) * 4u) | pm_; \
+    const int hb_ = (int)ho_ * a.sy - a.pt, wb_ = (int)wo_ * a.sx - a.pl_;     \
+    const unsigned xo_ = (unsigned)(hb_ + a.H * wb_ + (int)n_ * a.xSampleStride) * 4u; \
+    _Pragma("unroll") for (int j = 0; j < NEA; ++j)                            \
+      ra[j] = buf_load(dyrsrc, (arow4[j] + dyo_) | pm_);                       \
+    _Pragma("unroll") for (int j = 0; j < NEB; ++j) {                          \
+      bool ok_ = ((unsigned)(hb_ + tpy[j]) < (unsigned)a.H) &                  \
+                 ((unsigned)(wb_ + tpz[j]) < (unsigned)a.W);                   \
+      unsigned o_ = (xo_ + (unsigned)tpo[j]) | pm_;                            \
+      rb[j] = buf_load(xrsrc, ok_ ? o_ : 0xFFFFFFFFu);                         \
     }                                                                          \
-    ra[i].x = buf_load(dyrsrc, off_[0]);                                       \
-    ra[i].y = buf_load(dyrsrc, off_[1]);                                       \
-    ra[i].z = buf_load(dyrsrc, off_[2]);                                       \
-    ra[i].w = buf_load(dyrsrc, off_[3]);                                       \
-  }                                                                            \
-  _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
-    int g_ = gB0 + i * (256 / BN);                                             \
-    if (kNG * BN % 256 != 0) g_ = min(g_, kNG - 1);                            \
-    if (UNI_B) g_ = __builtin_amdgcn_readfirstlane(g_);                        \
-    unsigned off_[4];                                                          \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
-      uint32_t p_ = (uint32_t)((KT) * kBK + g_ * 4 + e);                       \
-      uint32_t n_ = xm_div(p_, a.divHW);                                       \
-      uint32_t q_ = p_ - n_ * a.divHW.d;                                       \
-      uint32_t wo_ = xm_div(q_, a.divHo);                                      \
-      uint32_t ho_ = q_ - wo_ * a.divHo.d;                                     \
-      int pix_ = ((int)ho_ * a.sy - a.pt) + a.H * ((int)wo_ * a.sx - a.pl_) +  \
-                 (int)n_ * a.xSampleStride;                                    \
-      unsigned pm_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu;                        \
-      bool ok_ = ((unsigned)((int)ho_ - holo) < (unsigned)hon) &               \
-                 ((unsigned)((int)wo_ - wolo) < (unsigned)won);                \
-      unsigned o_ = ((unsigned)pix_ * 4u + (unsigned)tp.x) | pm_;              \
-      off_[e] = ok_ ? o_ : 0xFFFFFFFFu;                                        \
-    }                                                                          \
-    rb[i].x = buf_load(xrsrc, off_[0]);                                        \
-    rb[i].y = buf_load(xrsrc, off_[1]);                                        \
-    rb[i].z = buf_load(xrsrc, off_[2]);                                        \
-    rb[i].w = buf_load(xrsrc, off_[3]);                                        \
   }
 
 #define XM_WSTORE_TILE(BUF)                                                    \
-  _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
-    if (kNG * BM % 256 == 0 || t + 256 * i < kNG * BM)                         \
-      *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = ra[i];          \
-  _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
-    if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
-      *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = rb[i];
+  _Pragma("unroll") for (int j = 0; j < NEA; ++j)                              \
+    sAw[(BUF) * kNG * PLA + j * 64] = ra[j];                                   \
+  _Pragma("unroll") for (int j = 0; j < NEB; ++j)                              \
+    sBw[(BUF) * kNG * PLB + j * 64] = rb[j];
 
 #define XM_WSTAGE(KT, CUR)                                                     \
   XM_WLOAD_TILE((KT) + 1)                                                      \

@@ -325,33 +325,42 @@ struct PoolGeo {
   int H, W, Ho, Wo, ph, pw, sy, sx, pt, pl;
 };
 
-// one thread per output element, lanes along ho (contiguous); window scan is column-major
+// one thread per output element, lanes along ho (contiguous); window scan is column-major.
+// `amax` (optional, max pooling): position of the FIRST maximum inside the un-clipped window,
+// code = dh + ph * dw -- the routing table of the backward pass.
 __global__ void __launch_bounds__(256)
-pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, PoolGeo g, FastDiv divHoWo,
-                FastDiv divHo, size_t total, int method) {
+pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ amax,
+                PoolGeo g, FastDiv divHoWo, FastDiv divHo, size_t total, int method) {
   size_t stride = (size_t)gridDim.x * 256;
   for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
     uint32_t plane = xm_div((uint32_t)idx, divHoWo);
     uint32_t q = (uint32_t)idx - plane * divHoWo.d;
     uint32_t wo = xm_div(q, divHo);
     uint32_t ho = q - wo * divHo.d;
-    int w1 = (int)wo * g.sx - g.pl, h1 = (int)ho * g.sy - g.pt;
-    int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
-    w1 = max(w1, 0);
-    h1 = max(h1, 0);
+    const int w0 = (int)wo * g.sx - g.pl, h0 = (int)ho * g.sy - g.pt;
+    int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
+    int w1 = max(w0, 0), h1 = max(h0, 0);
     const float *p = x + (size_t)plane * g.H * g.W;
     float r;
     if (method == XM_POOL_MAX) {
       r = -INFINITY;
+      int code = 0;
       for (int w = w1; w < w2; ++w)
-        for (int h = h1; h < h2; ++h) r = fmaxf(r, p[h + g.H * w]);
+        for (int h = h1; h < h2; ++h) {
+          float v = p[h + g.H * w];
+          if (v > r) {
+            r = v;
+            code = (h - h0) + g.ph * (w - w0);
+          }
+        }
+      if (amax) amax[idx] = (unsigned char)code;
     } else {
       r = 0.f;
       for (int w = w1; w < w2; ++w)
         for (int h = h1; h < h2; ++h) r += p[h + g.H * w];
       r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
     }
-    y[idx] = r;
+    if (y) y[idx] = r;
   }
 }
 
@@ -377,54 +386,38 @@ pool_global_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, i
 }
 
 // backward as a gather: one thread per INPUT element visits the <= ceil(ph/sy)*ceil(pw/sx)
-// windows that contain it.  max: the element receives dzdy(window) iff it equals the window
-// maximum y(window) and no element scanned earlier (column-major order, MatConvNet's CPU tie
-// rule) does.  Typical cost: 1 load of x + 1 load of y per covering window; the tie scan only
-// runs for the ~1-in-(ph*pw) elements that equal their window maximum.  No atomics.
+// windows that contain it and takes dzdy(window) iff the window's recorded first-maximum position
+// (amax, written by the forward kernel; MatConvNet's CPU tie rule) is this element.  avg: every
+// covering window contributes dzdy / clipped area.  No atomics, no dependent load chains.
 __global__ void __launch_bounds__(256)
-pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                const float *__restrict__ dy, float *__restrict__ dx, PoolGeo g, FastDiv divHW,
-                FastDiv divH, size_t total, int method) {
+pool_bwd_kernel(const unsigned char *__restrict__ amax, const float *__restrict__ dy,
+                float *__restrict__ dx, PoolGeo g, FastDiv divHW, FastDiv divH, FastDiv divSy,
+                FastDiv divSx, size_t total, int method) {
   size_t stride = (size_t)gridDim.x * 256;
   for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
     uint32_t plane = xm_div((uint32_t)idx, divHW);
     uint32_t q = (uint32_t)idx - plane * divHW.d;
     int w = (int)xm_div(q, divH);
     int h = (int)q - w * (int)divH.d;
-    const float *p = x + (size_t)plane * g.H * g.W;
-    const float *d = dy + (size_t)plane * g.Ho * g.Wo;
-    const float *yp = y + (size_t)plane * g.Ho * g.Wo;
-    // windows ho with ho*sy - pt <= h < ho*sy - pt + ph
+    const size_t ob = (size_t)plane * g.Ho * g.Wo;
+    // windows ho with ho*sy - pt <= h < ho*sy - pt + ph   (all dividends are >= 0)
     int ho_lo = h + g.pt - g.ph + 1;
-    ho_lo = ho_lo <= 0 ? 0 : (ho_lo + g.sy - 1) / g.sy;
-    int ho_hi = min((h + g.pt) / g.sy, g.Ho - 1);
+    ho_lo = ho_lo <= 0 ? 0 : (int)xm_div((uint32_t)(ho_lo + g.sy - 1), divSy);
+    int ho_hi = min((int)xm_div((uint32_t)(h + g.pt), divSy), g.Ho - 1);
     int wo_lo = w + g.pl - g.pw + 1;
-    wo_lo = wo_lo <= 0 ? 0 : (wo_lo + g.sx - 1) / g.sx;
-    int wo_hi = min((w + g.pl) / g.sx, g.Wo - 1);
+    wo_lo = wo_lo <= 0 ? 0 : (int)xm_div((uint32_t)(wo_lo + g.sx - 1), divSx);
+    int wo_hi = min((int)xm_div((uint32_t)(w + g.pl), divSx), g.Wo - 1);
     float acc = 0.f;
-    float xv = method == XM_POOL_MAX ? p[h + g.H * w] : 0.f;
     for (int wo = wo_lo; wo <= wo_hi; ++wo)
       for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
+        size_t o = ob + ho + (size_t)g.Ho * wo;
         if (method == XM_POOL_MAX) {
-          if (xv != yp[ho + g.Ho * wo]) continue;
-          int w1 = max(wo * g.sx - g.pl, 0), h1 = max(ho * g.sy - g.pt, 0);
-          int h2 = min(ho * g.sy - g.pt + g.ph, g.H);
-          bool first = true;
-          for (int ww = w1; ww <= w && first; ++ww) {
-            int hend = ww == w ? h : h2;
-            for (int hh = h1; hh < hend; ++hh)
-              if (p[hh + g.H * ww] == xv) {
-                first = false;
-                break;
-              }
-          }
-          if (first) acc += d[ho + g.Ho * wo];
+          int code = (h - h0) + g.ph * (w - w0);
+          if ((int)amax[o] == code) acc += dy[o];
         } else {
-          int w1 = wo * g.sx - g.pl, h1 = ho * g.sy - g.pt;
-          int w2 = min(w1 + g.pw, g.W), h2 = min(h1 + g.ph, g.H);
-          w1 = max(w1, 0);
-          h1 = max(h1, 0);
-          acc += d[ho + g.Ho * wo] * (1.0f / (float)((h2 - h1) * (w2 - w1)));
+          int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
+          acc += dy[o] * (1.0f / (float)((h2 - max(h0, 0)) * (w2 - max(w0, 0))));
         }
       }
     dx[idx] = acc;
@@ -445,6 +438,56 @@ static int pool_geo(PoolGeo &g, int H, int W, int C, int N, int ph, int pw, int 
   if (Ho <= 0 || Wo <= 0) return fail(XM_EINVAL, "vl_nnpool: window larger than padded input");
   if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "vl_nnpool: tensor with >= 2^31 elements");
   g = PoolGeo{H, W, Ho, Wo, ph, pw, sy, sx, pt, pl};
+  return XM_OK;
+}
+
+static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
+                        int pt, int pb, int pl, int pr, int method, float *y, unsigned char *amax,
+                        hipStream_t st) {
+  PoolGeo g;
+  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
+  if (rc) return rc;
+  if (!x || (!y && !amax)) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  if (amax && ph * pw > 255) return fail(XM_ENOTSUP, "vl_nnpool: windows above 255 elements are not built");
+  if (!amax && g.Ho == 1 && g.Wo == 1 && ph >= H && pw >= W && !(pt | pl)) {
+    int planes = C * N;
+    hipLaunchKernelGGL(pool_global_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, x, y, H * W,
+                       planes, method);
+    XM_LAUNCH_CHECK();
+    return XM_OK;
+  }
+  size_t total = (size_t)g.Ho * g.Wo * C * N;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, amax, g,
+                     make_fastdiv((uint32_t)(g.Ho * g.Wo)), make_fastdiv((uint32_t)g.Ho), total,
+                     method);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+static int pool_backward(const float *x, const unsigned char *amax, int H, int W, int C, int N, int ph,
+                         int pw, int sy, int sx, int pt, int pb, int pl, int pr, int method,
+                         const float *dzdy, float *dx_out, hipStream_t st) {
+  PoolGeo g;
+  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
+  if (rc) return rc;
+  if (!dzdy || !dx_out) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  size_t total = (size_t)H * W * C * N;
+  if (method == XM_POOL_MAX && !amax) {
+    // plain MatConvNet signature: recompute the routing table from X into scratch first
+    if (!x) return fail(XM_EINVAL, "vl_nnpool: X is NULL");
+    size_t ny = (size_t)g.Ho * g.Wo * C * N;
+    WsCarver ws;
+    rc = ws.init(WsCarver::need(ny, 1));
+    if (rc) return rc;
+    unsigned char *aw = ws.take<unsigned char>(ny);
+    rc = pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, nullptr, aw, st);
+    if (rc) return rc;
+    amax = aw;
+  }
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, amax, dzdy, dx_out, g,
+                     make_fastdiv((uint32_t)(H * W)), make_fastdiv((uint32_t)H),
+                     make_fastdiv((uint32_t)sy), make_fastdiv((uint32_t)sx), total, method);
+  XM_LAUNCH_CHECK();
   return XM_OK;
 }
 
@@ -488,50 +531,17 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
 
 int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
                       int pt, int pb, int pl, int pr, int method, float *y, void *stream) {
-  PoolGeo g;
-  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
-  if (rc) return rc;
-  if (!x || !y) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
-  hipStream_t st = (hipStream_t)stream;
-  if (g.Ho == 1 && g.Wo == 1 && ph >= H && pw >= W && !(pt | pl)) {
-    int planes = C * N;
-    hipLaunchKernelGGL(pool_global_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, x, y, H * W,
-                       planes, method);
-    XM_LAUNCH_CHECK();
-    return XM_OK;
-  }
-  size_t total = (size_t)g.Ho * g.Wo * C * N;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, g,
-                     make_fastdiv((uint32_t)(g.Ho * g.Wo)), make_fastdiv((uint32_t)g.Ho), total,
-                     method);
-  XM_LAUNCH_CHECK();
-  return XM_OK;
+  if (!y) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  return pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, y, nullptr,
+                      (hipStream_t)stream);
 }
 
-static int pool_backward(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
-                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
-                         const float *dzdy, float *dx_out, hipStream_t st) {
-  PoolGeo g;
-  int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
-  if (rc) return rc;
-  if (!x || !dzdy || !dx_out) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
-  size_t total = (size_t)H * W * C * N;
-  if (method == XM_POOL_MAX && !y) {
-    // plain MatConvNet signature: recompute the forward maxima into scratch first
-    size_t ny = (size_t)g.Ho * g.Wo * C * N;
-    WsCarver ws;
-    rc = ws.init(WsCarver::need(ny, 4));
-    if (rc) return rc;
-    float *yw = ws.take<float>(ny);
-    rc = xm_nnpool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, yw, st);
-    if (rc) return rc;
-    y = yw;
-  }
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y ? y : dzdy, dzdy,
-                     dx_out, g, make_fastdiv((uint32_t)(H * W)), make_fastdiv((uint32_t)H), total,
-                     method);
-  XM_LAUNCH_CHECK();
-  return XM_OK;
+int xm_nnpool_forward_argmax(const float *x, int H, int W, int C, int N, int ph, int pw, int sy,
+                             int sx, int pt, int pb, int pl, int pr, float *y, unsigned char *argmax,
+                             void *stream) {
+  if (!y || !argmax) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  return pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX, y, argmax,
+                      (hipStream_t)stream);
 }
 
 int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
@@ -541,10 +551,11 @@ int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int p
                        (hipStream_t)stream);
 }
 
-int xm_nnpool_backward_y(const float *x, const float *y, int H, int W, int C, int N, int ph, int pw,
-                         int sy, int sx, int pt, int pb, int pl, int pr, int method,
-                         const float *dzdy, float *dx_out, void *stream) {
-  return pool_backward(x, y, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, dzdy, dx_out,
-                       (hipStream_t)stream);
+int xm_nnpool_backward_argmax(const unsigned char *argmax, int H, int W, int C, int N, int ph, int pw,
+                              int sy, int sx, int pt, int pb, int pl, int pr, const float *dzdy,
+                              float *dx_out, void *stream) {
+  if (!argmax) return fail(XM_EINVAL, "vl_nnpool: argmax table is NULL");
+  return pool_backward(nullptr, argmax, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX, dzdy,
+                       dx_out, (hipStream_t)stream);
 }
 }

@@ -82,10 +82,13 @@ class Conv(Layer):
         return [vl.vl_nnconv(inputs[0], params[0], b, stride=self.stride, pad=self.pad,
                              dilate=self.dilate)]
 
-    def backward(self, inputs, params, derOutputs, need_dx=True):
+    def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None):
         b = params[1] if self.hasBias else None
+        dfo = der_out[0] if der_out else None
+        dbo = der_out[1] if (der_out and self.hasBias) else None
         dx, df, db = vl.vl_nnconv(inputs[0], params[0], b, derOutputs[0], stride=self.stride,
-                                  pad=self.pad, dilate=self.dilate, no_der_data=not need_dx)
+                                  pad=self.pad, dilate=self.dilate, no_der_data=not need_dx,
+                                  df_out=dfo, db_out=dbo)
         return [dx], ([df, db] if self.hasBias else [df])
 
     def initParams(self, rng):
@@ -112,11 +115,12 @@ class BatchNorm(Layer):
         self.moments = None if test else mom
         return [y]
 
-    def backward(self, inputs, params, derOutputs, relu=False, y=None):
+    def backward(self, inputs, params, derOutputs, relu=False, y=None, der_out=None):
         test = self.net is not None and self.net.mode == "test"
+        do = der_out or [None, None, None]
         dx, dg, db, mom = vl.vl_nnbnorm(inputs[0], params[0], params[1], derOutputs[0],
                                         epsilon=self.epsilon, moments=params[2] if test else None,
-                                        relu=relu, y=y)
+                                        relu=relu, y=y, dg_out=do[0], db_out=do[1], moments_out=do[2])
         # dagnn.BatchNorm: derParams{3} = the batch moments (consumed by trainMethod 'average')
         return [dx], [dg, db, mom]
 
@@ -154,15 +158,22 @@ class Pooling(Layer):
         self.stride = stride
         self.pad = pad
         self.method = method
+        self._argmax = None  # routing table kept between forward and backward (training)
 
     def forward(self, inputs, params):
+        training = self.net is not None and self.net.mode != "test" and self.method == "max"
+        if training:
+            y, self._argmax = vl.vl_nnpool(inputs[0], self.poolSize, stride=self.stride, pad=self.pad,
+                                           method=self.method, want_argmax=True)
+            return [y]
+        self._argmax = None
         return [vl.vl_nnpool(inputs[0], self.poolSize, stride=self.stride, pad=self.pad,
                              method=self.method)]
 
     def backward(self, inputs, params, derOutputs, outputs=None):
-        y = outputs[0] if outputs else None
+        am, self._argmax = self._argmax, None
         return [vl.vl_nnpool(inputs[0], self.poolSize, derOutputs[0], stride=self.stride,
-                             pad=self.pad, method=self.method, y=y)], []
+                             pad=self.pad, method=self.method, argmax=am)], []
 
 
 class GlobalPooling(Pooling):
@@ -528,10 +539,22 @@ class DagNN:
         else:
             v.der = vl.sum2(v.der, d)  # fan-out > 1: derivatives add (dagnn accumulates)
 
+    def _direct_der(self, rec):
+        """flat storage: let the kernels write parameter derivatives straight into the flat
+        gradient buffer (only when no parameter of the layer is shared or accumulated)."""
+        if self._flat is None or self.accumulateParamDers:
+            return None
+        ps = [self.params[p] for p in rec.params]
+        if any(p.fanout > 1 or p.der is None for p in ps):
+            return None
+        return [p.der for p in ps]
+
     def _set_param_der(self, name, d):
         if d is None:
             return
         p = self.params[name]
+        if self._flat is not None and d is p.der:
+            return  # already written in place by the kernel
         seen = self._pending_param_ders.get(name, 0)
         self._pending_param_ders[name] = seen + 1
         if self._flat is not None:
@@ -585,7 +608,10 @@ class _Step:
         ins = [net.vars[v].value for v in r.inputs]
         if isinstance(r.block, Conv):
             need_dx = net.vars[r.inputs[0]].fanin > 0  # network inputs need no derivative
-            dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx)
+            dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
+                                          der_out=net._direct_der(r))
+        elif isinstance(r.block, BatchNorm):
+            dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r))
         elif isinstance(r.block, Pooling):
             outs = [net.vars[v].value for v in r.outputs]
             dins, dpar = r.block.backward(ins, self._params(net), douts,
@@ -621,7 +647,8 @@ class _BnReluStep(_Step):
         if out.der is None:
             return
         ins = [net.vars[v].value for v in r.inputs]
-        dins, dpar = r.block.backward(ins, self._params(net), [out.der], relu=True, y=out.value)
+        dins, dpar = r.block.backward(ins, self._params(net), [out.der], relu=True, y=out.value,
+                                      der_out=net._direct_der(r))
         net._set_var_der(r.inputs[0], dins[0])
         for p, d in zip(r.params, dpar):
             net._set_param_der(p, d)

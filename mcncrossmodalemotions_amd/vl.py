@@ -127,7 +127,7 @@ def out_size(n, pa, pb, f, d, s):
 
 def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
               no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
-              relu=False):
+              relu=False, df_out=None, db_out=None):
     """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
 
     `scale/shift/residual/relu` select the fused forward epilogue (extension; see xmodal.h)."""
@@ -165,8 +165,9 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     if _shape4(dzdy) != [Ho, Wo, K, N]:
         raise ValueError("vl_nnconv: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, K, N)))
     dxo = None if no_der_data else mat_empty(H, W, Cc, N, device=x.device)
-    dfo = None if no_der_filters else mat_empty(FH, FW, FC, K, device=x.device)
-    dbo = None if (no_der_biases or bb is None) else mat_empty(K, 1, device=x.device)
+    # df_out / db_out: caller-owned destinations (e.g. views of the flat gradient buffer)
+    dfo = None if no_der_filters else (df_out if df_out is not None else mat_empty(FH, FW, FC, K, device=x.device))
+    dbo = None if (no_der_biases or bb is None) else (db_out if db_out is not None else mat_empty(K, 1, device=x.device))
     _lib.check(L.xm_nnconv_backward(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(dzdy),
                                     _ptr(dxo), _ptr(dfo), _ptr(dbo), sy, sx, pt, pb, pl, pr, dy, dx,
                                     _stream()))
@@ -179,9 +180,11 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
 _METHOD = {"max": 0, "avg": 1}
 
 
-def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", y=None):
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, want_argmax=False):
     """Y = VL_NNPOOL(X, POOL) / DX = VL_NNPOOL(X, POOL, DZDY).
-    `y` (optional, backward only): the forward output, reused instead of recomputed."""
+
+    Extension for max pooling: `want_argmax=True` (forward) also returns the uint8 routing table
+    of first maxima; pass it back as `argmax=` (backward) to skip the recomputation from X."""
     x = _chk(x, "X")
     if method not in _METHOD:
         raise ValueError("vl_nnpool: unknown METHOD '%s'" % method)
@@ -194,17 +197,21 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", y=None):
     Wo = L.xm_out_size(W, pl, pr, pw, 1, sx)
     if dzdy is None:
         y = mat_empty(max(Ho, 0), max(Wo, 0), Cc, N, device=x.device)
+        if want_argmax and method == "max":
+            am = torch.empty(max(Ho, 0) * max(Wo, 0) * Cc * N, dtype=torch.uint8, device=x.device)
+            _lib.check(L.xm_nnpool_forward_argmax(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
+                                                  _ptr(y), C.c_void_p(am.data_ptr()), _stream()))
+            return y, am
         _lib.check(L.xm_nnpool_forward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
                                        _METHOD[method], _ptr(y), _stream()))
-        return y
+        return (y, None) if want_argmax else y
     dzdy = _chk(dzdy, "DZDY")
     if _shape4(dzdy) != [Ho, Wo, Cc, N]:
         raise ValueError("vl_nnpool: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, Cc, N)))
     dxo = mat_empty(H, W, Cc, N, device=x.device)
-    if y is not None:
-        _lib.check(L.xm_nnpool_backward_y(_ptr(x), _ptr(_chk(y, "Y")), H, W, Cc, N, ph, pw, sy, sx,
-                                          pt, pb, pl, pr, _METHOD[method], _ptr(dzdy), _ptr(dxo),
-                                          _stream()))
+    if argmax is not None and method == "max":
+        _lib.check(L.xm_nnpool_backward_argmax(C.c_void_p(argmax.data_ptr()), H, W, Cc, N, ph, pw, sy,
+                                               sx, pt, pb, pl, pr, _ptr(dzdy), _ptr(dxo), _stream()))
     else:
         _lib.check(L.xm_nnpool_backward(_ptr(x), H, W, Cc, N, ph, pw, sy, sx, pt, pb, pl, pr,
                                         _METHOD[method], _ptr(dzdy), _ptr(dxo), _stream()))
@@ -216,7 +223,8 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", y=None):
 # --------------------------------------------------------------------------------------------
 
 
-def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None):
+def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None, dg_out=None,
+               db_out=None, moments_out=None):
     """forward:  Y, MOMENTS = VL_NNBNORM(X, G, B);  backward: DX, DG, DB, MOMENTS = (..., DZDY).
 
     MOMENTS is C x 2 = [mean, sqrt(var + epsilon)].  `relu=True` fuses vl_nnrelu (forward) /
@@ -231,7 +239,7 @@ def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=Non
         if mi.numel() != 2 * Cc:
             raise ValueError("vl_nnbnorm: MOMENTS must be %d x 2" % Cc)
     L = _L()
-    mo = mat_empty(Cc, 2, device=x.device)
+    mo = moments_out if moments_out is not None else mat_empty(Cc, 2, device=x.device)
     if dzdy is None:
         yo = mat_empty(H, W, Cc, N, device=x.device)
         _lib.check(L.xm_nnbnorm_forward_fused(_ptr(x), H, W, Cc, N, _ptr(g), _ptr(b),
@@ -242,8 +250,8 @@ def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=Non
     if _shape4(dzdy) != [H, W, Cc, N]:
         raise ValueError("vl_nnbnorm: DZDY shape mismatch")
     dxo = mat_empty(H, W, Cc, N, device=x.device)
-    dg = mat_empty(Cc, 1, device=x.device)
-    db = mat_empty(Cc, 1, device=x.device)
+    dg = dg_out if dg_out is not None else mat_empty(Cc, 1, device=x.device)
+    db = db_out if db_out is not None else mat_empty(Cc, 1, device=x.device)
     if relu:
         if y is None:
             raise ValueError("vl_nnbnorm: fused backward needs the forward output y")

@@ -141,6 +141,11 @@ def test_pool(gpu, case):
     dx_ref = O.vl_nnpool(x, pool, dzdy, stride=stride, pad=pad, method=method)
     dx = vl.vl_nnpool(xd, pool, vl.from_numpy(dzdy), stride=stride, pad=pad, method=method)
     close(vl.to_numpy(dx), dx_ref, 1e-5, "pool bwd")
+    # extension: forward records the first-maximum routing table, backward consumes it
+    y2, am = vl.vl_nnpool(xd, pool, stride=stride, pad=pad, method=method, want_argmax=True)
+    close(vl.to_numpy(y2), y_ref, 1e-6, "pool fwd (argmax variant)")
+    dx2 = vl.vl_nnpool(xd, pool, vl.from_numpy(dzdy), stride=stride, pad=pad, method=method, argmax=am)
+    close(vl.to_numpy(dx2), dx_ref, 1e-5, "pool bwd (argmax variant)")
 
 
 BN_CASES = [(13, 7, 5, 4), (8, 8, 16, 3), (1, 1, 32, 6), (1, 8, 24, 5), (30, 17, 3, 2)]

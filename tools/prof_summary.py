@@ -10,5 +10,5 @@ rows = db.execute("select name, total_calls, total_duration, average, percentage
 tot = sum(r[2] for r in rows)
 print("%-100s %8s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
 for name, calls, total, avg, pct in rows:
-    print("%-100s %8d %12.3f %10.2f %6.2f" % (name[:100], calls, total / 1e6, avg / 1e3, pct))
-print("TOTAL kernel time: %.3f ms  (%.3f ms per step over %g steps)" % (tot / 1e6, tot / 1e6 / steps, steps))
+    print("%-100s %8d %12.3f %10.2f %6.2f" % (name[:100], calls, total / 1e3, avg, pct))
+print("TOTAL kernel time: %.3f ms  (%.3f ms per step over %g steps)" % (tot / 1e3, tot / 1e3 / steps, steps))
