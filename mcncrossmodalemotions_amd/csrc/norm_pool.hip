@@ -531,7 +531,6 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
 
 int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
                       int pt, int pb, int pl, int pr, int method, float *y, void *stream) {
-  if (!y) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
   return pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, y, nullptr,
                       (hipStream_t)stream);
 }

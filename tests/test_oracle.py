@@ -1,0 +1,201 @@
+"""CPU: the oracle (oracle/xm_oracle.c) against (i) analytic known answers, (ii) an independent
+second opinion (torch CPU ops -- NOT the reference), (iii) fp64 finite differences,
+(iv) the committed golden fixtures.  Pure CPU; runs in well under a minute."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops_small.npz")
+
+
+def tn(a):  # MATLAB (H,W,C,N) -> torch (N,C,W,H) double
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a).transpose(3, 2, 1, 0))).double()
+
+
+def fm(t):  # back
+    return t.detach().numpy().transpose(3, 2, 1, 0)
+
+
+def torch_conv(x, f, b, stride, pad, dil=(1, 1)):
+    xt = tn(x).requires_grad_(True)
+    ft = tn(f).requires_grad_(True)
+    bt = None if b is None else torch.from_numpy(np.asarray(b, np.float64).ravel()).requires_grad_(True)
+    pt, pb, pl, pr = pad
+    y = TF.conv2d(TF.pad(xt, (pt, pb, pl, pr)), ft, bt, stride=(stride[1], stride[0]),
+                  dilation=(dil[1], dil[0]), groups=x.shape[2] // f.shape[2])
+    return xt, ft, bt, y
+
+
+CASES = [
+    ((12, 9, 5, 2), (3, 3, 5, 7), (1, 1), (1, 1, 1, 1), (1, 1)),
+    ((21, 18, 6, 2), (5, 5, 6, 9), (2, 2), (1, 1, 1, 1), (1, 1)),
+    ((11, 10, 4, 2), (3, 2, 4, 6), (2, 3), (0, 1, 2, 0), (1, 1)),
+    ((13, 12, 4, 2), (3, 3, 4, 6), (1, 1), (2, 2, 2, 2), (2, 2)),
+    ((10, 9, 8, 2), (3, 3, 4, 6), (1, 1), (1, 1, 1, 1), (1, 1)),  # groups
+    ((9, 8, 16, 3), (9, 1, 16, 10), (1, 1), (0, 0, 0, 0), (1, 1)),  # fc6-like
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("acc64", [False, True])
+def test_conv_vs_torch(case, acc64):
+    xs, fs, stride, pad, dil = case
+    rng = np.random.default_rng(1)
+    x, f, b = O.F(rng.standard_normal(xs)), O.F(rng.standard_normal(fs)), O.F(rng.standard_normal(fs[3]))
+    xt, ft, bt, yt = torch_conv(x, f, b, stride, pad, dil)
+    y = O.vl_nnconv(x, f, b, stride=stride, pad=pad, dilate=dil, acc64=acc64)
+    tol = 2e-6 if acc64 else 5e-5
+    assert np.abs(y - fm(yt)).max() <= tol * max(1, np.abs(fm(yt)).max())
+    dz = O.F(rng.standard_normal(y.shape))
+    yt.backward(tn(dz))
+    dx, df, db = O.vl_nnconv(x, f, b, dz, stride=stride, pad=pad, dilate=dil, acc64=acc64)
+    for got, ref in ((dx, fm(xt.grad)), (df, fm(ft.grad)), (db, bt.grad.numpy())):
+        assert np.abs(got - ref).max() <= tol * max(1, np.abs(ref).max())
+
+
+def test_conv_known_answers():
+    # identity 1x1 filter returns the input; a box filter sums the window (cross-correlation)
+    x = O.F(np.arange(2 * 3 * 1 * 1).reshape(2, 3, 1, 1, order="F"))
+    assert np.array_equal(O.vl_nnconv(x, O.F(np.ones((1, 1, 1, 1))), None), x)
+    y = O.vl_nnconv(x, O.F(np.ones((2, 2, 1, 1))), O.F([10.0]))
+    assert np.array_equal(y.ravel(order="F"), [0 + 1 + 2 + 3 + 10, 2 + 3 + 4 + 5 + 10])
+    # no kernel flip: filter [1 0] picks the TOP element of each vertical pair
+    f = O.F(np.array([1.0, 0.0]).reshape(2, 1, 1, 1))
+    assert np.array_equal(O.vl_nnconv(x, f, None).ravel(order="F"), [0, 2, 4])
+    # output size rule floor((H + pt + pb - FH) / sy) + 1
+    assert O.conv_out_size(512, 1, 1, 7, 1, 2) == 254 and O.conv_out_size(300, 1, 1, 7, 1, 2) == 148
+
+
+def test_pool_vs_torch_and_tie_rule():
+    rng = np.random.default_rng(2)
+    x = O.F(rng.standard_normal((13, 11, 5, 3)))
+    y = O.vl_nnpool(x, [3, 3], stride=2, method="max")
+    assert np.allclose(y, fm(TF.max_pool2d(tn(x), (3, 3), (2, 2))))
+    ya = O.vl_nnpool(x, [3, 2], stride=(2, 1), pad=(1, 1, 0, 1), method="avg")
+    ref = TF.avg_pool2d(TF.pad(tn(x), (1, 1, 0, 1)), (2, 3), (1, 2))  # count_include_pad would differ:
+    # MatConvNet divides by the CLIPPED window area, so compare only interior outputs
+    assert np.allclose(ya[1:-1, :-1], fm(ref)[1:-1, :-1], atol=1e-6)
+    # clipped-area rule on the border: a window hanging over one padded row averages 2x2 of 3x2
+    ones = O.F(np.ones((4, 4, 1, 1)))
+    assert np.allclose(O.vl_nnpool(ones, [3, 2], stride=1, pad=(1, 1, 0, 0), method="avg"), 1.0)
+    # max backward routes to the FIRST maximum in column-major scan order
+    z = O.F(np.zeros((3, 3, 1, 1)))
+    dx = O.vl_nnpool(z, [3, 3], O.F(np.ones((1, 1, 1, 1))), method="max")
+    assert dx[0, 0, 0, 0] == 1 and dx.sum() == 1
+    z[1, 0] = z[0, 1] = 5.0  # tie between (h=1,w=0) and (h=0,w=1): column 0 is scanned first
+    dx = O.vl_nnpool(z, [3, 3], O.F(np.ones((1, 1, 1, 1))), method="max")
+    assert dx[1, 0, 0, 0] == 1 and dx.sum() == 1
+
+
+def test_bnorm_vs_torch():
+    rng = np.random.default_rng(3)
+    x = O.F(rng.standard_normal((7, 5, 4, 3)) * 2 + 1)
+    g, b = O.F(rng.uniform(0.5, 1.5, 4)), O.F(rng.standard_normal(4))
+    eps = 1e-4
+    for acc64 in (False, True):
+        y, mom = O.vl_nnbnorm(x, g, b, epsilon=eps, acc64=acc64)
+        xt = tn(x).requires_grad_(True)
+        gt = torch.from_numpy(g.astype(np.float64)).requires_grad_(True)
+        bt = torch.from_numpy(b.astype(np.float64)).requires_grad_(True)
+        yt = TF.batch_norm(xt, None, None, gt, bt, training=True, eps=eps)
+        assert np.abs(y - fm(yt)).max() < 2e-5
+        # moments = [mean, sqrt(biased var + eps)]
+        assert np.allclose(mom[:, 0], x.mean((0, 1, 3)), atol=1e-5)
+        assert np.allclose(mom[:, 1], np.sqrt(x.astype(np.float64).var((0, 1, 3)) + eps), atol=1e-5)
+        dz = O.F(rng.standard_normal(x.shape))
+        yt.backward(tn(dz))
+        dx, dg, db, _ = O.vl_nnbnorm(x, g, b, dz, epsilon=eps, acc64=acc64)
+        assert np.abs(dx - fm(xt.grad)).max() < 5e-5
+        assert np.abs(dg - gt.grad.numpy()).max() < 5e-4 and np.abs(db - bt.grad.numpy()).max() < 5e-5
+    # test mode: y = g * (x - M1) / M2 + b
+    M = O.F(np.stack([rng.standard_normal(4), rng.uniform(0.5, 1.5, 4)], 1))
+    yt, _ = O.vl_nnbnorm(x, g, b, moments=M, acc64=True)
+    ref = g.reshape(1, 1, 4, 1) * (x - M[:, 0].reshape(1, 1, 4, 1)) / M[:, 1].reshape(1, 1, 4, 1) + b.reshape(1, 1, 4, 1)
+    assert np.abs(yt - ref).max() < 1e-5
+
+
+def test_distillation_loss_semantics_and_gradient():
+    """SURVEY A.6 decisions: summed over the batch, 1/T in the gradient, no T^2."""
+    rng = np.random.default_rng(4)
+    x, p = O.F(rng.standard_normal((1, 1, 8, 6)) * 3), O.F(rng.standard_normal((1, 1, 8, 6)) * 3)
+    T = 2.0
+    xt = torch.from_numpy(x.reshape(8, 6, order="F").T.copy()).double().requires_grad_(True)
+    pt = torch.from_numpy(p.reshape(8, 6, order="F").T.copy()).double()
+    loss = -(TF.softmax(pt / T, 1) * TF.log_softmax(xt / T, 1)).sum()
+    assert abs(O.vl_nnsoftmaxceloss(x, p, temperature=T, logit_targets=True) - loss.item()) < 1e-5
+    loss.backward()
+    dx = O.vl_nnsoftmaxceloss(x, p, np.ones(1, np.float32), temperature=T, logit_targets=True)
+    assert np.abs(dx.reshape(8, 6, order="F").T - xt.grad.numpy()).max() < 1e-6
+    # fp64 finite differences of the forward
+    eps = 1e-3
+    for (c, n) in [(0, 0), (3, 2), (7, 5)]:
+        xp, xm = x.copy(), x.copy()
+        xp[0, 0, c, n] += eps
+        xm[0, 0, c, n] -= eps
+        fd = (O.vl_nnsoftmaxceloss(xp, p, temperature=T, logit_targets=True) -
+              O.vl_nnsoftmaxceloss(xm, p, temperature=T, logit_targets=True)) / (2 * eps)
+        assert abs(fd - dx[0, 0, c, n]) < 2e-3
+    # vl_nnloss
+    lab = O.F(rng.integers(1, 9, (1, 1, 1, 6)))
+    ref = TF.cross_entropy(torch.from_numpy(x.reshape(8, 6, order="F").T.copy()).double(),
+                           torch.from_numpy(lab.ravel().astype(np.int64) - 1), reduction="sum")
+    assert abs(O.vl_nnloss(x, lab, loss="softmaxlog") - ref.item()) < 1e-5
+    err = (x.reshape(8, 6, order="F").argmax(0) + 1 != lab.ravel()).sum()
+    assert O.vl_nnloss(x, lab, loss="classerror") == err
+
+
+def test_elementwise_and_sgd():
+    rng = np.random.default_rng(5)
+    x, d = O.F(rng.standard_normal((4, 3, 2, 2))), O.F(rng.standard_normal((4, 3, 2, 2)))
+    assert np.array_equal(O.vl_nnrelu(x), np.maximum(x, 0))
+    assert np.array_equal(O.vl_nnrelu(x, d), d * (x > 0))
+    assert np.allclose(O.vl_nnsigmoid(x), 1 / (1 + np.exp(-x)), atol=1e-6)
+    a = O.F(rng.standard_normal((1, 1, 2, 2)))
+    assert np.allclose(O.scale_axpy(x, a, d, relu=True), np.maximum(a * x + d, 0), atol=1e-6)
+    dx, da = O.scale_backward(x, a, d)
+    assert np.allclose(dx, a * d, atol=1e-6) and np.allclose(da, (d * x).sum((0, 1), keepdims=True), atol=1e-5)
+    w, m, g = O.F(rng.standard_normal(10)), O.F(rng.standard_normal(10)), O.F(rng.standard_normal(10))
+    w2, m2 = O.sgd_update(w, m, g, lr=0.1, momentum=0.9, wd=5e-4, batch=4)
+    mref = 0.9 * m - (5e-4 * w + g / 4)
+    assert np.allclose(m2, mref, atol=1e-6) and np.allclose(w2, w + 0.1 * mref, atol=1e-6)
+    assert np.allclose(O.average_update(w, g, 0.1, 2), 0.9 * w + 0.1 * g / 2, atol=1e-6)
+
+
+def test_batch_math():
+    rng = np.random.default_rng(6)
+    s = O.F(np.abs(rng.standard_normal((8, 20, 1, 2))) * 3)
+    n = O.spec_rownorm(s)
+    assert np.allclose(n.mean(1), 0, atol=1e-5) and np.allclose(n.std(1, ddof=1), 1, atol=1e-4)  # std(.,[],2): N-1
+    lg = O.F(rng.standard_normal((17, 8)))
+    assert np.allclose(O.aggregate_logits(lg, 3, 9, "max"), lg[2:9].max(0))
+    assert np.allclose(O.aggregate_logits(lg, 3, 30, "mean"), lg[2:17].mean(0), atol=1e-6)  # clamp to F (:152)
+    rgb = O.F(rng.integers(0, 256, (6, 5, 3, 2)))
+    f = O.normalize_face(rgb, [131.1, 103.9, 91.5])
+    grey = np.minimum(np.floor(0.2989 * rgb[:, :, 0] + 0.5870 * rgb[:, :, 1] + 0.1140 * rgb[:, :, 2] + 0.5), 255)
+    assert np.allclose(f[:, :, 1], grey - 103.9, atol=1e-4)
+
+
+def test_golden_fixtures():
+    """the committed vectors (tests/golden/make_golden.py) still come out of the oracle."""
+    G = np.load(GOLD)
+    y = O.vl_nnconv(G["conv_x"], G["conv_f"], G["conv_b"], stride=2, pad=1, acc64=True)
+    assert np.abs(y - G["conv_y"]).max() < 1e-6
+    dx, df, db = O.vl_nnconv(G["conv_x"], G["conv_f"], G["conv_b"], G["conv_dzdy"], stride=2, pad=1, acc64=True)
+    assert np.abs(dx - G["conv_dx"]).max() < 1e-6 and np.abs(df - G["conv_df"]).max() < 1e-5
+    assert np.abs(db - G["conv_db"]).max() < 1e-5
+    # fp32 path (MatConvNet algorithm shape) stays within 1e-4 of the fp64-accumulate vectors
+    y32 = O.vl_nnconv(G["conv_x"], G["conv_f"], G["conv_b"], stride=2, pad=1, acc64=False)
+    assert np.abs(y32 - G["conv_y"]).max() < 1e-4 * max(1, np.abs(G["conv_y"]).max())
+    yb, mom = O.vl_nnbnorm(G["bn_x"], G["bn_g"], G["bn_b"], acc64=True)
+    assert np.abs(yb - G["bn_y"]).max() < 1e-6 and np.abs(mom - G["bn_moments"]).max() < 1e-6
+    dxb, dg, dbb, _ = O.vl_nnbnorm(G["bn_x"], G["bn_g"], G["bn_b"], G["bn_dzdy"], acc64=True)
+    assert np.abs(dxb - G["bn_dx"]).max() < 1e-6 and np.abs(dg - G["bn_dg"]).max() < 1e-5
+    assert np.array_equal(O.vl_nnpool(G["pool_x"], [3, 3], stride=2), G["pool_y"])
+    assert np.array_equal(O.vl_nnpool(G["pool_x"], [3, 3], G["pool_dzdy"], stride=2), G["pool_dx"])
+    assert abs(O.vl_nnsoftmaxceloss(G["loss_x"], G["loss_p"], temperature=2, logit_targets=True) - G["loss_y"]) < 1e-6
+    assert np.abs(O.spec_rownorm(G["spec"]) - G["spec_norm"]).max() < 1e-6
