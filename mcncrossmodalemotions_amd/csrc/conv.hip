@@ -120,23 +120,39 @@ static const Cfg kCfgs[] = {
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// cost model: time ~ rounds(occ) * occ * BM*BN * eff, where `occ` blocks share a CU's MFMA pipes
-// (each then runs occ x slower) and rounds = ceil(tiles / (256 CUs * occ)).
-static int pick_cfg(long long M, long long NP) {
+static int g_force_splits = 0;  // test hook
+
+// With few output tiles the reduction is split over grid.y; the split count fills ONE round of
+// 2 co-resident blocks per CU (no tail round).
+static int pick_splits(int tiles, int nkt) {
+  if (g_force_splits > 0) return std::max(1, std::min(g_force_splits, nkt));
+  if (tiles >= 384 || nkt < 16) return 1;
+  int s = 512 / tiles;
+  s = std::min(s, nkt / 8);  // keep >= 8 stages per split
+  return std::max(1, std::min(s, 64));
+}
+
+// Time model per tile configuration (seconds, coarse):
+//   block time  = 2*BM*BN*16*stages*eff / (157.3 TF / 256 CUs)    (a CU's MFMA pipes are shared by
+//                 its co-resident blocks, so >256 blocks cost proportionally more)
+//   rounds      = 1 if blocks <= 256 else 2*ceil(blocks/512)
+//   split-K adds the slab write + combine pass at HBM speed
+static int pick_cfg(long long M, long long NP, int nkt) {
   double best = 1e300;
   int bi = 0;
   for (int i = 0; i < kNumCfg; ++i) {
     const Cfg &c = kCfgs[i];
     long long tiles = ((M + c.bm() - 1) / c.bm()) * ((NP + c.bn() - 1) / c.bn());
+    int s = pick_splits((int)std::min<long long>(tiles, 1 << 20), nkt);
     double eff = (c.tm * c.tn >= 4) ? 1.0 : (c.tm * c.tn >= 2 ? 1.12 : 1.3);
-    double t = 1e300;
-    for (int occ = 1; occ <= 3; ++occ) {
-      long long rounds = (tiles + 256LL * occ - 1) / (256LL * occ);
-      t = std::min(t, (double)rounds * occ);
-    }
-    double cost = t * c.bm() * c.bn() * eff;
-    if (cost < best) {
-      best = cost;
+    double stages = (double)((nkt + s - 1) / s) + 3.0;  // + prologue / epilogue
+    double t_block = 2.0 * c.bm() * c.bn() * 16.0 * stages * eff / (157.3e12 / 256.0);
+    double blocks = (double)tiles * s;
+    double rounds = blocks <= 256 ? 1.0 : 2.0 * std::ceil(blocks / 512.0);
+    double t = rounds * t_block;
+    if (s > 1) t += 5e-6 + (double)(s + 1) * M * NP * 4.0 / 4e12;
+    if (t < best) {
+      best = t;
       bi = i;
     }
   }
@@ -198,18 +214,6 @@ struct ProfScope {
   }
 };
 
-static int g_force_splits = 0;  // test hook
-
-// Launches the implicit GEMM (a.nkt K-stages).  With few output tiles the reduction is split over
-// grid.y and combined by conv_splitk_epilogue_kernel; `ws` must have room (see gemm_slab_bytes).
-static int pick_splits(int tiles, int nkt) {
-  if (g_force_splits > 0) return std::max(1, std::min(g_force_splits, nkt));
-  if (tiles >= 384 || nkt < 16) return 1;
-  int s = 512 / tiles;                     // fill 2 blocks per CU in ONE round (no tail)
-  s = std::min(s, nkt / 8);                // keep >= 8 stages per split
-  return std::max(1, std::min(s, 64));
-}
-
 static size_t gemm_slab_floats(const ConvGemmArgs &a, int ci, int *splits_out) {
   const Cfg &c = kCfgs[ci];
   int nbm = (a.M + c.bm() - 1) / c.bm(), nbn = (a.NP + c.bn() - 1) / c.bn();
@@ -245,8 +249,8 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   return XM_OK;
 }
 
-static int choose_cfg(long long M, long long NP) {
-  return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP);
+static int choose_cfg(long long M, long long NP, int nkt) {
+  return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP, nkt);
 }
 
 static void launch_wgrad_cfg(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
@@ -328,7 +332,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   const int Rp = (g.R + kBK - 1) / kBK * kBK;
   const bool need_pad = (g.R % kBK) != 0 || ((uintptr_t)f & 15);
   const int mode = ((g.pt | g.pb | g.pl | g.pr) != 0 || Rp != g.R) ? 1 : 0;
-  const int ci = choose_cfg(g.Kg, (long long)g.Ho * g.Wo * g.N);
+  const int ci = choose_cfg(g.Kg, (long long)g.Ho * g.Wo * g.N, Rp / kBK);
   ConvGemmArgs proto{};
   proto.M = g.Kg;
   proto.NP = g.Ho * g.Wo * g.N;
@@ -464,7 +468,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     proto.M = g.FC;
     proto.NP = c.PI * c.PJ * g.N;
     proto.Rp = c.Rp;
-    cls_cfg[i] = choose_cfg(proto.M, proto.NP);
+    cls_cfg[i] = choose_cfg(proto.M, proto.NP, proto.Rp / kBK);
     slab_max = std::max(slab_max, gemm_slab_floats(proto, cls_cfg[i], &cls_splits[i]));
   }
   WsCarver ws;

@@ -2,6 +2,8 @@
 // fastest axis), float4 where the plane size allows, wave-shuffle + LDS tree reductions, fixed
 // reduction order (no atomics) so results are run-to-run identical.
 // Replaces MatConvNet's vl_nnbnorm / vl_nnpool MEX (bits/nnbnorm.cu, bits/nnpooling.cu).
+#include <algorithm>
+
 #include "xm_common.h"
 
 namespace xm {
@@ -325,24 +327,81 @@ struct PoolGeo {
   int H, W, Ho, Wo, ph, pw, sy, sx, pt, pl;
 };
 
-// one thread per output element, lanes along ho (contiguous); window scan is column-major.
+// 2-D indexing shared by the pooling kernels: threadIdx.x runs along the contiguous H axis,
+// (blockIdx.x * blockDim.y + threadIdx.y) along W, blockIdx.y (+ grid-stride) over C*N planes --
+// no per-element integer division.
+struct PoolLaunch {
+  dim3 grid, block;
+};
+static int pow2_ge(int v, int cap) {
+  int p = 1;
+  while (p < v && p < cap) p <<= 1;
+  return p;
+}
+static PoolLaunch pool_launch(int rows, int cols, long long planes) {
+  // 256 threads = bx (rows, contiguous) x by (cols) x bz (planes): small planes pack several
+  // planes into one block instead of idling lanes
+  int bx = pow2_ge(rows, 256);
+  int by = pow2_ge(cols, 256 / bx);
+  int bz = 256 / (bx * by);
+  PoolLaunch l;
+  l.block = dim3(bx, by, bz);
+  // ~8k blocks in total: each block then strides over several planes (amortises block start-up)
+  int gx = (cols + by - 1) / by, gz = (rows + bx - 1) / bx;
+  long long pg = (planes + bz - 1) / bz;
+  long long gy = std::max<long long>(1, 8192 / ((long long)gx * gz));
+  gy = std::min<long long>(std::min<long long>(gy, pg), 65535);
+  l.grid = dim3(gx, (unsigned)gy, gz);
+  return l;
+}
+
+// one thread per output element; window scan is column-major.
 // `amax` (optional, max pooling): position of the FIRST maximum inside the un-clipped window,
 // code = dh + ph * dw -- the routing table of the backward pass.
+// PH, PW > 0: compile-time window -> all PH*PW loads are independent (clamped address + validity
+// select) and in flight together; PH == 0: generic runtime window.
+template <int PH, int PW>
 __global__ void __launch_bounds__(256)
 pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ amax,
-                PoolGeo g, FastDiv divHoWo, FastDiv divHo, size_t total, int method) {
-  size_t stride = (size_t)gridDim.x * 256;
-  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
-    uint32_t plane = xm_div((uint32_t)idx, divHoWo);
-    uint32_t q = (uint32_t)idx - plane * divHoWo.d;
-    uint32_t wo = xm_div(q, divHo);
-    uint32_t ho = q - wo * divHo.d;
-    const int w0 = (int)wo * g.sx - g.pl, h0 = (int)ho * g.sy - g.pt;
-    int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
-    int w1 = max(w0, 0), h1 = max(h0, 0);
+                PoolGeo g, int planes, int method) {
+  const int ho = blockIdx.z * blockDim.x + threadIdx.x;
+  const int wo = blockIdx.x * blockDim.y + threadIdx.y;
+  if (ho >= g.Ho || wo >= g.Wo) return;
+  const int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
+  const int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
+  const int w1 = max(w0, 0), h1 = max(h0, 0);
+  for (int plane = blockIdx.y * blockDim.z + threadIdx.z; plane < planes; plane += gridDim.y * blockDim.z) {
     const float *p = x + (size_t)plane * g.H * g.W;
+    const size_t o = (size_t)plane * g.Ho * g.Wo + ho + (size_t)g.Ho * wo;
     float r;
-    if (method == XM_POOL_MAX) {
+    if (PH > 0) {
+      float v[PH * PW > 0 ? PH * PW : 1];
+#pragma unroll
+      for (int dw = 0; dw < PW; ++dw)
+#pragma unroll
+        for (int dh = 0; dh < PH; ++dh) {
+          int h = h0 + dh, w = w0 + dw;
+          bool ok = ((unsigned)h < (unsigned)g.H) & ((unsigned)w < (unsigned)g.W);
+          float ld = p[ok ? h + g.H * w : 0];
+          v[dh + PH * dw] = ok ? ld : (method == XM_POOL_MAX ? -INFINITY : 0.f);
+        }
+      if (method == XM_POOL_MAX) {
+        r = -INFINITY;
+        int code = 0;
+#pragma unroll
+        for (int i = 0; i < PH * PW; ++i)
+          if (v[i] > r) {
+            r = v[i];
+            code = i;
+          }
+        if (amax) amax[o] = (unsigned char)code;
+      } else {
+        r = 0.f;
+#pragma unroll
+        for (int i = 0; i < PH * PW; ++i) r += v[i];
+        r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
+      }
+    } else if (method == XM_POOL_MAX) {
       r = -INFINITY;
       int code = 0;
       for (int w = w1; w < w2; ++w)
@@ -353,14 +412,14 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
             code = (h - h0) + g.ph * (w - w0);
           }
         }
-      if (amax) amax[idx] = (unsigned char)code;
+      if (amax) amax[o] = (unsigned char)code;
     } else {
       r = 0.f;
       for (int w = w1; w < w2; ++w)
         for (int h = h1; h < h2; ++h) r += p[h + g.H * w];
       r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
     }
-    if (y) y[idx] = r;
+    if (y) y[o] = r;
   }
 }
 
@@ -389,38 +448,78 @@ pool_global_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, i
 // windows that contain it and takes dzdy(window) iff the window's recorded first-maximum position
 // (amax, written by the forward kernel; MatConvNet's CPU tie rule) is this element.  avg: every
 // covering window contributes dzdy / clipped area.  No atomics, no dependent load chains.
+// FAST: at most 2 x 2 windows cover an input element (ceil(ph/sy) <= 2, ceil(pw/sx) <= 2): the 4
+// candidate table bytes and dzdy values are loaded unconditionally (clamped) and selected -- all
+// loads independent; otherwise a runtime loop.
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 pool_bwd_kernel(const unsigned char *__restrict__ amax, const float *__restrict__ dy,
-                float *__restrict__ dx, PoolGeo g, FastDiv divHW, FastDiv divH, FastDiv divSy,
-                FastDiv divSx, size_t total, int method) {
-  size_t stride = (size_t)gridDim.x * 256;
-  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += stride) {
-    uint32_t plane = xm_div((uint32_t)idx, divHW);
-    uint32_t q = (uint32_t)idx - plane * divHW.d;
-    int w = (int)xm_div(q, divH);
-    int h = (int)q - w * (int)divH.d;
+                float *__restrict__ dx, PoolGeo g, FastDiv divSy, FastDiv divSx, int planes,
+                int method) {
+  const int h = blockIdx.z * blockDim.x + threadIdx.x;
+  const int w = blockIdx.x * blockDim.y + threadIdx.y;
+  if (h >= g.H || w >= g.W) return;
+  // windows ho with ho*sy - pt <= h < ho*sy - pt + ph   (all dividends are >= 0)
+  int ho_lo = h + g.pt - g.ph + 1;
+  ho_lo = ho_lo <= 0 ? 0 : (int)xm_div((uint32_t)(ho_lo + g.sy - 1), divSy);
+  const int ho_hi = min((int)xm_div((uint32_t)(h + g.pt), divSy), g.Ho - 1);
+  int wo_lo = w + g.pl - g.pw + 1;
+  wo_lo = wo_lo <= 0 ? 0 : (int)xm_div((uint32_t)(wo_lo + g.sx - 1), divSx);
+  const int wo_hi = min((int)xm_div((uint32_t)(w + g.pl), divSx), g.Wo - 1);
+  if (FAST) {
+    int off[4], code[4];
+    float scale[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int ho = ho_lo + i, wo = wo_lo + j;
+        ok[i + 2 * j] = (ho <= ho_hi) & (wo <= wo_hi);
+        int hoc = min(ho, g.Ho - 1), woc = min(wo, g.Wo - 1);
+        off[i + 2 * j] = hoc + g.Ho * woc;
+        int w0 = woc * g.sx - g.pl, h0 = hoc * g.sy - g.pt;
+        code[i + 2 * j] = (h - h0) + g.ph * (w - w0);
+        int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
+        scale[i + 2 * j] = 1.0f / (float)((h2 - max(h0, 0)) * (w2 - max(w0, 0)));
+      }
+    for (int plane = blockIdx.y * blockDim.z + threadIdx.z; plane < planes; plane += gridDim.y * blockDim.z) {
+      const size_t ob = (size_t)plane * g.Ho * g.Wo;
+      float d[4];
+      int a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = dy[ob + off[k]];
+        a[k] = method == XM_POOL_MAX ? (int)amax[ob + off[k]] : 0;
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (method == XM_POOL_MAX)
+          acc += (ok[k] & (a[k] == code[k])) ? d[k] : 0.f;
+        else
+          acc += ok[k] ? d[k] * scale[k] : 0.f;
+      }
+      dx[(size_t)plane * g.H * g.W + h + (size_t)g.H * w] = acc;
+    }
+    return;
+  }
+  for (int plane = blockIdx.y * blockDim.z + threadIdx.z; plane < planes; plane += gridDim.y * blockDim.z) {
     const size_t ob = (size_t)plane * g.Ho * g.Wo;
-    // windows ho with ho*sy - pt <= h < ho*sy - pt + ph   (all dividends are >= 0)
-    int ho_lo = h + g.pt - g.ph + 1;
-    ho_lo = ho_lo <= 0 ? 0 : (int)xm_div((uint32_t)(ho_lo + g.sy - 1), divSy);
-    int ho_hi = min((int)xm_div((uint32_t)(h + g.pt), divSy), g.Ho - 1);
-    int wo_lo = w + g.pl - g.pw + 1;
-    wo_lo = wo_lo <= 0 ? 0 : (int)xm_div((uint32_t)(wo_lo + g.sx - 1), divSx);
-    int wo_hi = min((int)xm_div((uint32_t)(w + g.pl), divSx), g.Wo - 1);
     float acc = 0.f;
     for (int wo = wo_lo; wo <= wo_hi; ++wo)
       for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-        int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
-        size_t o = ob + ho + (size_t)g.Ho * wo;
+        const int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
+        const size_t o = ob + ho + (size_t)g.Ho * wo;
         if (method == XM_POOL_MAX) {
-          int code = (h - h0) + g.ph * (w - w0);
+          const int code = (h - h0) + g.ph * (w - w0);
           if ((int)amax[o] == code) acc += dy[o];
         } else {
-          int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
+          const int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
           acc += dy[o] * (1.0f / (float)((h2 - max(h0, 0)) * (w2 - max(w0, 0))));
         }
       }
-    dx[idx] = acc;
+    dx[(size_t)plane * g.H * g.W + h + (size_t)g.H * w] = acc;
   }
 }
 
@@ -456,10 +555,15 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
     XM_LAUNCH_CHECK();
     return XM_OK;
   }
-  size_t total = (size_t)g.Ho * g.Wo * C * N;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, amax, g,
-                     make_fastdiv((uint32_t)(g.Ho * g.Wo)), make_fastdiv((uint32_t)g.Ho), total,
-                     method);
+  PoolLaunch pl_ = pool_launch(g.Ho, g.Wo, (long long)C * N);
+  if (ph == 3 && pw == 3)
+    hipLaunchKernelGGL((pool_fwd_kernel<3, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+  else if (ph == 5 && pw == 3)
+    hipLaunchKernelGGL((pool_fwd_kernel<5, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+  else if (ph == 2 && pw == 2)
+    hipLaunchKernelGGL((pool_fwd_kernel<2, 2>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+  else
+    hipLaunchKernelGGL((pool_fwd_kernel<0, 0>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }
@@ -471,7 +575,6 @@ static int pool_backward(const float *x, const unsigned char *amax, int H, int W
   int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
   if (rc) return rc;
   if (!dzdy || !dx_out) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
-  size_t total = (size_t)H * W * C * N;
   if (method == XM_POOL_MAX && !amax) {
     // plain MatConvNet signature: recompute the routing table from X into scratch first
     if (!x) return fail(XM_EINVAL, "vl_nnpool: X is NULL");
@@ -484,9 +587,14 @@ static int pool_backward(const float *x, const unsigned char *amax, int H, int W
     if (rc) return rc;
     amax = aw;
   }
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, amax, dzdy, dx_out, g,
-                     make_fastdiv((uint32_t)(H * W)), make_fastdiv((uint32_t)H),
-                     make_fastdiv((uint32_t)sy), make_fastdiv((uint32_t)sx), total, method);
+  PoolLaunch pl_ = pool_launch(H, W, (long long)C * N);
+  const bool fast = (ph + sy - 1) / sy <= 2 && (pw + sx - 1) / sx <= 2;
+  if (fast)
+    hipLaunchKernelGGL(pool_bwd_kernel<true>, pl_.grid, pl_.block, 0, st, amax, dzdy, dx_out, g,
+                       make_fastdiv((uint32_t)sy), make_fastdiv((uint32_t)sx), C * N, method);
+  else
+    hipLaunchKernelGGL(pool_bwd_kernel<false>, pl_.grid, pl_.block, 0, st, amax, dzdy, dx_out, g,
+                       make_fastdiv((uint32_t)sy), make_fastdiv((uint32_t)sx), C * N, method);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }
