@@ -2,6 +2,8 @@
 // Replaces MatConvNet's vl_nnconv MEX (matlab/src/vl_nnconv.cu, bits/nnconv.cu: im2row + SGEMM
 // per image) behind the same operator contract; see include/xmodal.h and conv_kernels.h.
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "conv_kernels.h"
@@ -233,7 +235,7 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   a.slab = splits > 1 ? slab : nullptr;
   dim3 grid(a.nbm * a.nbn, splits);
   {
-    ProfScope ps(0 * 100 + ci * 2 + mode, 2.0 * a.M * (double)a.NP * a.Rtrue, st);
+    ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st);
     if (mode)
       launch_gemm_cfg<1>(ci, a, grid, st);
     else
@@ -251,6 +253,60 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
 
 static int choose_cfg(long long M, long long NP, int nkt) {
   return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP, nkt);
+}
+
+// ---- measured tile selection ("find mode") ---------------------------------------------------
+// The first time a (direction, geometry) is seen, every tile configuration is timed on the
+// caller's stream (HIP events, 2 launches each, best of) and the winner is cached for the life of
+// the process.  Happens during warm-up; results are identical for every configuration.
+// XM_AUTOTUNE=0 falls back to the analytic model above.
+struct TuneKey {
+  int kind, M, NP, Rp, mode, a, b, c, d;
+  bool operator<(const TuneKey &o) const { return memcmp(this, &o, sizeof(TuneKey)) < 0; }
+};
+static std::map<TuneKey, int> g_tuned;
+static int autotune_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("XM_AUTOTUNE");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on;
+}
+template <class F>
+static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch) {
+  if (g_force_cfg >= 0) return g_force_cfg;
+  if (!autotune_enabled()) return fallback;
+  auto it = g_tuned.find(key);
+  if (it != g_tuned.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fallback;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
+  float best = 1e30f;
+  int bi = fallback;
+  for (int ci = 0; ci < kNumCfg; ++ci) {
+    float tmin = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(e0, st);
+      if (launch(ci) != XM_OK) {
+        tmin = 1e30f;
+        break;
+      }
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) tmin = std::min(tmin, ms);
+    }
+    if (tmin < best) {
+      best = tmin;
+      bi = ci;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  g_tuned[key] = bi;
+  return bi;
 }
 
 static void launch_wgrad_cfg(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
@@ -332,13 +388,16 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   const int Rp = (g.R + kBK - 1) / kBK * kBK;
   const bool need_pad = (g.R % kBK) != 0 || ((uintptr_t)f & 15);
   const int mode = ((g.pt | g.pb | g.pl | g.pr) != 0 || Rp != g.R) ? 1 : 0;
-  const int ci = choose_cfg(g.Kg, (long long)g.Ho * g.Wo * g.N, Rp / kBK);
   ConvGemmArgs proto{};
   proto.M = g.Kg;
   proto.NP = g.Ho * g.Wo * g.N;
   proto.Rp = Rp;
-  int splits = 1;
-  size_t slabf = gemm_slab_floats(proto, ci, &splits);
+  // scratch must fit the split-K slab of whichever tile configuration ends up being used
+  size_t slabf = 0;
+  for (int c = 0; c < kNumCfg; ++c) {
+    int sp;
+    slabf = std::max(slabf, gemm_slab_floats(proto, c, &sp));
+  }
   WsCarver ws;
   int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4));
   if (rc) return rc;
@@ -399,7 +458,15 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.OH = g.Ho;
     a.oChanStride = g.Ho * g.Wo;
     a.oSampleStride = g.Ho * g.Wo * g.K;
-    rc = launch_gemm(a, mode, ci, splits, slab, st);
+    auto run = [&](int ci) {
+      int sp;
+      gemm_slab_floats(a, ci, &sp);
+      ConvGemmArgs aa = a;
+      return launch_gemm(aa, mode, ci, sp, slab, st);
+    };
+    TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run);
+    rc = run(ci);
     if (rc) return rc;
   }
   return XM_OK;
@@ -459,23 +526,26 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   if (!covers_all || cls.empty())
     XM_HIP(hipMemsetAsync(dxo, 0, sizeof(float) * (size_t)g.H * g.W * g.C * g.N, st));
   if (cls.empty()) return XM_OK;
-  // tile configuration / split-K per class (slab sized for the largest class)
+  // scratch for the split-K slab of the largest class under any tile configuration
   size_t slab_max = 0;
-  std::vector<int> cls_cfg(cls.size()), cls_splits(cls.size());
   for (size_t i = 0; i < cls.size(); ++i) {
     const Cls &c = cls[i];
     ConvGemmArgs proto{};
     proto.M = g.FC;
     proto.NP = c.PI * c.PJ * g.N;
     proto.Rp = c.Rp;
-    cls_cfg[i] = choose_cfg(proto.M, proto.NP, proto.Rp / kBK);
-    slab_max = std::max(slab_max, gemm_slab_floats(proto, cls_cfg[i], &cls_splits[i]));
+    for (int ci = 0; ci < kNumCfg; ++ci) {
+      int sp;
+      slab_max = std::max(slab_max, gemm_slab_floats(proto, ci, &sp));
+    }
   }
   WsCarver ws;
   int rc = ws.init(abytes + WsCarver::need(slab_max, 4));
   if (rc) return rc;
   float *slab = slab_max ? (float *)(ws.base + abytes) : nullptr;
   const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
+  double pair_total = 0;
+  for (const Cls &c : cls) pair_total += (double)c.PI * c.PJ * g.N * c.Rc;
   for (size_t ic = 0; ic < cls.size(); ++ic) {
     const Cls &c = cls[ic];
     if (c.nU * c.nV > 63)
@@ -543,49 +613,43 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.OH = g.H;
       a.oChanStride = g.H * g.W;
       a.oSampleStride = g.H * g.W * g.C;
-      rc = launch_gemm(a, 1, cls_cfg[ic], cls_splits[ic], slab, st);
+      // algorithmic work of dgrad == forward MACs (2*Ho*Wo*N*K*R), apportioned over the classes by
+      // their share of (pixel, tap) pairs; masked-out pairs are not work
+      a.algoFlops = 2.0 * g.Ho * g.Wo * (double)g.N * g.Kg * g.R * ((double)a.NP * c.Rc) / pair_total;
+      auto run = [&](int ci) {
+        int sp;
+        gemm_slab_floats(a, ci, &sp);
+        ConvGemmArgs aa = a;
+        return launch_gemm(aa, 1, ci, sp, slab, st);
+      };
+      TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, c.PI, c.PJ, g.Ho};
+      int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run);
+      rc = run(ci);
       if (rc) return rc;
     }
   }
   return XM_OK;
 }
 
-static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
-  int ci = g_force_cfg;
-  if (ci < 0) {
-    double best = 1e300;
-    for (int i = 0; i < kNumCfg; ++i) {
-      const Cfg &cc = kCfgs[i];
-      double eff = (cc.tm * cc.tn >= 4) ? 1.0 : (cc.tm * cc.tn >= 2 ? 1.12 : 1.3);
-      double cost = (double)((g.Kg + cc.bm() - 1) / cc.bm() * cc.bm()) *
-                    ((g.R + cc.bn() - 1) / cc.bn() * cc.bn()) * eff;
-      if (cost < best) {
-        best = cost;
-        ci = i;
-      }
-    }
-  }
+// one wgrad launch (+ split reduction) with tile configuration ci; `part` has room for 256 slabs
+static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g, int ci, float *part,
+                     hipStream_t st) {
   const Cfg &c = kCfgs[ci];
   const int NP = g.Ho * g.Wo * g.N;
   const int nkt = (NP + kBK - 1) / kBK;
   const int nbm = (g.Kg + c.bm() - 1) / c.bm(), nbn = (g.R + c.bn() - 1) / c.bn();
   const int Rn = nbn * c.bn();
-  // split the pixel reduction until the grid fills the chip about twice
-  int tiles = nbm * nbn;
-  int splits = std::max(1, std::min(nkt / 8, 512 / tiles));  // one full round, no tail
+  // split the pixel reduction so that the grid fills one round of the chip (no tail round);
+  // smaller tiles co-reside more blocks per CU
+  const int tiles = nbm * nbn;
+  const int slots = 256 * (c.bm() * c.bn() >= 128 * 128 ? 2 : (c.bm() * c.bn() >= 64 * 128 ? 3 : 4));
+  int splits = std::max(1, std::min(nkt / 8, slots / tiles));
   splits = std::min(splits, 256);
   int tps = (nkt + splits - 1) / splits;
   splits = (nkt + tps - 1) / tps;
   const int4 *taps = fwd_taps(g, Rn);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
-  size_t slab = (size_t)g.Kg * g.R;
-  WsCarver ws;
-  float *part = nullptr;
-  if (splits > 1) {
-    int rc = ws.init(WsCarver::need(slab * splits, 4));
-    if (rc) return rc;
-    part = ws.take<float>(slab * splits);
-  }
+  const size_t slab = (size_t)g.Kg * g.R;
   for (int grp = 0; grp < g.G; ++grp) {
     WgradArgs a{};
     a.dY = dzdy + (size_t)grp * g.Kg * g.Ho * g.Wo;
@@ -633,6 +697,36 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
     }
   }
   return XM_OK;
+}
+
+static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
+  // analytic fallback: minimal padded work (split-K supplies the parallelism)
+  int fb = 0;
+  {
+    double best = 1e300;
+    for (int i = 0; i < kNumCfg; ++i) {
+      const Cfg &cc = kCfgs[i];
+      double eff = (cc.tm * cc.tn >= 4) ? 1.0 : (cc.tm * cc.tn >= 2 ? 1.12 : 1.3);
+      double cost = (double)((g.Kg + cc.bm() - 1) / cc.bm() * cc.bm()) *
+                    ((g.R + cc.bn() - 1) / cc.bn() * cc.bn()) * eff;
+      if (cost < best) {
+        best = cost;
+        fb = i;
+      }
+    }
+  }
+  const int NP = g.Ho * g.Wo * g.N;
+  const int nkt = (NP + kBK - 1) / kBK;
+  const size_t slab = (size_t)g.Kg * g.R;
+  const int max_splits = std::max(1, std::min(256, nkt / 8));
+  WsCarver ws;
+  int rc = ws.init(WsCarver::need(slab * max_splits, 4));
+  if (rc) return rc;
+  float *part = ws.take<float>(slab * max_splits);
+  auto run = [&](int ci) { return wgrad_run(x, dzdy, dfo, g, ci, part, st); };
+  TuneKey key{2, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+  int ci = tune_cfg(key, fb, st, run);
+  return run(ci);
 }
 
 }  // namespace xm

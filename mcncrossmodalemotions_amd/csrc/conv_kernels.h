@@ -53,6 +53,7 @@ struct ConvGemmArgs {
   int oChanStride, oSampleStride;
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
+  double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
 };
 
 // XCD-aware, bijective block remap: consecutive logical tiles (which share the same pixel tile)

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dirs", default="fwd,dgrad,wgrad")
+    ap.add_argument("--scan", action="store_true", help="time every tile configuration (forced)")
     args = ap.parse_args()
     names = args.cases or list(CASES)
     print("%-12s %-6s %9s %9s" % ("case", "dir", "ms", "TFLOP/s"))
@@ -64,14 +65,19 @@ def main():
         dz = vl.from_numpy(np.random.default_rng(2).standard_normal(tuple(y.shape)).astype(np.float32))
         Ho, Wo = int(y.shape[0]), int(y.shape[1])
         flops = 2.0 * Ho * Wo * N * K * FH * FW * C
-        for d in args.dirs.split(","):
+        from mcncrossmodalemotions_amd import _lib
+        L = _lib.load()
+        cfgs = list(range(L.xm_debug_num_conv_cfgs())) if args.scan else [-1]
+        for d, cfg in [(dd, cc) for dd in args.dirs.split(",") for cc in cfgs]:
+            L.xm_debug_force_conv_cfg(cfg)
             if d == "fwd":
                 ms = timeit(lambda: vl.vl_nnconv(x, f, b, stride=s, pad=p), args.reps)
             elif d == "dgrad":
                 ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_filters=True), args.reps)
             else:
                 ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_data=True), args.reps)
-            print("%-12s %-6s %9.3f %9.1f" % (nm, d, ms, flops / ms / 1e9), flush=True)
+            print("%-12s %-6s %9.3f %9.1f %s" % (nm, d, ms, flops / ms / 1e9, "" if cfg < 0 else "cfg%d" % cfg), flush=True)
+        L.xm_debug_force_conv_cfg(-1)
 
 
 if __name__ == "__main__":
