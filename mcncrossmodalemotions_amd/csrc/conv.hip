@@ -352,7 +352,7 @@ static int make_geo(Geo &g, int H, int W, int C, int N, int FH, int FW, int FC, 
 
 // forward tap table for the implicit GEMM: r = u + FH*(v + FW*c) -> {byte offset in X, (u,v) index}
 static const int2 *fwd_taps2(const Geo &g, int Rp) {
-  int count = Rp + 2 * kBK;  // kernels fetch the table two stages ahead
+  int count = Rp + 3 * kBK;  // kernels fetch the table three stages ahead
   std::vector<int2> t(count);
   for (int r = 0; r < count; ++r) {
     if (r < g.R) {
@@ -553,8 +553,8 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     // tap table in dY space: r' = iu + nU*(iv + nV*k); u' = (u*dy - a)/sy; ho = i' - u'
     const int up0 = ((c.u0 * g.dy) - c.a) / g.sy, ups = c.ustep * g.dy / g.sy;
     const int vp0 = ((c.v0 * g.dx) - c.b) / g.sx, vps = c.vstep * g.dx / g.sx;
-    std::vector<int2> t(c.Rp + 2 * kBK);
-    for (int r = 0; r < c.Rp + 2 * kBK; ++r) {
+    std::vector<int2> t(c.Rp + 3 * kBK);
+    for (int r = 0; r < c.Rp + 3 * kBK; ++r) {
       if (r < c.Rc) {
         int iu = r % c.nU, iv = (r / c.nU) % c.nV, k = r / (c.nU * c.nV);
         int up = up0 + iu * ups, vp = vp0 + iv * vps;

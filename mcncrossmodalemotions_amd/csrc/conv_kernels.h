@@ -39,7 +39,7 @@ struct ConvGemmArgs {
   const float *X;     // gather source
   float *Y;           // destination
   float *slab;        // splits > 1: [splits][M][NPs] raw partial sums
-  const int2 *taps;   // Rp + 2*kBK entries {byte offset, (u,v) index}; padding entries use index 63
+  const int2 *taps;   // Rp + 3*kBK entries {byte offset, (u,v) index}; padding entries use index 63
   const float *bias, *scale, *shift, *resid;
   int relu;
   unsigned xBytes;    // size of the gather source in bytes (buffer bounds check)
@@ -194,8 +194,11 @@ conv_gemm_kernel(const ConvGemmArgs a) {
   const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
   const float *sBr = sB + half * PLB + (wn * TN * 32 + l31) * 4;
 
-  f32x4 ra[NUA], rb[NUB];
-  int tpo[NUB * 4], tpi[NUB * 4];  // next tile's tap entries
+  // Two register sets: loads are issued TWO stages ahead of their use (prefetch distance 2), so a
+  // stage's global-load latency is covered by two compute phases and twice as many loads are in
+  // flight -- what the short-K / small-tile layers need (their compute phase is ~512 cycles).
+  f32x4 ra0[NUA], rb0[NUB], ra1[NUA], rb1[NUB];
+  int tpo[NUB * 4], tpi[NUB * 4];  // tap entries of the next tile to be loaded
 
 #define XM_FETCH_TAPS(KT)                                                      \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
@@ -210,9 +213,9 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     }                                                                          \
   }
 
-#define XM_LOAD_TILE(KT)                                                       \
+#define XM_LOAD_TILE(KT, RA, RB)                                               \
   _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
-    ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + (KT) * kBK);            \
+    RA[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + (KT) * kBK);            \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
     unsigned off_[4];                                                          \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
@@ -223,28 +226,35 @@ conv_gemm_kernel(const ConvGemmArgs a) {
         off_[e] |= (unsigned)(((int)(w_ << (31 - (idx_ & 31)))) >> 31);        \
       }                                                                        \
     }                                                                          \
-    rb[i].x = buf_load(xrsrc, off_[0]);                                        \
-    rb[i].y = buf_load(xrsrc, off_[1]);                                        \
-    rb[i].z = buf_load(xrsrc, off_[2]);                                        \
-    rb[i].w = buf_load(xrsrc, off_[3]);                                        \
+    RB[i].x = buf_load(xrsrc, off_[0]);                                        \
+    RB[i].y = buf_load(xrsrc, off_[1]);                                        \
+    RB[i].z = buf_load(xrsrc, off_[2]);                                        \
+    RB[i].w = buf_load(xrsrc, off_[3]);                                        \
   }
 
-#define XM_STORE_TILE(BUF)                                                     \
+#define XM_STORE_TILE(BUF, RA, RB)                                             \
   _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
     if (kNG * BM % 256 == 0 || t + 256 * i < kNG * BM)                         \
-      *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = ra[i];          \
+      *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = RA[i];          \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
     if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
-      *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = rb[i];
+      *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = RB[i];
 
-  // one pipeline stage: issue stage KT+1's loads, compute stage CUR from LDS, park KT+1 in LDS
-#define XM_STAGE(KT, CUR)                                                      \
-  XM_LOAD_TILE((KT) + 1)                                                       \
-  XM_FETCH_TAPS((KT) + 2)                                                      \
+  // one pipeline stage on LDS buffer CUR: issue stage KT+2's loads into (LA, LB), compute stage KT,
+  // then park stage KT+1 (already in flight in (SA, SB) since the previous stage) in LDS[CUR^1]
+#define XM_STAGE_LD(KT, CUR, LA, LB, SA, SB)                                   \
+  XM_LOAD_TILE((KT) + 2, LA, LB)                                               \
+  XM_FETCH_TAPS((KT) + 3)                                                      \
   XM_COMPUTE(CUR)                                                              \
   XM_INTERLEAVE(MODE == 1 ? 3 : 2)                                             \
   __builtin_amdgcn_sched_barrier(0);                                           \
-  XM_STORE_TILE((CUR) ^ 1)                                                     \
+  XM_STORE_TILE((CUR) ^ 1, SA, SB)                                             \
+  __syncthreads();
+  // same without issuing new loads (the last two stages of the reduction)
+#define XM_STAGE_NL(CUR, SA, SB)                                               \
+  XM_COMPUTE(CUR)                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  XM_STORE_TILE((CUR) ^ 1, SA, SB)                                             \
   __syncthreads();
 
   f32x16 acc[TM][TN];
@@ -255,20 +265,29 @@ conv_gemm_kernel(const ConvGemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // the tap table carries 2*kBK padding entries, so fetching ahead is always legal
+  // the tap table carries 3*kBK padding entries, so fetching ahead is always legal
   if (kt0 < kt1) {
     XM_FETCH_TAPS(kt0)
-    XM_LOAD_TILE(kt0)
+    XM_LOAD_TILE(kt0, ra0, rb0)
     XM_FETCH_TAPS(kt0 + 1)
-    XM_STORE_TILE(0)
+    if (kt0 + 1 < kt1) {
+      XM_LOAD_TILE(kt0 + 1, ra1, rb1)
+      XM_FETCH_TAPS(kt0 + 2)
+    }
+    XM_STORE_TILE(0, ra0, rb0)
     __syncthreads();
     int kt = kt0;
-    for (; kt + 2 < kt1; kt += 2) {
-      XM_STAGE(kt, 0)
-      XM_STAGE(kt + 1, 1)
+    for (; kt + 3 < kt1; kt += 2) {
+      XM_STAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
+      XM_STAGE_LD(kt + 1, 1, ra1, rb1, ra0, rb0)
     }
-    if (kt + 2 == kt1) {
-      XM_STAGE(kt, 0)
+    const int rem = kt1 - kt;  // 1, 2 or 3 stages left; LDS[0] holds stage kt, set 1 stage kt+1
+    if (rem == 3) {
+      XM_STAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
+      XM_STAGE_NL(1, ra0, rb0)
+      XM_COMPUTE(0)
+    } else if (rem == 2) {
+      XM_STAGE_NL(0, ra1, rb1)
       XM_COMPUTE(1)
     } else {
       XM_COMPUTE(0)
@@ -277,7 +296,8 @@ conv_gemm_kernel(const ConvGemmArgs a) {
 #undef XM_FETCH_TAPS
 #undef XM_LOAD_TILE
 #undef XM_STORE_TILE
-#undef XM_STAGE
+#undef XM_STAGE_LD
+#undef XM_STAGE_NL
 
   // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (a.slab) {
