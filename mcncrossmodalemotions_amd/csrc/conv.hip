@@ -29,7 +29,7 @@ __global__ void pad_filter_kernel(const float *__restrict__ f, float *__restrict
 __global__ void __launch_bounds__(256)
 prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int FH, int FW, int FC,
                          int Kg, int u0, int ustep, int nU, int v0, int vstep, int nV, int lda,
-                         int TS) {
+                         int TS, int fold) {
   extern __shared__ float tile[];  // [kl][cl][t], kl pitch TS*T + 1
   const int T = FH * FW, nT = nU * nV;
   const int c0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
@@ -47,13 +47,20 @@ prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int
     int iu = tt % nU, iv = tt / nU;
     int t = (u0 + iu * ustep) + FH * (v0 + iv * vstep);
     int c = c0 + cl, k = k0 + kl;
-    if (c < FC && k < Kg) o[(size_t)c * lda + (size_t)nT * k + tt] = tile[kl * pitch + cl * T + t];
+    if (c < FC && k < Kg) {
+      // fold: one GEMM row per (filter row u, channel c); the reduction keeps only (iv, k)
+      size_t dst = fold ? (size_t)(iu + nU * c) * lda + (size_t)nV * k + iv
+                        : (size_t)c * lda + (size_t)nT * k + tt;
+      o[dst] = tile[kl * pitch + cl * T + t];
+    }
   }
-  if (blockIdx.y == 0) {  // zero the K padding columns [nT*Kg, lda)
-    int padc = lda - nT * Kg;
-    for (int i = threadIdx.x; i < TS * padc; i += 256) {
-      int cl = i / padc, rr = nT * Kg + i % padc;
-      if (c0 + cl < FC) o[(size_t)(c0 + cl) * lda + rr] = 0.f;
+  if (blockIdx.y == 0) {  // zero the K padding columns
+    const int used = (fold ? nV : nT) * Kg, rows = fold ? nU : 1;
+    int padc = lda - used;
+    for (int i = threadIdx.x; i < TS * rows * padc; i += 256) {
+      int rl = i / padc, rr = used + i % padc;
+      int cl = rl / rows, ul = rl % rows;
+      if (c0 + cl < FC) o[((size_t)(c0 + cl) * rows + ul) * lda + rr] = 0.f;
     }
   }
 }
@@ -458,6 +465,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.OH = g.Ho;
     a.oChanStride = g.Ho * g.Wo;
     a.oSampleStride = g.Ho * g.Wo * g.K;
+    a.divMU = make_fastdiv(1);
+    a.oUStride = 0;
     auto run = [&](int ci) {
       int sp;
       gemm_slab_floats(a, ci, &sp);
@@ -478,6 +487,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
   };
+  // H-collapsing convolution (FC layer sliding along W only, e.g. the student's fc6: 9x1 filter on a
+  // 9 x Wi map): every input row hi is touched by exactly one filter row u = hi, so folding u into
+  // the GEMM rows (M = FH*FC) avoids multiplying FH-1 masked-out taps per pixel.
+  const bool foldH = g.Ho == 1 && g.FH > 1 && g.FH == g.H && g.pt == 0 && g.pb == 0 && g.dy == 1 && g.sy == 1;
   std::vector<Cls> cls;
   size_t abytes = 0;
   bool covers_all = true;
@@ -516,10 +529,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         covers_all = false;
         continue;
       }
-      c.Rc = c.nU * c.nV * g.Kg;
+      c.Rc = (foldH ? c.nV : c.nU * c.nV) * g.Kg;
       c.Rp = (c.Rc + kBK - 1) / kBK * kBK;
       c.aoff = abytes;
-      abytes += WsCarver::need((size_t)g.FC * c.Rp * g.G, 4);
+      abytes += WsCarver::need((size_t)g.FC * (foldH ? g.FH : 1) * c.Rp * g.G, 4);
       cls.push_back(c);
     }
   // pixels whose class has no tap (e.g. 1x1 stride 2) receive no gradient
@@ -531,8 +544,8 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   for (size_t i = 0; i < cls.size(); ++i) {
     const Cls &c = cls[i];
     ConvGemmArgs proto{};
-    proto.M = g.FC;
-    proto.NP = c.PI * c.PJ * g.N;
+    proto.M = foldH ? g.FC * g.FH : g.FC;
+    proto.NP = (foldH ? 1 : c.PI) * c.PJ * g.N;
     proto.Rp = c.Rp;
     for (int ci = 0; ci < kNumCfg; ++ci) {
       int sp;
@@ -545,7 +558,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   float *slab = slab_max ? (float *)(ws.base + abytes) : nullptr;
   const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
   double pair_total = 0;
-  for (const Cls &c : cls) pair_total += (double)c.PI * c.PJ * g.N * c.Rc;
+  for (const Cls &c : cls) pair_total += (double)(foldH ? 1 : c.PI) * c.PJ * g.N * c.Rc;
   for (size_t ic = 0; ic < cls.size(); ++ic) {
     const Cls &c = cls[ic];
     if (c.nU * c.nV > 63)
@@ -555,7 +568,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     const int vp0 = ((c.v0 * g.dx) - c.b) / g.sx, vps = c.vstep * g.dx / g.sx;
     std::vector<int2> t(c.Rp + 3 * kBK);
     for (int r = 0; r < c.Rp + 3 * kBK; ++r) {
-      if (r < c.Rc) {
+      if (r < c.Rc && foldH) {
+        int iv = r % c.nV, k = r / c.nV;
+        t[r] = make_int2(4 * (-g.Ho * (vp0 + iv * vps) + g.Ho * g.Wo * k), iv);
+      } else if (r < c.Rc) {
         int iu = r % c.nU, iv = (r / c.nU) % c.nV, k = r / (c.nU * c.nV);
         int up = up0 + iu * ups, vp = vp0 + iv * vps;
         t[r] = make_int2(4 * (-up - g.Ho * vp + g.Ho * g.Wo * k), iu + c.nU * iv);
@@ -567,14 +583,14 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
     float *At = (float *)(ws.base + c.aoff);
     for (int grp = 0; grp < g.G; ++grp) {
-      float *Ag = At + (size_t)grp * g.FC * c.Rp;
+      float *Ag = At + (size_t)grp * g.FC * (foldH ? g.FH : 1) * c.Rp;
       {
         const int T = g.FH * g.FW;
         const int TS = T <= 14 ? 32 : (T <= 56 ? 16 : 8);
         size_t lds = sizeof(float) * (size_t)TS * (TS * T + 1);
         hipLaunchKernelGGL(prep_dgrad_filter_kernel, dim3((g.FC + TS - 1) / TS, (g.Kg + TS - 1) / TS),
                            dim3(256), lds, st, f + (size_t)g.R * g.Kg * grp, Ag, g.FH, g.FW, g.FC, g.Kg,
-                           c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS);
+                           c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS, foldH ? 1 : 0);
         XM_LAUNCH_CHECK();
       }
       ConvGemmArgs a{};
@@ -585,14 +601,14 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.xBytes = (unsigned)((dyTotal - xoff) * 4);
       a.Y = dxo + (size_t)grp * g.FC * g.H * g.W;
       a.taps = taps;
-      a.M = g.FC;
+      a.M = foldH ? g.FC * g.FH : g.FC;
       a.Rp = c.Rp;
       a.Rtrue = c.Rc;
-      a.PI = c.PI;
+      a.PI = foldH ? 1 : c.PI;
       a.PJ = c.PJ;
-      a.NP = c.PI * c.PJ * g.N;
-      a.divPIJ = make_fastdiv((uint32_t)(c.PI * c.PJ));
-      a.divPI = make_fastdiv((uint32_t)c.PI);
+      a.NP = a.PI * c.PJ * g.N;
+      a.divPIJ = make_fastdiv((uint32_t)(a.PI * c.PJ));
+      a.divPI = make_fastdiv((uint32_t)a.PI);
       a.gsy = 1;
       a.gsx = 1;
       a.gh0 = c.i0;
@@ -600,9 +616,9 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.LimH = g.Ho;
       a.LimW = g.Wo;
       a.xSampleStride = g.Ho * g.Wo * g.K;
-      a.nU = c.nU;
+      a.nU = foldH ? 1 : c.nU;
       a.nV = c.nV;
-      a.du0 = -up0;
+      a.du0 = foldH ? 0 : -up0;
       a.dus = -ups;
       a.dv0 = -vp0;
       a.dvs = -vps;
@@ -613,6 +629,13 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.OH = g.H;
       a.oChanStride = g.H * g.W;
       a.oSampleStride = g.H * g.W * g.C;
+      a.divMU = make_fastdiv(foldH ? (uint32_t)g.FH : 1u);
+      a.oUStride = foldH ? 1 : 0;
+      if (foldH) {
+        a.gh0 = 0;  // the single dY row; destination row comes from the GEMM row (m % FH)
+        a.oh0 = 0;
+        a.osy = 0;
+      }
       // algorithmic work of dgrad == forward MACs (2*Ho*Wo*N*K*R), apportioned over the classes by
       // their share of (pixel, tap) pairs; masked-out pairs are not work
       a.algoFlops = 2.0 * g.Ho * g.Wo * (double)g.N * g.Kg * g.R * ((double)a.NP * c.Rc) / pair_total;
@@ -622,7 +645,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         ConvGemmArgs aa = a;
         return launch_gemm(aa, 1, ci, sp, slab, st);
       };
-      TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, c.PI, c.PJ, g.Ho};
+      TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
       int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run);
       rc = run(ci);
       if (rc) return rc;

@@ -51,6 +51,10 @@ struct ConvGemmArgs {
   int nU, nV, du0, dus, dv0, dvs;  // tap (iu,iv) sits at (du0 + iu*dus, dv0 + iv*dvs) from the origin
   int osy, osx, oh0, ow0, OH;      // destination of pixel (i,j): (oh0 + i*osy, ow0 + j*osx)
   int oChanStride, oSampleStride;
+  // GEMM row m -> destination offset (m / oMU) * oChanStride + (m % oMU) * oUStride.  oMU == 1 is the
+  // plain channel map; oMU == FH folds the filter rows of an H-collapsing conv (Ho == 1) into M.
+  FastDiv divMU;
+  int oUStride;
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
@@ -337,7 +341,8 @@ conv_gemm_kernel(const ConvGemmArgs a) {
           float v = acc[i][j][r];
           if (a.bias) v += a.bias[m];
           if (a.scale) v = v * a.scale[m] + a.shift[m];
-          int off = obase + m * a.oChanStride;
+          uint32_t mc = xm_div((uint32_t)m, a.divMU);
+          int off = obase + (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
           if (a.resid) v += a.resid[off];
           if (a.relu) v = fmaxf(v, 0.f);
           a.Y[off] = v;
@@ -360,8 +365,9 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits) {
   uint32_t q = (uint32_t)p - n * a.divPIJ.d;
   uint32_t jj = xm_div(q, a.divPI);
   uint32_t ii = q - jj * a.divPI.d;
+  uint32_t mc = xm_div((uint32_t)m, a.divMU);
   int off = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride +
-            m * a.oChanStride;
+            (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
   if (a.bias) v += a.bias[m];
   if (a.scale) v = v * a.scale[m] + a.shift[m];
   if (a.resid) v += a.resid[off];
