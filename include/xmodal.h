@@ -115,6 +115,22 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
                               const float *moments_in, float *dx_out, float *dg_out, float *db_out,
                               float *moments_out, int flags, void *stream);
 
+/* Extension: vl_nnbnorm -> vl_nnrelu -> vl_nnpool('max') as one fused operator pair.  The
+ * normalised / rectified tensor is never materialised: forward = moments (train mode) + one pass
+ * that normalises, rectifies and pools while recording the argmax table; backward = two passes
+ * over X that rebuild the routed, ReLU-masked derivative on the fly.  Results are identical to the
+ * three separate operators.  `moments` (backward) is what the forward returned; train != 0 applies
+ * the batch-statistics terms of vl_nnbnorm's backward (train mode), 0 treats them as constants. */
+int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *g,
+                                 const float *b, float epsilon, const float *moments_in, int ph, int pw,
+                                 int sy, int sx, int pt, int pb, int pl, int pr, float *y_pool,
+                                 unsigned char *argmax, float *moments_out, void *stream);
+int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, const float *g,
+                                  const float *b, const float *moments, int train, int ph, int pw,
+                                  int sy, int sx, int pt, int pb, int pl, int pr,
+                                  const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
+                                  float *dg_out, float *db_out, void *stream);
+
 /* ---- elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, mcnExtraLayers Scale/Axpy ------------
  * dzdy == NULL: forward; otherwise y receives DZDX. */
 int xm_nnrelu(const float *x, size_t n, float leak, const float *dzdy, float *y, void *stream);

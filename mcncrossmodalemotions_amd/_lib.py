@@ -35,6 +35,10 @@ SIGNATURES = {
                                                _vp],
     "xm_nnbnorm_backward_fused": [c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp,
                                                              c_fp, c_fp, _i, _vp],
+    "xm_nnbnorm_relu_pool_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp] + [_i] * 8 +
+                                    [c_fp, c_fp, c_fp, _vp],
+    "xm_nnbnorm_relu_pool_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _i] + [_i] * 8 +
+                                     [c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_nnrelu": [c_fp, _sz, _f, c_fp, c_fp, _vp],
     "xm_nnsigmoid": [c_fp, _sz, c_fp, c_fp, _vp],
     "xm_sum2": [c_fp, c_fp, _sz, _i, c_fp, _vp],

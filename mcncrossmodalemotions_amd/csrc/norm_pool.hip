@@ -360,10 +360,13 @@ static PoolLaunch pool_launch(int rows, int cols, long long planes) {
 // code = dh + ph * dw -- the routing table of the backward pass.
 // PH, PW > 0: compile-time window -> all PH*PW loads are independent (clamped address + validity
 // select) and in flight together; PH == 0: generic runtime window.
+// Optional fused producer (bn_g != NULL): every loaded value first goes through
+// relu(g/sigma * (v - mu) + b) of its channel -- vl_nnbnorm + vl_nnrelu without materialising them.
 template <int PH, int PW>
 __global__ void __launch_bounds__(256)
 pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ amax,
-                PoolGeo g, int planes, int method) {
+                PoolGeo g, int planes, int method, const float *__restrict__ bn_g,
+                const float *__restrict__ bn_b, const float *__restrict__ bn_mom, int C) {
   const int ho = blockIdx.z * blockDim.x + threadIdx.x;
   const int wo = blockIdx.x * blockDim.y + threadIdx.y;
   if (ho >= g.Ho || wo >= g.Wo) return;
@@ -373,6 +376,13 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
   for (int plane = blockIdx.y * blockDim.z + threadIdx.z; plane < planes; plane += gridDim.y * blockDim.z) {
     const float *p = x + (size_t)plane * g.H * g.W;
     const size_t o = (size_t)plane * g.Ho * g.Wo + ho + (size_t)g.Ho * wo;
+    float bsc = 1.f, bmu = 0.f, bbb = 0.f;
+    if (bn_g) {
+      int c = plane % C;
+      bsc = bn_g[c] / bn_mom[C + c];
+      bmu = bn_mom[c];
+      bbb = bn_b[c];
+    }
     float r;
     if (PH > 0) {
       float v[PH * PW > 0 ? PH * PW : 1];
@@ -383,6 +393,7 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
           int h = h0 + dh, w = w0 + dw;
           bool ok = ((unsigned)h < (unsigned)g.H) & ((unsigned)w < (unsigned)g.W);
           float ld = p[ok ? h + g.H * w : 0];
+          if (bn_g) ld = fmaxf(bsc * (ld - bmu) + bbb, 0.f);
           v[dh + PH * dw] = ok ? ld : (method == XM_POOL_MAX ? -INFINITY : 0.f);
         }
       if (method == XM_POOL_MAX) {
@@ -407,6 +418,7 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
       for (int w = w1; w < w2; ++w)
         for (int h = h1; h < h2; ++h) {
           float v = p[h + g.H * w];
+          if (bn_g) v = fmaxf(bsc * (v - bmu) + bbb, 0.f);
           if (v > r) {
             r = v;
             code = (h - h0) + g.ph * (w - w0);
@@ -416,7 +428,11 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
     } else {
       r = 0.f;
       for (int w = w1; w < w2; ++w)
-        for (int h = h1; h < h2; ++h) r += p[h + g.H * w];
+        for (int h = h1; h < h2; ++h) {
+          float v = p[h + g.H * w];
+          if (bn_g) v = fmaxf(bsc * (v - bmu) + bbb, 0.f);
+          r += v;
+        }
       r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
     }
     if (y) y[o] = r;
@@ -542,13 +558,14 @@ static int pool_geo(PoolGeo &g, int H, int W, int C, int N, int ph, int pw, int 
 
 static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,
                         int pt, int pb, int pl, int pr, int method, float *y, unsigned char *amax,
-                        hipStream_t st) {
+                        hipStream_t st, const float *bn_g = nullptr, const float *bn_b = nullptr,
+                        const float *bn_mom = nullptr) {
   PoolGeo g;
   int rc = pool_geo(g, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method);
   if (rc) return rc;
   if (!x || (!y && !amax)) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
   if (amax && ph * pw > 255) return fail(XM_ENOTSUP, "vl_nnpool: windows above 255 elements are not built");
-  if (!amax && g.Ho == 1 && g.Wo == 1 && ph >= H && pw >= W && !(pt | pl)) {
+  if (!amax && !bn_g && g.Ho == 1 && g.Wo == 1 && ph >= H && pw >= W && !(pt | pl)) {
     int planes = C * N;
     hipLaunchKernelGGL(pool_global_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, x, y, H * W,
                        planes, method);
@@ -557,15 +574,132 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
   }
   PoolLaunch pl_ = pool_launch(g.Ho, g.Wo, (long long)C * N);
   if (ph == 3 && pw == 3)
-    hipLaunchKernelGGL((pool_fwd_kernel<3, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+    hipLaunchKernelGGL((pool_fwd_kernel<3, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method, bn_g, bn_b,
+                       bn_mom, C);
   else if (ph == 5 && pw == 3)
-    hipLaunchKernelGGL((pool_fwd_kernel<5, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+    hipLaunchKernelGGL((pool_fwd_kernel<5, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method, bn_g, bn_b,
+                       bn_mom, C);
   else if (ph == 2 && pw == 2)
-    hipLaunchKernelGGL((pool_fwd_kernel<2, 2>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+    hipLaunchKernelGGL((pool_fwd_kernel<2, 2>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method, bn_g, bn_b,
+                       bn_mom, C);
   else
-    hipLaunchKernelGGL((pool_fwd_kernel<0, 0>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method);
+    hipLaunchKernelGGL((pool_fwd_kernel<0, 0>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method, bn_g, bn_b,
+                       bn_mom, C);
   XM_LAUNCH_CHECK();
   return XM_OK;
+}
+
+// ---- fused backward of vl_nnpool('max') o vl_nnrelu o vl_nnbnorm ------------------------------
+// dz(h,w) = [relu(bn(x)) > 0] * sum over covering windows [argmax(window) == (h,w)] dzdy_pool(window)
+// is formed on the fly from the 1-byte routing table; it is never written to HBM.  Threads own a
+// fixed (h, w) and walk the N samples of one channel, so all window arithmetic is done once.
+struct Route4 {
+  int off[4], code[4];
+  bool ok[4];
+};
+__device__ __forceinline__ Route4 make_route(const PoolGeo &g, int h, int w, FastDiv divSy, FastDiv divSx) {
+  int ho_lo = h + g.pt - g.ph + 1;
+  ho_lo = ho_lo <= 0 ? 0 : (int)xm_div((uint32_t)(ho_lo + g.sy - 1), divSy);
+  const int ho_hi = min((int)xm_div((uint32_t)(h + g.pt), divSy), g.Ho - 1);
+  int wo_lo = w + g.pl - g.pw + 1;
+  wo_lo = wo_lo <= 0 ? 0 : (int)xm_div((uint32_t)(wo_lo + g.sx - 1), divSx);
+  const int wo_hi = min((int)xm_div((uint32_t)(w + g.pl), divSx), g.Wo - 1);
+  Route4 r;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int ho = ho_lo + i, wo = wo_lo + j;
+      r.ok[i + 2 * j] = (ho <= ho_hi) & (wo <= wo_hi);
+      int hoc = min(ho, g.Ho - 1), woc = min(wo, g.Wo - 1);
+      r.off[i + 2 * j] = hoc + g.Ho * woc;
+      r.code[i + 2 * j] = (h - (hoc * g.sy - g.pt)) + g.ph * (w - (woc * g.sx - g.pl));
+    }
+  return r;
+}
+__device__ __forceinline__ float routed(const unsigned char *__restrict__ amax,
+                                        const float *__restrict__ dp, size_t ob, const Route4 &r) {
+  float d[4];
+  int a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    d[k] = dp[ob + r.off[k]];
+    a[k] = (int)amax[ob + r.off[k]];
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc += (r.ok[k] & (a[k] == r.code[k])) ? d[k] : 0.f;
+  return acc;
+}
+
+// grid (gx, C, gz*S), block (bx, by): partial (sum dz, sum dz*(x-mu)) per block
+__global__ void __launch_bounds__(256)
+bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ gg,
+                          const float *__restrict__ bb, const float *__restrict__ mom,
+                          const unsigned char *__restrict__ amax, const float *__restrict__ dp,
+                          float *__restrict__ part, PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N,
+                          int S, int gz) {
+  const int c = blockIdx.y;
+  const int zz = blockIdx.z / S, sp = blockIdx.z % S;
+  const int h = zz * blockDim.x + threadIdx.x;
+  const int w = blockIdx.x * blockDim.y + threadIdx.y;
+  float a = 0.f, b = 0.f;
+  if (h < g.H && w < g.W) {
+    const Route4 r = make_route(g, h, w, divSy, divSx);
+    const float mu = mom[c], sc = gg[c] / mom[C + c], bc = bb[c];
+    for (int n = sp; n < N; n += S) {
+      const size_t plane = (size_t)c + (size_t)C * n;
+      float xv = x[plane * g.H * g.W + h + (size_t)g.H * w];
+      float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
+      d = (sc * (xv - mu) + bc > 0.f) ? d : 0.f;
+      a += d;
+      b += d * (xv - mu);
+    }
+  }
+  __shared__ float red[8];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if (tid < 8) red[tid] = 0.f;  // blocks may hold fewer than 4 waves (small planes)
+  __syncthreads();
+  a = xm_wave_sum(a);
+  b = xm_wave_sum(b);
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = a;
+    red[4 + (tid >> 6)] = b;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    size_t nb = (size_t)gridDim.x * gridDim.z;
+    size_t slot = ((size_t)c * nb + (size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2;
+    part[slot] = red[0] + red[1] + red[2] + red[3];
+    part[slot + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+  (void)gz;
+}
+
+__global__ void __launch_bounds__(256)
+bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gg,
+                        const float *__restrict__ bb, const float *__restrict__ mom,
+                        const float *__restrict__ sums, const unsigned char *__restrict__ amax,
+                        const float *__restrict__ dp, float *__restrict__ dx, PoolGeo g, FastDiv divSy,
+                        FastDiv divSx, int C, int N, int S, float m, int train) {
+  const int c = blockIdx.y;
+  const int zz = blockIdx.z / S, sp = blockIdx.z % S;
+  const int h = zz * blockDim.x + threadIdx.x;
+  const int w = blockIdx.x * blockDim.y + threadIdx.y;
+  if (h >= g.H || w >= g.W) return;
+  const Route4 r = make_route(g, h, w, divSy, divSx);
+  const float mu = mom[c], sg = mom[C + c];
+  const float gs = gg[c] / sg, bc = bb[c];
+  const float c1 = train ? sums[c] / m : 0.f;
+  const float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
+  for (int n = sp; n < N; n += S) {
+    const size_t plane = (size_t)c + (size_t)C * n;
+    const size_t xi = plane * g.H * g.W + h + (size_t)g.H * w;
+    float xv = x[xi];
+    float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
+    d = (gs * (xv - mu) + bc > 0.f) ? d : 0.f;
+    dx[xi] = gs * (d - c1 - (xv - mu) * c2);
+  }
 }
 
 static int pool_backward(const float *x, const unsigned char *amax, int H, int W, int C, int N, int ph,
@@ -596,6 +730,72 @@ static int pool_backward(const float *x, const unsigned char *amax, int H, int W
     hipLaunchKernelGGL(pool_bwd_kernel<false>, pl_.grid, pl_.block, 0, st, amax, dzdy, dx_out, g,
                        make_fastdiv((uint32_t)sy), make_fastdiv((uint32_t)sx), C * N, method);
   XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+static int bnrelupool_forward(const float *x, int H, int W, int C, int N, const float *g,
+                              const float *b, float eps, const float *moments_in, int ph, int pw,
+                              int sy, int sx, int pt, int pb, int pl, int pr, float *y_pool,
+                              unsigned char *amax, float *moments_out, hipStream_t st) {
+  int rc = bn_check(H, W, C, N);
+  if (rc) return rc;
+  if (!x || !g || !b || !y_pool || !amax || !moments_out)
+    return fail(XM_EINVAL, "bnorm+relu+pool: NULL tensor");
+  const int HW = H * W;
+  if (!moments_in) {
+    const int S = bn_splits(C, N);
+    WsCarver ws;
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4));
+    if (rc) return rc;
+    float *part = ws.take<float>((size_t)2 * C * S);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    XM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, moments_out,
+                       HW, C, S, (float)((double)HW * N), eps);
+    XM_LAUNCH_CHECK();
+  } else if (moments_out != moments_in) {
+    XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
+  }
+  return pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX, y_pool, amax, st, g, b,
+                      moments_out);
+}
+
+static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const float *g,
+                               const float *b, const float *moments, int train, int ph, int pw, int sy,
+                               int sx, int pt, int pb, int pl, int pr, const unsigned char *amax,
+                               const float *dzdy_pool, float *dx_out, float *dg_out, float *db_out,
+                               hipStream_t st) {
+  PoolGeo pg;
+  int rc = pool_geo(pg, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX);
+  if (rc) return rc;
+  if (!x || !g || !b || !moments || !amax || !dzdy_pool)
+    return fail(XM_EINVAL, "bnorm+relu+pool: NULL tensor");
+  if ((ph + sy - 1) / sy > 2 || (pw + sx - 1) / sx > 2)
+    return fail(XM_ENOTSUP, "bnorm+relu+pool backward: more than 2x2 windows cover an element");
+  // blocks: (bx, by) threads own (h, w); grid.y = channel; the N samples are split S ways
+  int bx = pow2_ge(H, 256), by = 256 / bx;
+  by = pow2_ge(W, by);
+  int gx = (W + by - 1) / by, gz = (H + bx - 1) / bx;
+  int S = std::max(1, std::min(N, 4096 / std::max(1, C * gx * gz)));
+  size_t nb = (size_t)gx * gz * S;
+  WsCarver ws;
+  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4));
+  if (rc) return rc;
+  float *part = ws.take<float>((size_t)2 * C * nb);
+  float *sums = ws.take<float>((size_t)2 * C);
+  dim3 grid(gx, C, gz * S), block(bx, by);
+  FastDiv dsy = make_fastdiv((uint32_t)sy), dsx = make_fastdiv((uint32_t)sx);
+  hipLaunchKernelGGL(bnpool_bwd_partial_kernel, grid, block, 0, st, x, g, b, moments, amax, dzdy_pool,
+                     part, pg, dsy, dsx, C, N, S, gz);
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, moments, sums,
+                     dg_out, db_out, C, (int)nb);
+  XM_LAUNCH_CHECK();
+  if (dx_out) {
+    hipLaunchKernelGGL(bnpool_bwd_apply_kernel, grid, block, 0, st, x, g, b, moments, sums, amax,
+                       dzdy_pool, dx_out, pg, dsy, dsx, C, N, S, (float)((double)H * W * N), train);
+    XM_LAUNCH_CHECK();
+  }
   return XM_OK;
 }
 
@@ -664,5 +864,22 @@ int xm_nnpool_backward_argmax(const unsigned char *argmax, int H, int W, int C, 
   if (!argmax) return fail(XM_EINVAL, "vl_nnpool: argmax table is NULL");
   return pool_backward(nullptr, argmax, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX, dzdy,
                        dx_out, (hipStream_t)stream);
+}
+
+int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *g,
+                                 const float *b, float epsilon, const float *moments_in, int ph, int pw,
+                                 int sy, int sx, int pt, int pb, int pl, int pr, float *y_pool,
+                                 unsigned char *argmax, float *moments_out, void *stream) {
+  return bnrelupool_forward(x, H, W, C, N, g, b, epsilon, moments_in, ph, pw, sy, sx, pt, pb, pl, pr,
+                            y_pool, argmax, moments_out, (hipStream_t)stream);
+}
+
+int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, const float *g,
+                                  const float *b, const float *moments, int train, int ph, int pw,
+                                  int sy, int sx, int pt, int pb, int pl, int pr,
+                                  const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
+                                  float *dg_out, float *db_out, void *stream) {
+  return bnrelupool_backward(x, H, W, C, N, g, b, moments, train, ph, pw, sy, sx, pt, pb, pl, pr, argmax,
+                             dzdy_pool, dx_out, dg_out, db_out, (hipStream_t)stream);
 }
 }

@@ -656,6 +656,55 @@ class _BnReluStep(_Step):
             out.der = None
 
 
+class _BnReluPoolStep(_Step):
+    """BatchNorm -> ReLU -> Pooling('max') as one fused operator pair (train or test mode): the
+    normalised / rectified tensor is never written to HBM (vl.bnorm_relu_pool)."""
+
+    def __init__(self, bn_rec, relu_rec, pool_rec):
+        super().__init__(bn_rec)
+        self.relu_rec, self.pool_rec = relu_rec, pool_rec
+        self._saved = None
+
+    @staticmethod
+    def eligible(pool_block):
+        ph, pw = pool_block.poolSize
+        sy, sx = vl._pair(pool_block.stride, "STRIDE")
+        return pool_block.method == "max" and -(-ph // sy) <= 2 and -(-pw // sx) <= 2 and ph * pw <= 255
+
+    def forward(self, net):
+        r, pb = self.rec, self.pool_rec.block
+        x = net.vars[r.inputs[0]].value
+        g, b, mom = self._params(net)
+        test = net.mode == "test"
+        do = net._direct_der(r) if not test else None
+        y, am, mo = vl.bnorm_relu_pool(x, g, b, pb.poolSize, stride=pb.stride, pad=pb.pad,
+                                       epsilon=r.block.epsilon, moments=mom if test else None,
+                                       moments_out=do[2] if do else None)
+        r.block.moments = None if test else mo
+        self._saved = (am, mo)
+        net.vars[self.pool_rec.outputs[0]].value = y
+
+    def backward(self, net):
+        r, pb = self.rec, self.pool_rec.block
+        out = net.vars[self.pool_rec.outputs[0]]
+        if out.der is None:
+            return
+        am, mo = self._saved
+        self._saved = None
+        x = net.vars[r.inputs[0]].value
+        g, b, mom = self._params(net)
+        test = net.mode == "test"
+        do = net._direct_der(r)
+        dx, dg, db = vl.bnorm_relu_pool_backward(x, g, b, mom if test else mo, am, out.der, pb.poolSize,
+                                                 stride=pb.stride, pad=pb.pad, train=not test,
+                                                 dg_out=do[0] if do else None, db_out=do[1] if do else None)
+        net._set_var_der(r.inputs[0], dx)
+        for p, d in zip(r.params, [dg, db, mo]):
+            net._set_param_der(p, d)
+        if net.conserveMemory and not out.precious:
+            out.der = None
+
+
 class _ConvFoldStep(_Step):
     """test mode only: Conv -> BatchNorm [-> Sum(shortcut)] [-> ReLU] in the conv epilogue.
     scale_k = g_k / sigma_k, shift_k = b_k - mu_k * scale_k  (frozen moments)."""
@@ -744,6 +793,12 @@ def build_plan(net, training):
         if isinstance(r.block, BatchNorm):
             rl = sole_consumer(r.outputs[0], ReLU)
             if rl is not None and rl.block.leak == 0.0:
+                pl = sole_consumer(rl.outputs[0], Pooling)
+                if pl is not None and not isinstance(pl.block, GlobalPooling) and \
+                        _BnReluPoolStep.eligible(pl.block):
+                    steps.append(_BnReluPoolStep(r, rl, pl))
+                    skip.update((id(rl), id(pl)))
+                    continue
                 steps.append(_BnReluStep(r, rl))
                 skip.add(id(rl))
                 continue

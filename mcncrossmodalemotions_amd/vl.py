@@ -266,6 +266,44 @@ def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=Non
     return dxo, dg, db, mo
 
 
+def bnorm_relu_pool(x, g, b, pool, stride=1, pad=0, epsilon=1e-4, moments=None, moments_out=None):
+    """Extension: vl_nnpool(vl_nnrelu(vl_nnbnorm(x, g, b)), pool, 'method', 'max') in one fused pass.
+    Returns (y_pool, argmax_table, moments)."""
+    x, g, b = _chk(x, "X"), _chk(g, "G"), _chk(b, "B")
+    H, W, Cc, N = _shape4(x)
+    ph, pw = _pair(pool, "POOL")
+    sy, sx = _pair(stride, "STRIDE")
+    pt, pb, pl, pr = _pad4(pad)
+    L = _L()
+    Ho, Wo = L.xm_out_size(H, pt, pb, ph, 1, sy), L.xm_out_size(W, pl, pr, pw, 1, sx)
+    y = mat_empty(max(Ho, 0), max(Wo, 0), Cc, N, device=x.device)
+    am = torch.empty(max(Ho, 0) * max(Wo, 0) * Cc * N, dtype=torch.uint8, device=x.device)
+    mo = moments_out if moments_out is not None else mat_empty(Cc, 2, device=x.device)
+    mi = None if moments is None else _chk(moments, "MOMENTS")
+    _lib.check(L.xm_nnbnorm_relu_pool_forward(_ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), float(epsilon),
+                                              _ptr(mi), ph, pw, sy, sx, pt, pb, pl, pr, _ptr(y),
+                                              C.c_void_p(am.data_ptr()), _ptr(mo), _stream()))
+    return y, am, mo
+
+
+def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad=0, train=True,
+                             dg_out=None, db_out=None, need_dx=True):
+    """Backward of bnorm_relu_pool: returns (dx, dg, db)."""
+    x, g, b, dzdy = _chk(x, "X"), _chk(g, "G"), _chk(b, "B"), _chk(dzdy, "DZDY")
+    H, W, Cc, N = _shape4(x)
+    ph, pw = _pair(pool, "POOL")
+    sy, sx = _pair(stride, "STRIDE")
+    pt, pb, pl, pr = _pad4(pad)
+    dx = mat_empty(H, W, Cc, N, device=x.device) if need_dx else None
+    dg = dg_out if dg_out is not None else mat_empty(Cc, 1, device=x.device)
+    db = db_out if db_out is not None else mat_empty(Cc, 1, device=x.device)
+    _lib.check(_L().xm_nnbnorm_relu_pool_backward(
+        _ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), _ptr(_chk(moments, "MOMENTS")), 1 if train else 0, ph, pw,
+        sy, sx, pt, pb, pl, pr, C.c_void_p(argmax.data_ptr()), _ptr(dzdy), _ptr(dx), _ptr(dg), _ptr(db),
+        _stream()))
+    return dx, dg, db
+
+
 # --------------------------------------------------------------------------------------------
 # elementwise
 # --------------------------------------------------------------------------------------------

@@ -184,6 +184,36 @@ def test_bnorm(gpu, shape, relu):
     close(vl.to_numpy(dgt).ravel(), dgt_ref, what="bn test-mode dg")
 
 
+@pytest.mark.parametrize("case", [(13, 11, 5, 3, (3, 3), (2, 2), (0, 0, 0, 0)), (9, 8, 6, 2, (5, 3), (3, 2), (0, 0, 0, 0)),
+                                  (12, 12, 4, 2, (3, 3), (2, 2), (0, 1, 0, 1)), (10, 9, 3, 2, (2, 2), (1, 1), (1, 0, 1, 0))])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_bnorm_relu_pool(gpu, case, train):
+    """extension op == vl_nnpool(vl_nnrelu(vl_nnbnorm(x))) forward and backward (oracle composition)."""
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N, pool, stride, pad = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + int(train))
+    x = O.F(rng.standard_normal((H, W, C, N)) * 1.5 + 0.3)
+    g, b = O.F(rng.uniform(0.5, 1.5, C) * rng.choice([-1, 1], C)), rnd(rng, C)  # negative gains too
+    mom = None if train else O.F(np.stack([rng.standard_normal(C) * 0.3, rng.uniform(0.5, 1.5, C)], 1))
+    yb, mref = O.vl_nnbnorm(x, g, b, moments=mom, acc64=True)
+    yr = np.maximum(yb, 0)
+    yp = O.vl_nnpool(yr, pool, stride=stride, pad=pad, method="max")
+    dz = rnd(rng, *yp.shape)
+    dyr = O.vl_nnpool(yr, pool, dz, stride=stride, pad=pad, method="max")
+    dyb = dyr * (yb > 0)
+    dx_ref, dg_ref, db_ref, _ = O.vl_nnbnorm(x, g, b, dyb, moments=mom, acc64=True)
+    xd, gd, bd = vl.from_numpy(x), vl.from_numpy(g.reshape(C, 1)), vl.from_numpy(b.reshape(C, 1))
+    md = None if mom is None else vl.from_numpy(mom)
+    y, am, mo = vl.bnorm_relu_pool(xd, gd, bd, pool, stride=stride, pad=pad, moments=md)
+    close(vl.to_numpy(y), yp, what="fused fwd")
+    close(vl.to_numpy(mo), mref, what="fused moments")
+    dx, dg, db = vl.bnorm_relu_pool_backward(xd, gd, bd, mo, am, vl.from_numpy(dz), pool, stride=stride,
+                                             pad=pad, train=train)
+    close(vl.to_numpy(dx), dx_ref, what="fused dx")
+    close(vl.to_numpy(dg).ravel(), dg_ref, what="fused dg")
+    close(vl.to_numpy(db).ravel(), db_ref, what="fused db")
+
+
 def test_elementwise(gpu):
     from mcncrossmodalemotions_amd import vl
     rng = np.random.default_rng(5)
