@@ -321,28 +321,49 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     }
     return;
   }
-  // ---- epilogue: bias -> per-channel affine -> residual -> relu -> store ----
+  // ---- epilogue: y = act((acc + bias) * scale + shift + residual) ----
+  // Per-row constants are wave-uniform up to lane>>5 (rows r and r+4 of an MFMA tile), so they are
+  // fetched through the scalar cache (two candidates per output, selected by the lane half) instead
+  // of three vector loads per output element.
+  const int wbase = __builtin_amdgcn_readfirstlane(bm * BM + wm * TM * 32);
+  int obase[TN];
+  bool pok[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     int p = bn * BN + (wn * TN + j) * 32 + l31;
-    if (p >= a.NP) continue;
-    uint32_t n = xm_div((uint32_t)p, a.divPIJ);
-    uint32_t q = (uint32_t)p - n * a.divPIJ.d;
+    pok[j] = p < a.NP;
+    uint32_t pc = pok[j] ? p : a.NP - 1;
+    uint32_t n = xm_div(pc, a.divPIJ);
+    uint32_t q = pc - n * a.divPIJ.d;
     uint32_t jj = xm_div(q, a.divPI);
     uint32_t ii = q - jj * a.divPI.d;
-    int obase = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) +
-                (int)n * a.oSampleStride;
+    obase[j] = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride;
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < a.M) {
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[m];
-          if (a.scale) v = v * a.scale[m] + a.shift[m];
-          uint32_t mc = xm_div((uint32_t)m, a.divMU);
-          int off = obase + (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
+    for (int r = 0; r < 16; ++r) {
+      const int row_lo = wbase + i * 32 + (r & 3) + 8 * (r >> 2);  // wave-uniform
+      const int m = row_lo + 4 * half;
+      const int c_lo = min(row_lo, a.M - 1), c_hi = min(row_lo + 4, a.M - 1);
+      float mul = 1.f, add = 0.f;
+      if (a.scale) {
+        float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
+        float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
+        mul = half ? s_hi : s_lo;
+        add = half ? t_hi : t_lo;
+      }
+      if (a.bias) {
+        float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
+        add += (half ? b_hi : b_lo) * mul;  // (acc + b) * s + t == acc * s + (b * s + t)
+      }
+      uint32_t mc = xm_div((uint32_t)min(m, a.M - 1), a.divMU);
+      const int moff = (int)mc * a.oChanStride + (min(m, a.M - 1) - (int)mc * (int)a.divMU.d) * a.oUStride;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (m < a.M && pok[j]) {
+          int off = obase[j] + moff;
+          float v = acc[i][j][r] * mul + add;
           if (a.resid) v += a.resid[off];
           if (a.relu) v = fmaxf(v, 0.f);
           a.Y[off] = v;
