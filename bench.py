@@ -50,8 +50,10 @@ def parse():
     ap.add_argument("--width", type=int, default=300, help="spectrogram width (3 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--parserv", default="torch", choices=["torch", "rccl-capi"])
+    ap.add_argument("--overlap-teacher", action="store_true",
+                    help="run the frozen teacher on a second HIP stream (measured gain < 1%%: both nets fill the chip)")
     return ap.parse_args()
 
 
@@ -118,6 +120,8 @@ def main():
             lgo = vl.from_numpy((rng.standard_normal((1, 1, 8, nb)) * 3).astype(np.float32), dev)
             lab = vl.max_label(lgo)
 
+    tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher) else None
+
     def step(it):
         if wl == "teacher":
             teacher.eval(["data", faces])
@@ -126,12 +130,28 @@ def main():
             train.train_step(student, ["data", spec, "logitTarget", lgo, "maxLabel", lab], opts, it,
                              parserv, nb * world)
             return
-        if wl == "distill":
+        if wl == "distill" and tstream is None:
             teacher.eval(["data", faces])
             tl = teacher.vars["prediction"].value      # 1 x 1 x 8 x nb teacher logits
             ml = vl.max_label(tl)                       # getBatchEmoVoxCeleb.m:32
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world)
+            return
+        if wl == "distill":
+            # optional: the frozen teacher runs on its own HIP stream and overlaps with the student
+            # layers that do not need its logits yet (only the loss / metric layers consume them)
+            main = torch.cuda.current_stream()
+            tstream.wait_stream(main)
+            with torch.cuda.stream(tstream):
+                teacher.eval(["data", faces])
+                tl = teacher.vars["prediction"].value
+                ml = vl.max_label(tl)
+                ev = torch.cuda.Event()
+                ev.record(tstream)
+            tl.record_stream(main)
+            ml.record_stream(main)
+            train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
+                             parserv, nb * world, input_events={"logitTarget": ev, "maxLabel": ev})
             return
         # joint: teacher fwd+bwd (hard-label CE head, ferPlusZoo.m:240-249) + student distillation
         teacher.vars["prediction"].precious = True

@@ -20,28 +20,32 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-static void *g_ws = nullptr;
-static size_t g_ws_cap = 0;
+struct WsBuf {
+  void *ptr = nullptr;
+  size_t cap = 0;
+};
+static std::map<hipStream_t, WsBuf> g_ws;
 
-int ws_get(size_t bytes, void **ptr) {
-  if (bytes > g_ws_cap) {
+int ws_get(size_t bytes, void **ptr, hipStream_t stream) {
+  WsBuf &w = g_ws[stream];
+  if (bytes > w.cap) {
     // grow geometrically; a grow happens only while shapes are first seen (warm-up)
     size_t want = bytes + bytes / 4 + (1u << 20);
-    if (g_ws) {
+    if (w.ptr) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) return fail(XM_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(e));
-      (void)hipFree(g_ws);
-      g_ws = nullptr;
-      g_ws_cap = 0;
+      (void)hipFree(w.ptr);
+      w.ptr = nullptr;
+      w.cap = 0;
     }
-    hipError_t e = hipMalloc(&g_ws, want);
+    hipError_t e = hipMalloc(&w.ptr, want);
     if (e != hipSuccess) {
-      g_ws = nullptr;
+      w.ptr = nullptr;
       return fail(XM_ENOMEM, "workspace hipMalloc(%zu) -> %s", want, hipGetErrorString(e));
     }
-    g_ws_cap = want;
+    w.cap = want;
   }
-  *ptr = g_ws;
+  *ptr = w.ptr;
   return XM_OK;
 }
 
@@ -70,9 +74,13 @@ const char *xm_last_error(void) { return xm::err_buf(); }
 
 int xm_workspace_reserve(size_t bytes) {
   void *p;
-  return xm::ws_get(bytes, &p);
+  return xm::ws_get(bytes, &p, nullptr);
 }
-size_t xm_workspace_bytes(void) { return xm::g_ws_cap; }
+size_t xm_workspace_bytes(void) {
+  size_t t = 0;
+  for (auto &kv : xm::g_ws) t += kv.second.cap;
+  return t;
+}
 
 int xm_out_size(int in, int pad_a, int pad_b, int f, int dilate, int stride) {
   return xm::out_size(in, pad_a, pad_b, f, dilate, stride);

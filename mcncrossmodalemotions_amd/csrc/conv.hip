@@ -406,7 +406,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     slabf = std::max(slabf, gemm_slab_floats(proto, c, &sp));
   }
   WsCarver ws;
-  int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4));
+  int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4), st);
   if (rc) return rc;
   const int2 *taps = fwd_taps2(g, Rp);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
@@ -553,7 +553,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     }
   }
   WsCarver ws;
-  int rc = ws.init(abytes + WsCarver::need(slab_max, 4));
+  int rc = ws.init(abytes + WsCarver::need(slab_max, 4), st);
   if (rc) return rc;
   float *slab = slab_max ? (float *)(ws.base + abytes) : nullptr;
   const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
@@ -743,7 +743,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   const size_t slab = (size_t)g.Kg * g.R;
   const int max_splits = std::max(1, std::min(256, nkt / 8));
   WsCarver ws;
-  int rc = ws.init(WsCarver::need(slab * max_splits, 4));
+  int rc = ws.init(WsCarver::need(slab * max_splits, 4), st);
   if (rc) return rc;
   float *part = ws.take<float>(slab * max_splits);
   auto run = [&](int ci) { return wgrad_run(x, dzdy, dfo, g, ci, part, st); };
@@ -860,7 +860,7 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
     int S = std::max(1, std::min(N, 2048 / K));
     if ((long long)g.Ho * g.Wo < 1024) S = 1;
     WsCarver ws;
-    rc = ws.init(WsCarver::need((size_t)K * S, 4));
+    rc = ws.init(WsCarver::need((size_t)K * S, 4), st);
     if (rc) return rc;
     float *part = ws.take<float>((size_t)K * S);
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(K, S), dim3(256), 0, st, dzdy, part, g.Ho * g.Wo,

@@ -248,7 +248,7 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
   const float *mom = moments_in;
   WsCarver ws;
   if (!moments_in) {
-    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + WsCarver::need((size_t)2 * C, 4));
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + WsCarver::need((size_t)2 * C, 4), st);
     if (rc) return rc;
     float *part = ws.take<float>((size_t)2 * C * S);
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
@@ -283,7 +283,7 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
   const int HW = H * W;
   const int S = bn_splits(C, N);
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + 2 * WsCarver::need((size_t)2 * C, 4));
+  rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + 2 * WsCarver::need((size_t)2 * C, 4), st);
   if (rc) return rc;
   float *part = ws.take<float>((size_t)2 * C * S);
   float *sums = ws.take<float>((size_t)2 * C);
@@ -714,7 +714,7 @@ static int pool_backward(const float *x, const unsigned char *amax, int H, int W
     if (!x) return fail(XM_EINVAL, "vl_nnpool: X is NULL");
     size_t ny = (size_t)g.Ho * g.Wo * C * N;
     WsCarver ws;
-    rc = ws.init(WsCarver::need(ny, 1));
+    rc = ws.init(WsCarver::need(ny, 1), st);
     if (rc) return rc;
     unsigned char *aw = ws.take<unsigned char>(ny);
     rc = pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, method, nullptr, aw, st);
@@ -745,7 +745,7 @@ static int bnrelupool_forward(const float *x, int H, int W, int C, int N, const 
   if (!moments_in) {
     const int S = bn_splits(C, N);
     WsCarver ws;
-    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4));
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4), st);
     if (rc) return rc;
     float *part = ws.take<float>((size_t)2 * C * S);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
@@ -779,7 +779,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   int S = std::max(1, std::min(N, 4096 / std::max(1, C * gx * gz)));
   size_t nb = (size_t)gx * gz * S;
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4));
+  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4), st);
   if (rc) return rc;
   float *part = ws.take<float>((size_t)2 * C * nb);
   float *sums = ws.take<float>((size_t)2 * C);

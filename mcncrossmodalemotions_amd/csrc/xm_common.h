@@ -30,16 +30,17 @@ int fail(int code, const char *fmt, ...);
   } while (0)
 
 // ---- stream-ordered scratch ----------------------------------------------------------------
-// One growable device buffer.  Every API call carves what it needs from offset 0; calls are
-// stream-ordered on the caller's stream, so reuse across consecutive calls is safe as long as a
-// process drives one stream at a time (MatConvNet's model).  Growing synchronises the device.
-int ws_get(size_t bytes, void **ptr);
+// One growable device buffer PER STREAM.  Every API call carves what it needs from offset 0 of its
+// stream's buffer; calls are stream-ordered, so reuse across consecutive calls on one stream is
+// safe, and calls on different streams (teacher forward overlapping the student step) never share
+// scratch.  Growing synchronises the device (only while shapes are first seen).
+int ws_get(size_t bytes, void **ptr, hipStream_t stream);
 struct WsCarver {
   char *base = nullptr;
   size_t off = 0, cap = 0;
-  int init(size_t bytes) {
+  int init(size_t bytes, hipStream_t stream) {
     void *p = nullptr;
-    int rc = ws_get(bytes, &p);
+    int rc = ws_get(bytes, &p, stream);
     base = (char *)p;
     cap = bytes;
     off = 0;

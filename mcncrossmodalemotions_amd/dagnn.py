@@ -496,11 +496,14 @@ class DagNN:
         return self._flat
 
     # ---- evaluation -----------------------------------------------------------------------
-    def eval(self, inputs, derOutputs=None):
+    def eval(self, inputs, derOutputs=None, input_events=None):
         """net.eval(inputs) / net.eval(inputs, derOutputs).
 
         inputs:     ['name', tensor, ...] (the cell array of getBatch) or a dict
-        derOutputs: ['objective', 1] or a dict; None -> forward only."""
+        derOutputs: ['objective', 1] or a dict; None -> forward only.
+        input_events (extension): {input name: torch.cuda.Event} -- the current stream waits for the
+        event right before the first layer that consumes that input (lets a producer running on
+        another stream, e.g. the frozen teacher, overlap with the layers that do not need it)."""
         if not isinstance(inputs, dict):
             inputs = {inputs[i]: inputs[i + 1] for i in range(0, len(inputs), 2)}
         if derOutputs is not None and not isinstance(derOutputs, dict):
@@ -514,7 +517,16 @@ class DagNN:
                 continue  # MatConvNet ignores unused inputs with a warning
             self.vars[k].value = t
         plan = self._plan(derOutputs is not None)
+        pending = dict(input_events or {})
         for step in plan:
+            if pending:
+                recs = [step.rec] + [getattr(step, n) for n in ("relu_rec", "pool_rec", "bn_rec", "sum_rec")
+                                     if getattr(step, n, None) is not None]
+                for rec in recs:
+                    for v in rec.inputs:
+                        ev = pending.pop(v, None)
+                        if ev is not None:
+                            torch.cuda.current_stream().wait_event(ev)
             step.forward(self)
         if derOutputs is None:
             return

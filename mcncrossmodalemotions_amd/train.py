@@ -91,12 +91,12 @@ def accumulate_gradients(net, opts, lr, global_batch, nworkers=1):
                           opts.weightDecay * wd_mult, global_batch)
 
 
-def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None):
+def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, input_events=None):
     """One minibatch of cnn_train_dag's processEpoch in training mode."""
     if net._flat is None:
         net.pack_params()
     net.mode = "normal"
-    net.eval(inputs, opts.derOutputs)
+    net.eval(inputs, opts.derOutputs, input_events=input_events)
     world = parserv.world if parserv is not None else 1
     if parserv is not None and world > 1:
         parserv.allreduce_(net._flat.der)
