@@ -532,7 +532,13 @@ class DagNN:
             return
         for k, d in derOutputs.items():
             if not isinstance(d, torch.Tensor):
-                d = vl.from_numpy(np.array([[float(d)]], np.float32), self.device)
+                # cached device scalar: a fresh host->device copy here would block the host until the
+                # queued forward pass has drained
+                cache = self.__dict__.setdefault("_der_consts", {})
+                key = (float(d), str(self.device))
+                if key not in cache:
+                    cache[key] = vl.from_numpy(np.array([[float(d)]], np.float32), self.device)
+                d = cache[key]
             self.vars[k].der = d
         if not self.accumulateParamDers and self._flat is None:
             for p in self.params.values():
