@@ -120,7 +120,8 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
  * that normalises, rectifies and pools while recording the argmax table; backward = two passes
  * over X that rebuild the routed, ReLU-masked derivative on the fly.  Results are identical to the
  * three separate operators.  `moments` (backward) is what the forward returned; train != 0 applies
- * the batch-statistics terms of vl_nnbnorm's backward (train mode), 0 treats them as constants. */
+ * the batch-statistics terms of vl_nnbnorm's backward (train mode), 0 treats them as constants.
+ * dxsum_out (optional, C floats): per-channel sum of DX = the DZDB of a vl_nnconv that produced X. */
 int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *g,
                                  const float *b, float epsilon, const float *moments_in, int ph, int pw,
                                  int sy, int sx, int pt, int pb, int pl, int pr, float *y_pool,
@@ -129,7 +130,7 @@ int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, co
                                   const float *b, const float *moments, int train, int ph, int pw,
                                   int sy, int sx, int pt, int pb, int pl, int pr,
                                   const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
-                                  float *dg_out, float *db_out, void *stream);
+                                  float *dg_out, float *db_out, float *dxsum_out, void *stream);
 
 /* ---- elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, mcnExtraLayers Scale/Axpy ------------
  * dzdy == NULL: forward; otherwise y receives DZDX. */

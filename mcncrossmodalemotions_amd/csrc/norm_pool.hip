@@ -676,30 +676,59 @@ bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__
   (void)gz;
 }
 
+// `part2` (optional): per-block partial sums of the produced dx -- the derivative of a bias that was
+// added right before the normalisation (dzdb of the producing vl_nnconv = sum over pixels of its dzdy),
+// so that tensor does not have to be read a second time just to be summed.
 __global__ void __launch_bounds__(256)
 bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gg,
                         const float *__restrict__ bb, const float *__restrict__ mom,
                         const float *__restrict__ sums, const unsigned char *__restrict__ amax,
-                        const float *__restrict__ dp, float *__restrict__ dx, PoolGeo g, FastDiv divSy,
-                        FastDiv divSx, int C, int N, int S, float m, int train) {
+                        const float *__restrict__ dp, float *__restrict__ dx, float *__restrict__ part2,
+                        PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N, int S, float m,
+                        int train) {
   const int c = blockIdx.y;
   const int zz = blockIdx.z / S, sp = blockIdx.z % S;
   const int h = zz * blockDim.x + threadIdx.x;
   const int w = blockIdx.x * blockDim.y + threadIdx.y;
-  if (h >= g.H || w >= g.W) return;
-  const Route4 r = make_route(g, h, w, divSy, divSx);
-  const float mu = mom[c], sg = mom[C + c];
-  const float gs = gg[c] / sg, bc = bb[c];
-  const float c1 = train ? sums[c] / m : 0.f;
-  const float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
-  for (int n = sp; n < N; n += S) {
-    const size_t plane = (size_t)c + (size_t)C * n;
-    const size_t xi = plane * g.H * g.W + h + (size_t)g.H * w;
-    float xv = x[xi];
-    float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
-    d = (gs * (xv - mu) + bc > 0.f) ? d : 0.f;
-    dx[xi] = gs * (d - c1 - (xv - mu) * c2);
+  float acc = 0.f;
+  if (h < g.H && w < g.W) {
+    const Route4 r = make_route(g, h, w, divSy, divSx);
+    const float mu = mom[c], sg = mom[C + c];
+    const float gs = gg[c] / sg, bc = bb[c];
+    const float c1 = train ? sums[c] / m : 0.f;
+    const float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
+    for (int n = sp; n < N; n += S) {
+      const size_t plane = (size_t)c + (size_t)C * n;
+      const size_t xi = plane * g.H * g.W + h + (size_t)g.H * w;
+      float xv = x[xi];
+      float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
+      d = (gs * (xv - mu) + bc > 0.f) ? d : 0.f;
+      float o = gs * (d - c1 - (xv - mu) * c2);
+      dx[xi] = o;
+      acc += o;
+    }
   }
+  if (part2) {
+    __shared__ float red[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 4) red[tid] = 0.f;
+    __syncthreads();
+    acc = xm_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      size_t nb = (size_t)gridDim.x * gridDim.z;
+      part2[(size_t)c * nb + (size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+  }
+}
+
+__global__ void sum_partials_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int S) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < S; ++i) s += part[(size_t)c * S + i];
+  out[c] = s;
 }
 
 static int pool_backward(const float *x, const unsigned char *amax, int H, int W, int C, int N, int ph,
@@ -764,7 +793,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
                                const float *b, const float *moments, int train, int ph, int pw, int sy,
                                int sx, int pt, int pb, int pl, int pr, const unsigned char *amax,
                                const float *dzdy_pool, float *dx_out, float *dg_out, float *db_out,
-                               hipStream_t st) {
+                               float *dxsum_out, hipStream_t st) {
   PoolGeo pg;
   int rc = pool_geo(pg, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX);
   if (rc) return rc;
@@ -779,10 +808,13 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   int S = std::max(1, std::min(N, 4096 / std::max(1, C * gx * gz)));
   size_t nb = (size_t)gx * gz * S;
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4), st);
+  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4) +
+                   WsCarver::need((size_t)C * nb, 4), st);
   if (rc) return rc;
   float *part = ws.take<float>((size_t)2 * C * nb);
   float *sums = ws.take<float>((size_t)2 * C);
+  float *part2 = dxsum_out ? ws.take<float>((size_t)C * nb) : nullptr;
+  if (dxsum_out && !dx_out) return fail(XM_EINVAL, "bnorm+relu+pool backward: dxsum needs dx");
   dim3 grid(gx, C, gz * S), block(bx, by);
   FastDiv dsy = make_fastdiv((uint32_t)sy), dsx = make_fastdiv((uint32_t)sx);
   hipLaunchKernelGGL(bnpool_bwd_partial_kernel, grid, block, 0, st, x, g, b, moments, amax, dzdy_pool,
@@ -793,8 +825,13 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   XM_LAUNCH_CHECK();
   if (dx_out) {
     hipLaunchKernelGGL(bnpool_bwd_apply_kernel, grid, block, 0, st, x, g, b, moments, sums, amax,
-                       dzdy_pool, dx_out, pg, dsy, dsx, C, N, S, (float)((double)H * W * N), train);
+                       dzdy_pool, dx_out, part2, pg, dsy, dsx, C, N, S, (float)((double)H * W * N), train);
     XM_LAUNCH_CHECK();
+    if (part2) {
+      hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dxsum_out, C,
+                         (int)nb);
+      XM_LAUNCH_CHECK();
+    }
   }
   return XM_OK;
 }
@@ -878,8 +915,8 @@ int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, co
                                   const float *b, const float *moments, int train, int ph, int pw,
                                   int sy, int sx, int pt, int pb, int pl, int pr,
                                   const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
-                                  float *dg_out, float *db_out, void *stream) {
+                                  float *dg_out, float *db_out, float *dxsum_out, void *stream) {
   return bnrelupool_backward(x, H, W, C, N, g, b, moments, train, ph, pw, sy, sx, pt, pb, pl, pr, argmax,
-                             dzdy_pool, dx_out, dg_out, db_out, (hipStream_t)stream);
+                             dzdy_pool, dx_out, dg_out, db_out, dxsum_out, (hipStream_t)stream);
 }
 }

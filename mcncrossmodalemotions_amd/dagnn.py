@@ -82,13 +82,13 @@ class Conv(Layer):
         return [vl.vl_nnconv(inputs[0], params[0], b, stride=self.stride, pad=self.pad,
                              dilate=self.dilate)]
 
-    def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None):
+    def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None, skip_db=False):
         b = params[1] if self.hasBias else None
         dfo = der_out[0] if der_out else None
         dbo = der_out[1] if (der_out and self.hasBias) else None
         dx, df, db = vl.vl_nnconv(inputs[0], params[0], b, derOutputs[0], stride=self.stride,
                                   pad=self.pad, dilate=self.dilate, no_der_data=not need_dx,
-                                  df_out=dfo, db_out=dbo)
+                                  no_der_biases=skip_db, df_out=dfo, db_out=dbo)
         return [dx], ([df, db] if self.hasBias else [df])
 
     def initParams(self, rng):
@@ -607,6 +607,7 @@ class _Step:
 
     def __init__(self, rec):
         self.rec = rec
+        self.bias_from = None  # fused consumer step that already produced this conv's bias derivative
 
     def _params(self, net):
         return [net.params[p].value for p in self.rec.params]
@@ -626,8 +627,11 @@ class _Step:
         ins = [net.vars[v].value for v in r.inputs]
         if isinstance(r.block, Conv):
             need_dx = net.vars[r.inputs[0]].fanin > 0  # network inputs need no derivative
+            skip_db = self.bias_from is not None and self.bias_from.bias_conv_done
             dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
-                                          der_out=net._direct_der(r))
+                                          der_out=net._direct_der(r), skip_db=skip_db)
+            if skip_db:
+                dpar = [dpar[0], net.params[r.params[1]].der]
         elif isinstance(r.block, BatchNorm):
             dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r))
         elif isinstance(r.block, Pooling):
@@ -678,10 +682,14 @@ class _BnReluPoolStep(_Step):
     """BatchNorm -> ReLU -> Pooling('max') as one fused operator pair (train or test mode): the
     normalised / rectified tensor is never written to HBM (vl.bnorm_relu_pool)."""
 
-    def __init__(self, bn_rec, relu_rec, pool_rec):
+    def __init__(self, bn_rec, relu_rec, pool_rec, bias_conv=None):
         super().__init__(bn_rec)
         self.relu_rec, self.pool_rec = relu_rec, pool_rec
         self._saved = None
+        self.bias_conv = bias_conv        # _Step of the biased Conv feeding this BN (or None)
+        self.bias_conv_done = False
+        if bias_conv is not None:
+            bias_conv.bias_from = self
 
     @staticmethod
     def eligible(pool_block):
@@ -713,9 +721,17 @@ class _BnReluPoolStep(_Step):
         g, b, mom = self._params(net)
         test = net.mode == "test"
         do = net._direct_der(r)
+        # the producing convolution's bias derivative (= per-channel sum of this dx) comes for free
+        bias_der = None
+        if self.bias_conv is not None and net._flat is not None and not net.accumulateParamDers:
+            bp = net.params[self.bias_conv.rec.params[1]]
+            if bp.fanout == 1 and bp.der is not None:
+                bias_der = bp.der
+        self.bias_conv_done = bias_der is not None
         dx, dg, db = vl.bnorm_relu_pool_backward(x, g, b, mom if test else mo, am, out.der, pb.poolSize,
                                                  stride=pb.stride, pad=pb.pad, train=not test,
-                                                 dg_out=do[0] if do else None, db_out=do[1] if do else None)
+                                                 dg_out=do[0] if do else None, db_out=do[1] if do else None,
+                                                 dxsum_out=bias_der)
         net._set_var_der(r.inputs[0], dx)
         for p, d in zip(r.params, [dg, db, mo]):
             net._set_param_der(p, d)
@@ -814,7 +830,12 @@ def build_plan(net, training):
                 pl = sole_consumer(rl.outputs[0], Pooling)
                 if pl is not None and not isinstance(pl.block, GlobalPooling) and \
                         _BnReluPoolStep.eligible(pl.block):
-                    steps.append(_BnReluPoolStep(r, rl, pl))
+                    bias_conv = None
+                    prod = [q for q in steps if type(q) is _Step and r.inputs[0] in q.rec.outputs]
+                    if training and prod and isinstance(prod[0].rec.block, Conv) and prod[0].rec.block.hasBias \
+                            and len(consumers.get(r.inputs[0], [])) == 1:
+                        bias_conv = prod[0]
+                    steps.append(_BnReluPoolStep(r, rl, pl, bias_conv))
                     skip.update((id(rl), id(pl)))
                     continue
                 steps.append(_BnReluStep(r, rl))

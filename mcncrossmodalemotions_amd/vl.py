@@ -287,8 +287,9 @@ def bnorm_relu_pool(x, g, b, pool, stride=1, pad=0, epsilon=1e-4, moments=None, 
 
 
 def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad=0, train=True,
-                             dg_out=None, db_out=None, need_dx=True):
-    """Backward of bnorm_relu_pool: returns (dx, dg, db)."""
+                             dg_out=None, db_out=None, need_dx=True, dxsum_out=None):
+    """Backward of bnorm_relu_pool: returns (dx, dg, db).  dxsum_out (optional, C x 1): receives
+    sum(dx) per channel = the bias derivative of the convolution that produced x."""
     x, g, b, dzdy = _chk(x, "X"), _chk(g, "G"), _chk(b, "B"), _chk(dzdy, "DZDY")
     H, W, Cc, N = _shape4(x)
     ph, pw = _pair(pool, "POOL")
@@ -300,7 +301,7 @@ def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad
     _lib.check(_L().xm_nnbnorm_relu_pool_backward(
         _ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), _ptr(_chk(moments, "MOMENTS")), 1 if train else 0, ph, pw,
         sy, sx, pt, pb, pl, pr, C.c_void_p(argmax.data_ptr()), _ptr(dzdy), _ptr(dx), _ptr(dg), _ptr(db),
-        _stream()))
+        _ptr(dxsum_out), _stream()))
     return dx, dg, db
 
 

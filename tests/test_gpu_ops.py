@@ -207,9 +207,12 @@ def test_fused_bnorm_relu_pool(gpu, case, train):
     y, am, mo = vl.bnorm_relu_pool(xd, gd, bd, pool, stride=stride, pad=pad, moments=md)
     close(vl.to_numpy(y), yp, what="fused fwd")
     close(vl.to_numpy(mo), mref, what="fused moments")
+    dxs = vl.mat_zeros(C, 1)
     dx, dg, db = vl.bnorm_relu_pool_backward(xd, gd, bd, mo, am, vl.from_numpy(dz), pool, stride=stride,
-                                             pad=pad, train=train)
+                                             pad=pad, train=train, dxsum_out=dxs)
     close(vl.to_numpy(dx), dx_ref, what="fused dx")
+    # dxsum = dzdb of a convolution that produced x (sum of dx over pixels and samples)
+    close(vl.to_numpy(dxs).ravel(), dx_ref.astype(np.float64).sum((0, 1, 3)), 2e-4, what="fused dxsum")
     close(vl.to_numpy(dg).ravel(), dg_ref, what="fused dg")
     close(vl.to_numpy(db).ravel(), db_ref, what="fused db")
 
