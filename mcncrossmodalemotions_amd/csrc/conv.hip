@@ -467,6 +467,9 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.oSampleStride = g.Ho * g.Wo * g.K;
     a.divMU = make_fastdiv(1);
     a.oUStride = 0;
+    // 4 consecutive output pixels are contiguous (same sample) and every tile starts on a multiple
+    // of 32 pixels; 16-byte alignment of (y, residual) rows needs Ho*Wo % 4 == 0
+    a.vecStore = ((g.Ho * g.Wo) % 4 == 0 && (((uintptr_t)a.Y | (uintptr_t)a.resid) & 15) == 0) ? 1 : 0;
     auto run = [&](int ci) {
       int sp;
       gemm_slab_floats(a, ci, &sp);
@@ -631,6 +634,8 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.oSampleStride = g.H * g.W * g.C;
       a.divMU = make_fastdiv(foldH ? (uint32_t)g.FH : 1u);
       a.oUStride = foldH ? 1 : 0;
+      a.vecStore = (!foldH && g.sy == 1 && g.sx == 1 && (c.PI * c.PJ) % 4 == 0 && c.PI == g.H &&
+                    c.PJ == g.W && ((uintptr_t)a.Y & 15) == 0) ? 1 : 0;
       if (foldH) {
         a.gh0 = 0;  // the single dY row; destination row comes from the GEMM row (m % FH)
         a.oh0 = 0;

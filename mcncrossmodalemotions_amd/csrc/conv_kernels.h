@@ -55,6 +55,7 @@ struct ConvGemmArgs {
   // plain channel map; oMU == FH folds the filter rows of an H-collapsing conv (Ho == 1) into M.
   FastDiv divMU;
   int oUStride;
+  int vecStore;       // 1: 4 consecutive pixels are contiguous & 16-B friendly -> dwordx4 epilogue
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
@@ -76,6 +77,26 @@ constexpr int kNG = 4;   // float4 groups per stage (kBK / 4)
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, full-rate VALU): on entry lane i holds
+// v[k] = element (row k, column i); on exit v[k] = element (row i, column k).
+__device__ __forceinline__ float dpp_quad(float x, const int ctrl_is_xor1) {
+  int xi = __builtin_bit_cast(int, x);
+  int r = ctrl_is_xor1 ? __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xF, 0xF, true)   // quad_perm [1,0,3,2]
+                       : __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
+  const bool b0 = iq & 1, b1 = iq & 2;
+  float s0 = b0 ? v[0] : v[1], s1 = b0 ? v[2] : v[3];
+  s0 = dpp_quad(s0, 1);
+  s1 = dpp_quad(s1, 1);
+  if (b0) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+  float t0 = b1 ? v[0] : v[2], t1 = b1 ? v[1] : v[3];
+  t0 = dpp_quad(t0, 0);
+  t1 = dpp_quad(t1, 0);
+  if (b1) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
 }
 
 // sched_group_barrier masks
@@ -164,16 +185,19 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     int pw = (int)j * a.gsx + a.gw0;
     xbase4 = (unsigned)(ph + a.LimH * pw + (int)n * a.xSampleStride) * 4u;
     if (MODE == 1) {
-      int uv = 0;
+      // validity is separable: tap (iu, iv) is outside the image iff its row OR its column is.
+      // nU + nV checks, then the per-column copies of the row mask are OR-ed into a 64-bit mask.
+      unsigned rowinv = 0;
+      for (int iu = 0; iu < a.nU; ++iu)
+        rowinv |= ((unsigned)(ph + a.du0 + iu * a.dus) < (unsigned)a.LimH ? 0u : 1u) << iu;
+      const unsigned rowall = a.nU >= 32 ? 0xFFFFFFFFu : ((1u << a.nU) - 1u);
+      unsigned long long inv = 0;
       for (int iv = 0; iv < a.nV; ++iv) {
         bool okw = (unsigned)(pw + a.dv0 + iv * a.dvs) < (unsigned)a.LimW;
-        for (int iu = 0; iu < a.nU; ++iu, ++uv) {
-          bool ok = okw & ((unsigned)(ph + a.du0 + iu * a.dus) < (unsigned)a.LimH);
-          unsigned bit = ok ? 0u : 1u;
-          if (uv < 32) inv_lo |= bit << uv;
-          else inv_hi |= bit << (uv - 32);
-        }
+        inv |= (unsigned long long)(okw ? rowinv : rowall) << (iv * a.nU);
       }
+      inv_lo |= (unsigned)inv;
+      inv_hi |= (unsigned)(inv >> 32);
     }
   }
   const __amdgpu_buffer_rsrc_t xrsrc =
@@ -350,6 +374,70 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     uint32_t jj = xm_div(q, a.divPI);
     uint32_t ii = q - jj * a.divPI.d;
     obase[j] = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride;
+  }
+  if (a.vecStore) {
+    // Wide path (dword stores are issue-bound at ~2.5 TB/s on this chip): each group of 4
+    // accumulator registers holds 4 consecutive channel rows of one pixel; a 4x4 transpose inside
+    // the lane quad turns that into 4 consecutive pixels of one row -> one 16-byte store per lane.
+    const int iq = l31 & 3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rb_lo = wbase + i * 32 + 8 * g4;  // wave-uniform; this lane half adds 4
+        float mul[4], add[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c_lo = min(rb_lo + k, a.M - 1), c_hi = min(rb_lo + k + 4, a.M - 1);
+          mul[k] = 1.f;
+          add[k] = 0.f;
+          if (a.scale) {
+            float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
+            float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
+            mul[k] = half ? s_hi : s_lo;
+            add[k] = half ? t_hi : t_lo;
+          }
+          if (a.bias) {
+            float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
+            add[k] += (half ? b_hi : b_lo) * mul[k];
+          }
+        }
+        const int row = rb_lo + 4 * half + iq;  // the row this lane stores after the transpose
+        const int rowc = min(row, a.M - 1);
+        uint32_t mc = xm_div((uint32_t)rowc, a.divMU);
+        const int moff = (int)mc * a.oChanStride + (rowc - (int)mc * (int)a.divMU.d) * a.oUStride;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k] * mul[k] + add[k];
+          quad_transpose4(v, iq);
+          if (row < a.M && pok[j]) {
+            const int off = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (a.resid) {
+              const float *rp = a.resid + off;
+              o.x += rp[0];
+              o.y += rp[1];
+              o.z += rp[2];
+              o.w += rp[3];
+            }
+            if (a.relu) {
+              o.x = fmaxf(o.x, 0.f);
+              o.y = fmaxf(o.y, 0.f);
+              o.z = fmaxf(o.z, 0.f);
+              o.w = fmaxf(o.w, 0.f);
+            }
+            float *yp = a.Y + off;
+            yp[0] = o.x;
+            yp[1] = o.y;
+            yp[2] = o.z;
+            yp[3] = o.w;
+          }
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
