@@ -659,7 +659,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   return XM_OK;
 }
 
-// one wgrad launch (+ split reduction) with tile configuration ci; `part` has room for 256 slabs
+// one wgrad launch (+ split reduction) with tile configuration ci; `part` has room for 1024 slabs
 static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g, int ci, float *part,
                      hipStream_t st) {
   const Cfg &c = kCfgs[ci];
@@ -670,9 +670,9 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
   // split the pixel reduction so that the grid fills one round of the chip (no tail round);
   // smaller tiles co-reside more blocks per CU
   const int tiles = nbm * nbn;
-  const int slots = 256 * (c.bm() * c.bn() >= 128 * 128 ? 2 : (c.bm() * c.bn() >= 64 * 128 ? 3 : 4));
+  const int slots = 256 * (c.bm() * c.bn() >= 128 * 128 ? 2 : (c.bm() * c.bn() >= 64 * 128 ? 3 : 6));
   int splits = std::max(1, std::min(nkt / 8, slots / tiles));
-  splits = std::min(splits, 256);
+  splits = std::min(splits, 1024);
   int tps = (nkt + splits - 1) / splits;
   splits = (nkt + tps - 1) / tps;
   const int4 *taps = fwd_taps(g, Rn);
@@ -746,7 +746,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   const int NP = g.Ho * g.Wo * g.N;
   const int nkt = (NP + kBK - 1) / kBK;
   const size_t slab = (size_t)g.Kg * g.R;
-  const int max_splits = std::max(1, std::min(256, nkt / 8));
+  const int max_splits = std::max(1, std::min(1024, nkt / 8));
   WsCarver ws;
   int rc = ws.init(WsCarver::need(slab * max_splits, 4), st);
   if (rc) return rc;

@@ -572,9 +572,11 @@ conv_wgrad_kernel(const WgradArgs a) {
   const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
   const float *sBr = sB + half * PLB + (wn * TN * 32 + l31) * 4;
 
-  float ra[NEA], rb[NEB];
+  // two register sets, loads issued two stages ahead (see conv_gemm_kernel): the small-tile /
+  // huge-reduction layers (conv1: 1.2 M pixels into a 96 x 49 filter gradient) are latency-bound
+  float ra0[NEA], rb0[NEB], ra1[NEA], rb1[NEB];
 
-#define XM_WLOAD_TILE(KT)                                                      \
+#define XM_WLOAD_TILE(KT, RA, RB)                                              \
   {                                                                            \
     uint32_t p_ = (uint32_t)((KT) * kBK + px);                                 \
     uint32_t n_ = xm_div(p_, a.divHW);                                         \
@@ -586,27 +588,32 @@ conv_wgrad_kernel(const WgradArgs a) {
     const int hb_ = (int)ho_ * a.sy - a.pt, wb_ = (int)wo_ * a.sx - a.pl_;     \
     const unsigned xo_ = (unsigned)(hb_ + a.H * wb_ + (int)n_ * a.xSampleStride) * 4u; \
     _Pragma("unroll") for (int j = 0; j < NEA; ++j)                            \
-      ra[j] = buf_load(dyrsrc, (arow4[j] + dyo_) | pm_);                       \
+      RA[j] = buf_load(dyrsrc, (arow4[j] + dyo_) | pm_);                       \
     _Pragma("unroll") for (int j = 0; j < NEB; ++j) {                          \
       bool ok_ = ((unsigned)(hb_ + tpy[j]) < (unsigned)a.H) &                  \
                  ((unsigned)(wb_ + tpz[j]) < (unsigned)a.W);                   \
       unsigned o_ = (xo_ + (unsigned)tpo[j]) | pm_;                            \
-      rb[j] = buf_load(xrsrc, ok_ ? o_ : 0xFFFFFFFFu);                         \
+      RB[j] = buf_load(xrsrc, ok_ ? o_ : 0xFFFFFFFFu);                         \
     }                                                                          \
   }
 
-#define XM_WSTORE_TILE(BUF)                                                    \
+#define XM_WSTORE_TILE(BUF, RA, RB)                                            \
   _Pragma("unroll") for (int j = 0; j < NEA; ++j)                              \
-    sAw[(BUF) * kNG * PLA + j * 64] = ra[j];                                   \
+    sAw[(BUF) * kNG * PLA + j * 64] = RA[j];                                   \
   _Pragma("unroll") for (int j = 0; j < NEB; ++j)                              \
-    sBw[(BUF) * kNG * PLB + j * 64] = rb[j];
+    sBw[(BUF) * kNG * PLB + j * 64] = RB[j];
 
-#define XM_WSTAGE(KT, CUR)                                                     \
-  XM_WLOAD_TILE((KT) + 1)                                                      \
+#define XM_WSTAGE_LD(KT, CUR, LA, LB, SA, SB)                                  \
+  XM_WLOAD_TILE((KT) + 2, LA, LB)                                              \
   XM_COMPUTE(CUR)                                                              \
   XM_INTERLEAVE(4)                                                             \
   __builtin_amdgcn_sched_barrier(0);                                           \
-  XM_WSTORE_TILE((CUR) ^ 1)                                                    \
+  XM_WSTORE_TILE((CUR) ^ 1, SA, SB)                                            \
+  __syncthreads();
+#define XM_WSTAGE_NL(CUR, SA, SB)                                              \
+  XM_COMPUTE(CUR)                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  XM_WSTORE_TILE((CUR) ^ 1, SA, SB)                                            \
   __syncthreads();
 
   f32x16 acc[TM][TN], accx;
@@ -620,16 +627,24 @@ conv_wgrad_kernel(const WgradArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kt0 < kt1) {
-    XM_WLOAD_TILE(kt0)
-    XM_WSTORE_TILE(0)
+    XM_WLOAD_TILE(kt0, ra0, rb0)
+    if (kt0 + 1 < kt1) {
+      XM_WLOAD_TILE(kt0 + 1, ra1, rb1)
+    }
+    XM_WSTORE_TILE(0, ra0, rb0)
     __syncthreads();
     int kt = kt0;
-    for (; kt + 2 < kt1; kt += 2) {
-      XM_WSTAGE(kt, 0)
-      XM_WSTAGE(kt + 1, 1)
+    for (; kt + 3 < kt1; kt += 2) {
+      XM_WSTAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
+      XM_WSTAGE_LD(kt + 1, 1, ra1, rb1, ra0, rb0)
     }
-    if (kt + 2 == kt1) {
-      XM_WSTAGE(kt, 0)
+    const int rem = kt1 - kt;
+    if (rem == 3) {
+      XM_WSTAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
+      XM_WSTAGE_NL(1, ra0, rb0)
+      XM_COMPUTE(0)
+    } else if (rem == 2) {
+      XM_WSTAGE_NL(0, ra1, rb1)
       XM_COMPUTE(1)
     } else {
       XM_COMPUTE(0)
@@ -637,7 +652,8 @@ conv_wgrad_kernel(const WgradArgs a) {
   }
 #undef XM_WLOAD_TILE
 #undef XM_WSTORE_TILE
-#undef XM_WSTAGE
+#undef XM_WSTAGE_LD
+#undef XM_WSTAGE_NL
 
   if (TM * TN == 1) acc[0][0] += accx;
   float *out = a.out + (size_t)split * a.splitStride;
