@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--parserv", default="torch", choices=["torch", "rccl-capi"])
+    ap.add_argument("--teacher", default="resnet50", choices=["resnet50", "senet50"],
+                    help="frozen teacher of the distill workload (BASELINE config 4 names resnet50)")
     ap.add_argument("--overlap-teacher", action="store_true",
                     help="run the frozen teacher on a second HIP stream (measured gain < 1%%: both nets fill the chip)")
     return ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     # ---- networks ------------------------------------------------------------------------
     teacher = student = None
     if wl in ("distill", "teacher", "joint"):
-        tname = "resnet50-ferplus" if wl == "distill" else "senet50-ferplus"
+        tname = ("%s-ferplus" % args.teacher) if wl == "distill" else "senet50-ferplus"
         teacher = zoo.ferPlusZoo(tname, seed=100 if wl == "distill" else 300)
         if wl == "joint":
             teacher.removeLayer("top1error")
@@ -225,7 +227,7 @@ def main():
         cpu = cpu_baseline(wl, args.cpu_pairs, W)
 
     if wl == "distill":
-        gflop_unit = GFLOP["resnet50_fwd"] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
+        gflop_unit = GFLOP["%s_fwd" % args.teacher] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
     elif wl == "student":
         gflop_unit = GFLOP["student_fwd_bwd_300"]
     elif wl == "teacher":
@@ -241,7 +243,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"distill": "run_distillation step: frozen resnet50-ferplus teacher fwd -> "
+            "config": {"workload": {"distill": "run_distillation step: frozen %s-ferplus teacher fwd -> " % args.teacher +
                                                "VGGVox student fwd+bwd, soft-target CE T=2, SGD (BASELINE config 4 shard)",
                                     "student": "VGGVox student fwd+bwd+update (BASELINE config 2)",
                                     "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",

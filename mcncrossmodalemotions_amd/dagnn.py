@@ -678,6 +678,34 @@ class _BnReluStep(_Step):
             out.der = None
 
 
+class _AddReluStep(_Step):
+    """dagnn.Sum / dagnn.Axpy followed by ReLU: the rectification rides in the producing kernel
+    (y = relu(a + b) or relu(s .* x + r)); backward masks dzdy by (y > 0) first."""
+
+    def __init__(self, rec, relu_rec):
+        super().__init__(rec)
+        self.relu_rec = relu_rec
+
+    def forward(self, net):
+        r = self.rec
+        ins = [net.vars[v].value for v in r.inputs]
+        y = r.block.forward(ins, [], relu=True)[0]
+        net.vars[self.relu_rec.outputs[0]].value = y
+
+    def backward(self, net):
+        r = self.rec
+        out = net.vars[self.relu_rec.outputs[0]]
+        if out.der is None:
+            return
+        dz = vl.vl_nnrelu(out.value, out.der)  # y = relu(.) > 0  <=>  pre-activation > 0
+        ins = [net.vars[v].value for v in r.inputs]
+        dins, _ = r.block.backward(ins, [], [dz])
+        for v, d in zip(r.inputs, dins):
+            net._set_var_der(v, d)
+        if net.conserveMemory and not out.precious:
+            out.der = None
+
+
 class _BnReluPoolStep(_Step):
     """BatchNorm -> ReLU -> Pooling('max') as one fused operator pair (train or test mode): the
     normalised / rectified tensor is never written to HBM (vl.bnorm_relu_pool)."""
@@ -823,6 +851,12 @@ def build_plan(net, training):
                     rl = None
                 steps.append(_ConvFoldStep(r, bn, sm, rl, out))
                 skip.update(id(q) for q in (bn, sm, rl) if q is not None)
+                continue
+        if isinstance(r.block, (Sum, Axpy)) and (not isinstance(r.block, Sum) or len(r.inputs) == 2):
+            rl = sole_consumer(r.outputs[0], ReLU)
+            if rl is not None and rl.block.leak == 0.0:
+                steps.append(_AddReluStep(r, rl))
+                skip.add(id(rl))
                 continue
         if isinstance(r.block, BatchNorm):
             rl = sole_consumer(r.outputs[0], ReLU)
