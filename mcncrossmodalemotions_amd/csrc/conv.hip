@@ -65,15 +65,55 @@ prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int
   }
 }
 
-__global__ void reduce_splits_kernel(const float *__restrict__ part, float *__restrict__ out,
-                                     int M, int R, int ldo, int splits, size_t splitStride) {
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * R) return;
-  int r = (int)(i % R);
-  size_t m = i / R;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[z * splitStride + m * ldo + r];
-  out[i] = s;
+// out[i] = sum_z part[z][i] in a FIXED order (deterministic): ZL "z-lanes" per output each sum a
+// strided subset of the splits with four independent accumulators (loads in flight instead of one
+// dependent chain), then the lanes are combined through LDS in lane order.
+template <int ZL>
+__global__ void __launch_bounds__(256)
+reduce_splits_kernel(const float *__restrict__ part, float *__restrict__ out, size_t total, int splits,
+                     size_t splitStride) {
+  constexpr int OPB = 256 / ZL;
+  const int ol = threadIdx.x % OPB, zl = threadIdx.x / OPB;
+  const size_t i = blockIdx.x * (size_t)OPB + ol;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < total) {
+    const float *p = part + i;
+    int z = zl;
+    for (; z + 3 * ZL < splits; z += 4 * ZL) {
+      s0 += p[(size_t)z * splitStride];
+      s1 += p[(size_t)(z + ZL) * splitStride];
+      s2 += p[(size_t)(z + 2 * ZL) * splitStride];
+      s3 += p[(size_t)(z + 3 * ZL) * splitStride];
+    }
+    for (; z < splits; z += ZL) s0 += p[(size_t)z * splitStride];
+  }
+  float s = (s0 + s1) + (s2 + s3);
+  if (ZL == 1) {
+    if (i < total) out[i] = s;
+    return;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (zl == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < ZL; ++k) t += red[k * OPB + ol];
+    out[i] = t;
+  }
+}
+
+static void launch_reduce_splits(const float *part, float *out, size_t total, int splits,
+                                 size_t splitStride, hipStream_t st) {
+  if (splits >= 64)
+    hipLaunchKernelGGL(reduce_splits_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st,
+                       part, out, total, splits, splitStride);
+  else if (splits >= 8)
+    hipLaunchKernelGGL(reduce_splits_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
+                       part, out, total, splits, splitStride);
+  else
+    hipLaunchKernelGGL(reduce_splits_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       part, out, total, splits, splitStride);
 }
 
 // dzdb(k) = sum over pixels and samples of dzdy(:,:,k,:): grid (K, S) partial sums, then a
@@ -719,8 +759,7 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
     }
     XM_LAUNCH_CHECK();
     if (splits > 1) {
-      hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st,
-                         part, dst, g.Kg, g.R, g.R, splits, slab);
+      launch_reduce_splits(part, dst, slab, splits, slab, st);
       XM_LAUNCH_CHECK();
     }
   }
