@@ -110,41 +110,38 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
 // lane four consecutive k of its row.  MFMA 32x32x2 takes k from lane>>5, so lanes 0-31 read
 // group 2s and lanes 32-63 group 2s+1; the e-th MFMA of a chunk then sums k = 8s+e and 8s+4+e
 // -- A and B use the same assignment, so the dot product is complete and exact.
-#define XM_MFMA_E(E)                                                           \
+#define XM_MFMA_E(E, AF, BF)                                                   \
   _Pragma("unroll") for (int i = 0; i < TM; ++i)                               \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                           \
       if (TM * TN == 1 && ((E) & 1))                                           \
-        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][E], bf[j][E], accx, 0, 0, 0); \
+        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[i][E], BF[j][E], accx, 0, 0, 0); \
       else                                                                     \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][E], bf[j][E], acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[i][E], BF[j][E], acc[i][j], 0, 0, 0); \
     }
 // Consecutive MFMAs always target DIFFERENT accumulators (k outer, tile inner): an instruction
 // issued between two MFMAs on the same accumulator costs ~43 extra cycles on gfx950
 // (MI355X_MICROARCH.md), and the interleaved staging code sits exactly there.  A 1x1 wave tile
 // splits its chain over two accumulators (odd / even k), added once at the end.
-#define XM_COMPUTE(CUR)                                                        \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                           \
-    f32x4 af[TM], bf[TN];                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
-      af[i] = *reinterpret_cast<const f32x4 *>(sAr + ((CUR) * kNG + 2 * s_) * PLA + i * 128); \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                             \
-      bf[j] = *reinterpret_cast<const f32x4 *>(sBr + ((CUR) * kNG + 2 * s_) * PLB + j * 128); \
-    XM_MFMA_E(0)                                                               \
-    XM_MFMA_E(1)                                                               \
-    XM_MFMA_E(2)                                                               \
-    XM_MFMA_E(3)                                                               \
-  }
+#define XM_MFMA_CHUNK(AF, BF)                                                  \
+  XM_MFMA_E(0, AF, BF)                                                         \
+  XM_MFMA_E(1, AF, BF)                                                         \
+  XM_MFMA_E(2, AF, BF)                                                         \
+  XM_MFMA_E(3, AF, BF)
+// fragments of 8-k chunk S (0 / 1) of LDS buffer CUR
+#define XM_READ_FRAGS(CUR, S, AF, BF)                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                               \
+    AF[i] = *reinterpret_cast<const f32x4 *>(sAr + ((CUR) * kNG + 2 * (S)) * PLA + i * 128); \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                               \
+    BF[j] = *reinterpret_cast<const f32x4 *>(sBr + ((CUR) * kNG + 2 * (S)) * PLB + j * 128);
 
-// interleave recipe for one stage: per 8-k chunk, the fragment reads, then each MFMA followed by a
-// few VALU and one buffer load of the next stage
+// interleave recipe for one 8-k chunk: the fragment reads of the NEXT chunk first (they have the
+// whole chunk of MFMAs to land), then each MFMA followed by a few VALU and one buffer load
 #define XM_INTERLEAVE(NVALU)                                                   \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                           \
-    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, TM + TN, 0);            \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {               \
-      __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                 \
-      __builtin_amdgcn_sched_group_barrier(XM_SGB_VALU, NVALU, 0);             \
-      __builtin_amdgcn_sched_group_barrier(XM_SGB_VMEM_RD, 1, 0);              \
-    }                                                                          \
+  __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, TM + TN, 0);              \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_VALU, NVALU, 0);              \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_VMEM_RD, 1, 0);                \
   }
 
 // MODE 0: every tap is inside the image (pad == 0, Rp == R);  MODE 1: (u,v) validity mask.
@@ -277,23 +274,45 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
       *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = RB[i];
 
-  // one pipeline stage on LDS buffer CUR: issue stage KT+2's loads into (LA, LB), compute stage KT,
-  // then park stage KT+1 (already in flight in (SA, SB) since the previous stage) in LDS[CUR^1]
+  // One pipeline stage on LDS buffer CUR.  The MFMA operands are double-buffered in REGISTERS: the
+  // fragments of a chunk are read from LDS while the previous chunk's MFMAs run, so no MFMA ever
+  // waits on an LDS round trip.  To make that work across stages with two LDS buffers, the
+  // store-to-LDS + barrier sit in the MIDDLE of the stage:
+  //   issue stage KT+2's global loads into (LA, LB)
+  //   read chunk 1 of CUR -> (af1, bf1)        | MFMAs of chunk 0 from (af0, bf0)
+  //   park stage KT+1 (in flight in (SA, SB) since the previous stage) in LDS[CUR^1]; barrier
+  //   read chunk 0 of CUR^1 -> (af0, bf0)      | MFMAs of chunk 1 from (af1, bf1)
+  // LDS[CUR^1] was last read (its chunk 1) at the start of the previous stage, i.e. before the
+  // previous mid-stage barrier, so overwriting it here is safe.
 #define XM_STAGE_LD(KT, CUR, LA, LB, SA, SB)                                   \
   XM_LOAD_TILE((KT) + 2, LA, LB)                                               \
   XM_FETCH_TAPS((KT) + 3)                                                      \
-  XM_COMPUTE(CUR)                                                              \
-  XM_INTERLEAVE(MODE == 1 ? 3 : 2)                                             \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
+  XM_INTERLEAVE(MODE == 1 ? 6 : 4)                                             \
   __builtin_amdgcn_sched_barrier(0);                                           \
   XM_STORE_TILE((CUR) ^ 1, SA, SB)                                             \
-  __syncthreads();
-  // same without issuing new loads (the last two stages of the reduction)
+  __syncthreads();                                                             \
+  XM_READ_FRAGS((CUR) ^ 1, 0, af0, bf0)                                        \
+  XM_MFMA_CHUNK(af1, bf1)                                                      \
+  XM_INTERLEAVE(MODE == 1 ? 6 : 4)                                             \
+  __builtin_amdgcn_sched_barrier(0);
+  // same without issuing new loads (the last stages of the reduction)
 #define XM_STAGE_NL(CUR, SA, SB)                                               \
-  XM_COMPUTE(CUR)                                                              \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
   __builtin_amdgcn_sched_barrier(0);                                           \
   XM_STORE_TILE((CUR) ^ 1, SA, SB)                                             \
-  __syncthreads();
+  __syncthreads();                                                             \
+  XM_READ_FRAGS((CUR) ^ 1, 0, af0, bf0)                                        \
+  XM_MFMA_CHUNK(af1, bf1)                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+#define XM_STAGE_LAST(CUR)                                                     \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
+  XM_MFMA_CHUNK(af1, bf1)
 
+  f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
   f32x16 acc[TM][TN], accx;
 #pragma unroll
   for (int r = 0; r < 16; ++r) accx[r] = 0.f;
@@ -315,6 +334,7 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     }
     XM_STORE_TILE(0, ra0, rb0)
     __syncthreads();
+    XM_READ_FRAGS(0, 0, af0, bf0)
     int kt = kt0;
     for (; kt + 3 < kt1; kt += 2) {
       XM_STAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
@@ -324,12 +344,12 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     if (rem == 3) {
       XM_STAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
       XM_STAGE_NL(1, ra0, rb0)
-      XM_COMPUTE(0)
+      XM_STAGE_LAST(0)
     } else if (rem == 2) {
       XM_STAGE_NL(0, ra1, rb1)
-      XM_COMPUTE(1)
+      XM_STAGE_LAST(1)
     } else {
-      XM_COMPUTE(0)
+      XM_STAGE_LAST(0)
     }
   }
 #undef XM_FETCH_TAPS
@@ -337,6 +357,7 @@ conv_gemm_kernel(const ConvGemmArgs a) {
 #undef XM_STORE_TILE
 #undef XM_STAGE_LD
 #undef XM_STAGE_NL
+#undef XM_STAGE_LAST
 
   if (TM * TN == 1) acc[0][0] += accx;
   // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -603,19 +624,34 @@ conv_wgrad_kernel(const WgradArgs a) {
   _Pragma("unroll") for (int j = 0; j < NEB; ++j)                              \
     sBw[(BUF) * kNG * PLB + j * 64] = RB[j];
 
+  // same mid-stage store + barrier pipeline as conv_gemm_kernel (register double-buffered fragments)
 #define XM_WSTAGE_LD(KT, CUR, LA, LB, SA, SB)                                  \
   XM_WLOAD_TILE((KT) + 2, LA, LB)                                              \
-  XM_COMPUTE(CUR)                                                              \
-  XM_INTERLEAVE(4)                                                             \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
+  XM_INTERLEAVE(8)                                                             \
   __builtin_amdgcn_sched_barrier(0);                                           \
   XM_WSTORE_TILE((CUR) ^ 1, SA, SB)                                            \
-  __syncthreads();
+  __syncthreads();                                                             \
+  XM_READ_FRAGS((CUR) ^ 1, 0, af0, bf0)                                        \
+  XM_MFMA_CHUNK(af1, bf1)                                                      \
+  XM_INTERLEAVE(8)                                                             \
+  __builtin_amdgcn_sched_barrier(0);
 #define XM_WSTAGE_NL(CUR, SA, SB)                                              \
-  XM_COMPUTE(CUR)                                                              \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
   __builtin_amdgcn_sched_barrier(0);                                           \
   XM_WSTORE_TILE((CUR) ^ 1, SA, SB)                                            \
-  __syncthreads();
+  __syncthreads();                                                             \
+  XM_READ_FRAGS((CUR) ^ 1, 0, af0, bf0)                                        \
+  XM_MFMA_CHUNK(af1, bf1)                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+#define XM_WSTAGE_LAST(CUR)                                                    \
+  XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
+  XM_MFMA_CHUNK(af0, bf0)                                                      \
+  XM_MFMA_CHUNK(af1, bf1)
 
+  f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
   f32x16 acc[TM][TN], accx;
 #pragma unroll
   for (int r = 0; r < 16; ++r) accx[r] = 0.f;
@@ -633,6 +669,7 @@ conv_wgrad_kernel(const WgradArgs a) {
     }
     XM_WSTORE_TILE(0, ra0, rb0)
     __syncthreads();
+    XM_READ_FRAGS(0, 0, af0, bf0)
     int kt = kt0;
     for (; kt + 3 < kt1; kt += 2) {
       XM_WSTAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
@@ -642,18 +679,19 @@ conv_wgrad_kernel(const WgradArgs a) {
     if (rem == 3) {
       XM_WSTAGE_LD(kt, 0, ra0, rb0, ra1, rb1)
       XM_WSTAGE_NL(1, ra0, rb0)
-      XM_COMPUTE(0)
+      XM_WSTAGE_LAST(0)
     } else if (rem == 2) {
       XM_WSTAGE_NL(0, ra1, rb1)
-      XM_COMPUTE(1)
+      XM_WSTAGE_LAST(1)
     } else {
-      XM_COMPUTE(0)
+      XM_WSTAGE_LAST(0)
     }
   }
 #undef XM_WLOAD_TILE
 #undef XM_WSTORE_TILE
 #undef XM_WSTAGE_LD
 #undef XM_WSTAGE_NL
+#undef XM_WSTAGE_LAST
 
   if (TM * TN == 1) acc[0][0] += accx;
   float *out = a.out + (size_t)split * a.splitStride;
@@ -671,7 +709,8 @@ conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
-#undef XM_COMPUTE
+#undef XM_READ_FRAGS
+#undef XM_MFMA_CHUNK
 #undef XM_MFMA_E
 #undef XM_INTERLEAVE
 
