@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--parserv", default="torch", choices=["torch", "rccl-capi"])
     ap.add_argument("--teacher", default="resnet50", choices=["resnet50", "senet50"],
                     help="frozen teacher of the distill workload (BASELINE config 4 names resnet50)")
+    ap.add_argument("--teacher-lanes", type=int, default=2,
+                    help="teacher workload: sample slices evaluated concurrently on that many HIP streams")
     ap.add_argument("--overlap-teacher", action="store_true",
                     help="run the frozen teacher on a second HIP stream (measured gain < 1%%: both nets fill the chip)")
     return ap.parse_args()
@@ -123,10 +125,11 @@ def main():
             lab = vl.max_label(lgo)
 
     tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher) else None
+    frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if wl == "teacher" else None
 
     def step(it):
         if wl == "teacher":
-            teacher.eval(["data", faces])
+            frozen.logits(faces)   # fetch_emovoxceleb_imdb.m:129-130
             return
         if wl == "student":
             train.train_step(student, ["data", spec, "logitTarget", lgo, "maxLabel", lab], opts, it,

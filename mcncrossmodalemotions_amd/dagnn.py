@@ -414,6 +414,22 @@ class DagNN:
             if p not in used:
                 del self.params[p]
 
+    def replica(self):
+        """A second evaluation context over the SAME parameters: own variables, layer blocks and
+        execution plan, shared Param records.  Replicas can evaluate different batches concurrently
+        on different HIP streams (forward-only use; derivatives would collide in the shared Params)."""
+        import copy
+        r = DagNN()
+        r.meta, r.mode, r.fuse, r.device = self.meta, self.mode, self.fuse, self.device
+        r.conserveMemory = self.conserveMemory
+        for l in self.layers:
+            r.layers.append(_LayerRec(l.name, copy.copy(l.block), l.inputs, l.outputs, l.params))
+        r.params = self.params
+        r.rebuild()
+        for name, v in self.vars.items():
+            r.vars[name].precious = v.precious
+        return r
+
     def getLayerIndex(self, name):
         for i, l in enumerate(self.layers):
             if l.name == name:

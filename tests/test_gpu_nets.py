@@ -100,6 +100,33 @@ def test_teacher_forward_matches_oracle(gpu, name):
     close(outs[True], outs[False], 1e-5, "fused vs unfused")
 
 
+def test_frozen_teacher_lanes_match_single_stream(gpu):
+    """zoo.FrozenTeacher (fetch_emovoxceleb_imdb.m:98-136): sample slices on two / three HIP streams
+    give the logits of the one-stream evaluation and of the oracle (uneven split included)."""
+    from mcncrossmodalemotions_amd import vl, zoo
+    rng = np.random.default_rng(35)
+    net = zoo.ferPlusZoo("senet50-ferplus", seed=8, width_mult=0.125, blocks=(1, 1, 1, 1))
+    zoo.strip_losses(net)
+    net.getLayer("pool5").block.poolSize = [2, 2]
+    net.mode = "test"
+    x = O.F(rng.standard_normal((64, 64, 3, 7)) * 40)
+    V = oracle_net.forward(net, {"data": x}, mode="test")
+    net.move("gpu")
+    xd = vl.from_numpy(x)
+    one = vl.to_numpy(zoo.FrozenTeacher(net, lanes=1).logits(xd))
+    close(one, V["prediction"], 1e-4, "single lane vs oracle")
+    for lanes in (2, 3):
+        ft = zoo.FrozenTeacher(net, lanes=lanes)
+        for _ in range(2):  # second call reuses plans / replicas
+            got = vl.to_numpy(ft.logits(xd))
+        assert got.shape == one.shape
+        close(got, one, 1e-5, "%d lanes vs single" % lanes)
+        close(got, V["prediction"], 1e-4, "%d lanes vs oracle" % lanes)
+    net.mode = "normal"
+    with pytest.raises(ValueError):
+        zoo.FrozenTeacher(net)
+
+
 def test_teacher_training_backward(gpu):
     """config-5 precedent (ferplus_baselines.m:140): SE teacher fwd+bwd in train mode."""
     from mcncrossmodalemotions_amd import vl, zoo
