@@ -56,6 +56,8 @@ def parse():
                     help="frozen teacher of the distill workload (BASELINE config 4 names resnet50)")
     ap.add_argument("--teacher-lanes", type=int, default=2,
                     help="teacher workload: sample slices evaluated concurrently on that many HIP streams")
+    ap.add_argument("--wgrad-stream", type=int, default=1,
+                    help="1: filter/bias derivatives of the student on a side HIP stream")
     ap.add_argument("--overlap-teacher", action="store_true",
                     help="run the frozen teacher on a second HIP stream (measured gain < 1%%: both nets fill the chip)")
     return ap.parse_args()
@@ -126,6 +128,12 @@ def main():
 
     tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher) else None
     frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if wl == "teacher" else None
+    if args.wgrad_stream:
+        side = torch.cuda.Stream(device=dev)
+        if student is not None:
+            student.wgradStream = side
+        if wl == "joint":
+            teacher.wgradStream = side
 
     def step(it):
         if wl == "teacher":

@@ -82,13 +82,15 @@ class Conv(Layer):
         return [vl.vl_nnconv(inputs[0], params[0], b, stride=self.stride, pad=self.pad,
                              dilate=self.dilate)]
 
-    def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None, skip_db=False):
+    def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None, skip_db=False,
+                 need_df=True):
         b = params[1] if self.hasBias else None
         dfo = der_out[0] if der_out else None
         dbo = der_out[1] if (der_out and self.hasBias) else None
         dx, df, db = vl.vl_nnconv(inputs[0], params[0], b, derOutputs[0], stride=self.stride,
                                   pad=self.pad, dilate=self.dilate, no_der_data=not need_dx,
-                                  no_der_biases=skip_db, df_out=dfo, db_out=dbo)
+                                  no_der_filters=not need_df, no_der_biases=skip_db or not need_df,
+                                  df_out=dfo if need_df else None, db_out=dbo if need_df else None)
         return [dx], ([df, db] if self.hasBias else [df])
 
     def initParams(self, rng):
@@ -356,6 +358,8 @@ class DagNN:
         self.conserveMemory = True
         self.accumulateParamDers = False
         self.fuse = True  # MI355X peephole fusion (results identical)
+        self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
+        self._side_pending = False
         self.device = None
         self._flat = None
 
@@ -562,6 +566,9 @@ class DagNN:
         self._pending_param_ders = {}
         for step in reversed(plan):
             step.backward(self)
+        if self._side_pending:
+            torch.cuda.current_stream().wait_stream(self.wgradStream)
+            self._side_pending = False
 
     # helpers used by the plan steps
     def _set_var_der(self, name, d):
@@ -644,8 +651,23 @@ class _Step:
         if isinstance(r.block, Conv):
             need_dx = net.vars[r.inputs[0]].fanin > 0  # network inputs need no derivative
             skip_db = self.bias_from is not None and self.bias_from.bias_conv_done
-            dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
-                                          der_out=net._direct_der(r), skip_db=skip_db)
+            side = net.wgradStream if need_dx else None
+            if side is not None and net._flat is not None and net._direct_der(r) is None:
+                side = None  # the derivative would need a copy on this stream
+            if side is None:
+                dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
+                                              der_out=net._direct_der(r), skip_db=skip_db)
+            else:
+                # dzdw / dzdb are off the critical path of the backward pass: they run on the side
+                # stream next to the (HBM-bound) bnorm / pooling derivatives of the layers below
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _, dpar = r.block.backward(ins, self._params(net), douts, need_dx=False,
+                                               der_out=net._direct_der(r), skip_db=skip_db)
+                douts[0].record_stream(side)
+                net._side_pending = True
+                dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False)
             if skip_db:
                 dpar = [dpar[0], net.params[r.params[1]].der]
         elif isinstance(r.block, BatchNorm):

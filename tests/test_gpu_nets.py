@@ -175,3 +175,27 @@ def test_batch_provider(gpu):
     assert f.shape == (224, 224, 3, 4)
     # the three channels differ only by the mean offset (fetch_emovoxceleb_imdb.m:176-193)
     assert np.abs((f[:, :, 0] - f[:, :, 1]) - (103.8827 - 131.0912)).max() < 1e-3
+
+
+def test_wgrad_side_stream_is_bit_identical(gpu):
+    """DagNN.wgradStream: filter / bias derivatives on a side HIP stream -- same kernels, same
+    inputs, so one SGD step leaves bit-identical parameters."""
+    import torch
+    from mcncrossmodalemotions_amd import train, vl, zoo
+    rng = np.random.default_rng(5)
+    x = O.F(rng.standard_normal((512, 100, 1, 4)))
+    lg = O.F(rng.standard_normal((1, 1, 8, 4)) * 3)
+    res = []
+    for side in (False, True):
+        net = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
+        net.pack_params()
+        if side:
+            net.wgradStream = torch.cuda.Stream()
+        opts = train.TrainOpts(batchSize=4)
+        xd, lgd = vl.from_numpy(x), vl.from_numpy(lg)
+        for it in range(3):
+            train.train_step(net, ["data", xd, "logitTarget", lgd, "maxLabel", vl.max_label(lgd)], opts, it,
+                             None, 4)
+        torch.cuda.synchronize()
+        res.append(net._flat.val.clone())
+    assert torch.equal(res[0], res[1])
