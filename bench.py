@@ -58,8 +58,11 @@ def parse():
                     help="teacher workload: sample slices evaluated concurrently on that many HIP streams")
     ap.add_argument("--wgrad-stream", type=int, default=1,
                     help="1: filter/bias derivatives of the student on a side HIP stream")
-    ap.add_argument("--overlap-teacher", action="store_true",
-                    help="run the frozen teacher on a second HIP stream (measured gain < 1%%: both nets fill the chip)")
+    ap.add_argument("--frames", type=int, default=1,
+                    help="distill: face frames per pair; F > 1 runs the teacher on nb*F faces and max-aggregates "
+                         "their logits per pair (getBatchEmoVoxCeleb.m:145-158,179-185; SURVEY 8f row 1)")
+    ap.add_argument("--overlap-teacher", type=int, default=1,
+                    help="1: the frozen teacher runs on a second HIP stream next to the student forward (+2 %%)")
     return ap.parse_args()
 
 
@@ -109,7 +112,8 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------
     faces = spec = lgo = lab = flab = None
     if teacher is not None:
-        faces = xbatch.getImageBatch(nb, seed=seed, device=dev)
+        F = args.frames if wl == "distill" else 1
+        faces = xbatch.getImageBatch(nb * F, seed=seed, device=dev)
         calib = xbatch.getImageBatch(min(nb, 16), seed=999, device=dev)
         zoo.calibrate_moments(teacher, ["data", calib])  # realistic stored moments
         teacher.mode = "test" if wl != "joint" else "normal"
@@ -126,8 +130,12 @@ def main():
             lgo = vl.from_numpy((rng.standard_normal((1, 1, 8, nb)) * 3).astype(np.float32), dev)
             lab = vl.max_label(lgo)
 
-    tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher) else None
-    frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if wl == "teacher" else None
+    F = args.frames if wl == "distill" else 1
+    tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher and F == 1) else None
+    frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if (wl == "teacher" or F > 1) else None
+    if F > 1:
+        first = torch.arange(0, nb, device=dev, dtype=torch.int32) * F + 1   # 1-based, inclusive
+        last = first + (F - 1)
     if args.wgrad_stream:
         side = torch.cuda.Stream(device=dev)
         if student is not None:
@@ -141,6 +149,15 @@ def main():
             return
         if wl == "student":
             train.train_step(student, ["data", spec, "logitTarget", lgo, "maxLabel", lab], opts, it,
+                             parserv, nb * world)
+            return
+        if wl == "distill" and F > 1:
+            # multi-frame pair: teacher over all nb*F frames (two stream lanes), per-pair max over the
+            # window's frames (getBatchEmoVoxCeleb.m:179-185), then the student step
+            lg = frozen.logits(faces)                                  # 1 x 1 x 8 x (nb*F)
+            fl = lg.permute(3, 2, 1, 0).reshape(nb * F, 8).t().contiguous().t()   # frames x 8 mat
+            tl, ml = vl.aggregate_logits(fl, first, last, "max")
+            train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world)
             return
         if wl == "distill" and tstream is None:
@@ -234,11 +251,11 @@ def main():
 
     # ---- CPU baseline leg (rank 0, N = 1): the oracle on a bounded sample ------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and F == 1:
         cpu = cpu_baseline(wl, args.cpu_pairs, W)
 
     if wl == "distill":
-        gflop_unit = GFLOP["%s_fwd" % args.teacher] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
+        gflop_unit = F * GFLOP["%s_fwd" % args.teacher] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
     elif wl == "student":
         gflop_unit = GFLOP["student_fwd_bwd_300"]
     elif wl == "teacher":
@@ -255,7 +272,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"distill": "run_distillation step: frozen %s-ferplus teacher fwd -> " % args.teacher +
-                                               "VGGVox student fwd+bwd, soft-target CE T=2, SGD (BASELINE config 4 shard)",
+                                               "VGGVox student fwd+bwd, soft-target CE T=2, SGD (BASELINE config 4 shard)" +
+                                               ("" if F == 1 else "; %d face frames per pair, max-aggregated" % F),
                                     "student": "VGGVox student fwd+bwd+update (BASELINE config 2)",
                                     "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",
                                     "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
