@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--frames", type=int, default=1,
                     help="distill: face frames per pair; F > 1 runs the teacher on nb*F faces and max-aggregates "
                          "their logits per pair (getBatchEmoVoxCeleb.m:145-158,179-185; SURVEY 8f row 1)")
+    ap.add_argument("--serial", action="store_true",
+                    help="one HIP stream, no overlap anywhere (what the roofline leg and the rocprof profile use: "
+                         "kernel durations are then those of isolated kernels)")
+    ap.add_argument("--teacher-prefetch", type=int, default=1,
+                    help="1: the teacher stream works one batch ahead of the student (needs --overlap-teacher 1)")
     ap.add_argument("--overlap-teacher", type=int, default=1,
                     help="1: the frozen teacher runs on a second HIP stream next to the student forward (+2 %%)")
     return ap.parse_args()
@@ -143,9 +148,25 @@ def main():
         if wl == "joint":
             teacher.wgradStream = side
 
+    prefetched = {}
+    mode = {"serial": bool(args.serial)}
+    side_streams = {id(n): n.wgradStream for n in (student, teacher) if n is not None}
+
+    def set_serial(on):
+        mode["serial"] = on
+        prefetched.clear()
+        for n in (student, teacher):
+            if n is not None:
+                n.wgradStream = None if on else side_streams[id(n)]
+
+    set_serial(mode["serial"])
+
     def step(it):
         if wl == "teacher":
-            frozen.logits(faces)   # fetch_emovoxceleb_imdb.m:129-130
+            if mode["serial"]:
+                teacher.eval(["data", faces])
+            else:
+                frozen.logits(faces)   # fetch_emovoxceleb_imdb.m:129-130
             return
         if wl == "student":
             train.train_step(student, ["data", spec, "logitTarget", lgo, "maxLabel", lab], opts, it,
@@ -154,13 +175,17 @@ def main():
         if wl == "distill" and F > 1:
             # multi-frame pair: teacher over all nb*F frames (two stream lanes), per-pair max over the
             # window's frames (getBatchEmoVoxCeleb.m:179-185), then the student step
-            lg = frozen.logits(faces)                                  # 1 x 1 x 8 x (nb*F)
+            if mode["serial"]:
+                teacher.eval(["data", faces])
+                lg = teacher.vars["prediction"].value
+            else:
+                lg = frozen.logits(faces)                              # 1 x 1 x 8 x (nb*F)
             fl = lg.permute(3, 2, 1, 0).reshape(nb * F, 8).t().contiguous().t()   # frames x 8 mat
             tl, ml = vl.aggregate_logits(fl, first, last, "max")
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world)
             return
-        if wl == "distill" and tstream is None:
+        if wl == "distill" and (tstream is None or mode["serial"]):
             teacher.eval(["data", faces])
             tl = teacher.vars["prediction"].value      # 1 x 1 x 8 x nb teacher logits
             ml = vl.max_label(tl)                       # getBatchEmoVoxCeleb.m:32
@@ -168,18 +193,38 @@ def main():
                              parserv, nb * world)
             return
         if wl == "distill":
-            # optional: the frozen teacher runs on its own HIP stream and overlaps with the student
-            # layers that do not need its logits yet (only the loss / metric layers consume them)
+            # the frozen teacher runs on its own HIP stream; only the loss / metric layers of the
+            # student wait for its logits (input_events).  With --teacher-prefetch the teacher works
+            # one batch ahead, like getBatch's prefetch call (getBatchEmoVoxCeleb.m:20-24): every step
+            # still launches exactly one teacher forward and one student step.
             main = torch.cuda.current_stream()
-            tstream.wait_stream(main)
-            with torch.cuda.stream(tstream):
-                teacher.eval(["data", faces])
-                tl = teacher.vars["prediction"].value
-                ml = vl.max_label(tl)
-                ev = torch.cuda.Event()
-                ev.record(tstream)
-            tl.record_stream(main)
-            ml.record_stream(main)
+
+            def launch_teacher():
+                # prefetch: pipeline depth 1 -- the teacher of step i+1 starts no earlier than the
+                # student of step i (event recorded on the main stream at the start of this step)
+                if args.teacher_prefetch:
+                    e0 = torch.cuda.Event()
+                    e0.record(main)
+                    tstream.wait_event(e0)
+                else:
+                    tstream.wait_stream(main)
+                with torch.cuda.stream(tstream):
+                    teacher.eval(["data", faces])
+                    tl_ = teacher.vars["prediction"].value
+                    ml_ = vl.max_label(tl_)
+                    ev_ = torch.cuda.Event()
+                    ev_.record(tstream)
+                tl_.record_stream(main)
+                ml_.record_stream(main)
+                return tl_, ml_, ev_
+
+            if args.teacher_prefetch:
+                if "next" not in prefetched:
+                    prefetched["next"] = launch_teacher()
+                tl, ml, ev = prefetched["next"]
+                prefetched["next"] = launch_teacher()
+            else:
+                tl, ml, ev = launch_teacher()
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world, input_events={"logitTarget": ev, "maxLabel": ev})
             return
@@ -216,11 +261,18 @@ def main():
     # ---- roofline leg: same K steps again with HIP events around every conv launch ---------
     roofline = None
     if not args.no_roofline:
+        # serial: with the overlap streams on, kernels share the chip and a launch's duration is
+        # not the kernel's own speed
+        was_serial = mode["serial"]
+        set_serial(True)
+        step(args.warmup + args.steps)   # shapes of the serial path (full-batch teacher) get tuned
+        torch.cuda.synchronize()
         L.xm_prof_enable(1)
         for it in range(args.steps):
-            step(args.warmup + args.steps + it)
+            step(args.warmup + args.steps + 1 + it)
         torch.cuda.synchronize()
         L.xm_prof_enable(0)
+        set_serial(was_serial)
         cap = 64
         keys = (C.c_int * cap)()
         ms = (C.c_double * cap)()
@@ -241,6 +293,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(ach, 2),
                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "mode": "serial pass (one stream): launch durations of isolated kernels",
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "flop_per_launch": d["flops"] / d["launches"],
                         "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
@@ -279,7 +332,11 @@ def main():
                                     "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
                        "per_gpu_batch": nb, "global_batch": units, "face": "224x224x3",
                        "spectrogram": "512x%dx1" % W, "parallelism": "dp%d" % world,
-                       "weights": "random-init (seeded)", "parameter_server": args.parserv},
+                       "weights": "random-init (seeded)", "parameter_server": args.parserv,
+                       "streams": "serial" if args.serial else
+                                  {"distill": "teacher one batch ahead on its own stream + wgrad side stream",
+                                   "student": "wgrad side stream", "joint": "wgrad side stream",
+                                   "teacher": "%d sample-slice lanes" % args.teacher_lanes}[wl]},
             "model_tflops_per_gpu": round(value / world * gflop_unit / 1e3, 2),
             "model_frac_of_fp32_mfma_peak": round(value / world * gflop_unit / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
