@@ -11,7 +11,11 @@ template <int VAR>
 __global__ void __launch_bounds__(256, 2) probe(float *out, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
   const int t = threadIdx.x;
-  for (int i = t; i < 8192; i += 256) lds[i] = (float)(i & 7) * 0.001f;
+  for (int i = t; i < 8192; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    lds[i] = VAR >= 10 ? ((float)(h & 0xFFFFFF) / 8388608.f - 1.f) : (float)(i & 7) * 0.001f;
+  }
   __syncthreads();
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i)
@@ -149,7 +153,35 @@ void run(const char *name, int blocks, int iters) {
   hipFree(out);
 }
 
-int main() {
+template <int VAR>
+void sustained(const char *name, int blocks, int iters, int launches) {
+  float *out;
+  hipMalloc(&out, (size_t)blocks * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int rep = 0; rep < launches; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(probe<VAR>, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double fl = (double)blocks * 4 * iters * 16 * 4096.0;
+    if (rep % 20 == 0 || rep == launches - 1)
+      printf("%-28s launch %4d  %8.3f ms  %7.1f TFLOP/s\n", name, rep, ms, fl / ms / 1e9);
+  }
+  hipFree(out);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) {
+    sustained<11>("sustained random-data mfma", 512, 20000, 200);   // ~3.6 s of back-to-back MFMA
+    return 0;
+  }
+  run<11>("random data: lds reads + mfma", 512, 20000);
+  run<12>("random data: lds reads + barrier + mfma", 512, 20000);
+  run<1>("same, tiny constant data", 512, 20000);
   run<0>("pure mfma", 512, 20000);
   run<0>("pure mfma (1 block/CU)", 256, 20000);
   run<0>("pure mfma (4 rounds)", 2048, 5000);
