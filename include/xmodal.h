@@ -148,6 +148,10 @@ int xm_scale_backward(const float *x, int HW, int CN, const float *a, const floa
 /* ---- losses --------------------------------------------------------------------------------
  * vl_nnsoftmaxt(X, 'temperature', T): softmax(X / T) along dim 3; X is HW x C x N */
 int xm_nnsoftmaxt(const float *x, int HW, int C, int N, float temperature, float *y, void *stream);
+/* DZDX = vl_nnsoftmax(X, DZDY) [EXT, SURVEY 8b] generalised to a temperature:
+ * y = softmax(x/T) along C; dx = y .* (dzdy - sum_c(dzdy .* y)) / T.  Same indexing as above. */
+int xm_nnsoftmaxt_backward(const float *x, const float *dzdy, int HW, int C, int N, float temperature,
+                           float *dx, void *stream);
 /* vl_nnsoftmaxceloss(X, P [, DZDY], 'temperature', T, 'logitTargets', tf, 'instanceWeights', w)
  * (dagnn.SoftmaxCELoss at emoVoxZoo.m:152, ferPlusZoo.m:244).  X, P: 1 x 1 x C x N, C <= 64.
  * forward (dzdy == NULL): y[0] = sum_n w_n * CE(softmax(P/T) or P, softmax(X/T));

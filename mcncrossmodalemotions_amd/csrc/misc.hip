@@ -112,6 +112,24 @@ __global__ void softmaxt_kernel(const float *__restrict__ x, float *__restrict__
   for (int c = 0; c < C; ++c) q[(size_t)HW * c] = (float)(exp((double)p[(size_t)HW * c] / T - mx) / s);
 }
 
+__global__ void softmaxt_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dzdy,
+                                    float *__restrict__ dx, int HW, int C, int N, float T) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HW * N) return;
+  int i = idx % HW, n = idx / HW;
+  const size_t base = i + (size_t)HW * C * n;
+  const float *p = x + base, *d = dzdy + base;
+  float *q = dx + base;
+  double mx = -INFINITY, s = 0, dot = 0;
+  for (int c = 0; c < C; ++c) mx = fmax(mx, (double)p[(size_t)HW * c] / T);
+  for (int c = 0; c < C; ++c) s += exp((double)p[(size_t)HW * c] / T - mx);
+  for (int c = 0; c < C; ++c) dot += (double)d[(size_t)HW * c] * (exp((double)p[(size_t)HW * c] / T - mx) / s);
+  for (int c = 0; c < C; ++c) {
+    double y = exp((double)p[(size_t)HW * c] / T - mx) / s;
+    q[(size_t)HW * c] = (float)(y * ((double)d[(size_t)HW * c] - dot) / T);
+  }
+}
+
 // block-wide deterministic sum of one double per thread (256 threads) -> thread 0
 __device__ double block_sum_d(double v, double *red /*256*/) {
   red[threadIdx.x] = v;
@@ -368,6 +386,18 @@ int xm_nnsoftmaxt(const float *x, int HW, int C, int N, float temperature, float
   int cols = HW * N;
   hipLaunchKernelGGL(softmaxt_kernel, dim3((cols + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, y,
                      HW, C, N, temperature);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnsoftmaxt_backward(const float *x, const float *dzdy, int HW, int C, int N, float temperature,
+                           float *dx, void *stream) {
+  if (HW <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "vl_nnsoftmaxt: empty tensor");
+  if (!x || !dzdy || !dx) return fail(XM_EINVAL, "vl_nnsoftmaxt: NULL tensor");
+  if (!(temperature > 0.f)) return fail(XM_EINVAL, "vl_nnsoftmaxt: temperature must be > 0");
+  int cols = HW * N;
+  hipLaunchKernelGGL(softmaxt_bwd_kernel, dim3((cols + 127) / 128), dim3(128), 0, (hipStream_t)stream, x,
+                     dzdy, dx, HW, C, N, temperature);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -230,6 +230,9 @@ class SoftMax(Layer):
     def forward(self, inputs, params):
         return [vl.vl_nnsoftmax(inputs[0])]
 
+    def backward(self, inputs, params, derOutputs):
+        return [vl.vl_nnsoftmax(inputs[0], derOutputs[0])], []
+
 
 class DropOut(Layer):
     """dagnn.DropOut -- identity in test mode; training-time masks are not built (dropout is

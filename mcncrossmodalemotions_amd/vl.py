@@ -364,8 +364,9 @@ def scale_backward(x, a, dzdy, need_dx=True):
 # --------------------------------------------------------------------------------------------
 
 
-def vl_nnsoftmaxt(x, temperature=1.0, dim=3):
-    """VL_NNSOFTMAXT(X, 'temperature', T, 'dim', d).  dim is 1-based as in MATLAB."""
+def vl_nnsoftmaxt(x, dzdy=None, temperature=1.0, dim=3):
+    """Y = VL_NNSOFTMAXT(X, 'temperature', T, 'dim', d); DZDX = VL_NNSOFTMAXT(X, DZDY, ...).
+    dim is 1-based as in MATLAB (student_stats.m:95 uses 'dim', 2)."""
     x = _chk(x, "X")
     shp = [int(s) for s in x.shape] + [1] * (4 - x.dim())
     d = int(dim) - 1
@@ -373,12 +374,20 @@ def vl_nnsoftmaxt(x, temperature=1.0, dim=3):
     Cc = shp[d]
     N = int(np.prod(shp[d + 1:])) if d < 3 else 1
     y = mat_empty(*x.shape, device=x.device)
-    _lib.check(_L().xm_nnsoftmaxt(_ptr(x), HW, Cc, N, float(temperature), _ptr(y), _stream()))
+    if dzdy is None:
+        _lib.check(_L().xm_nnsoftmaxt(_ptr(x), HW, Cc, N, float(temperature), _ptr(y), _stream()))
+        return y
+    dzdy = _chk(dzdy, "DZDY")
+    if tuple(dzdy.shape) != tuple(x.shape):
+        raise ValueError("vl_nnsoftmaxt: DZDY must have the size of X")
+    _lib.check(_L().xm_nnsoftmaxt_backward(_ptr(x), _ptr(dzdy), HW, Cc, N, float(temperature), _ptr(y),
+                                           _stream()))
     return y
 
 
-def vl_nnsoftmax(x):
-    return vl_nnsoftmaxt(x, 1.0, 3)
+def vl_nnsoftmax(x, dzdy=None):
+    """Y = VL_NNSOFTMAX(X); DZDX = VL_NNSOFTMAX(X, DZDY) -- channel softmax along dim 3."""
+    return vl_nnsoftmaxt(x, dzdy, 1.0, 3)
 
 
 def vl_nnsoftmaxceloss(x, p, dzdy=None, temperature=1.0, logitTargets=False, instanceWeights=None):

@@ -197,6 +197,14 @@ def vl_nnsoftmaxt(x, temperature=1.0):
     return y
 
 
+def vl_nnsoftmaxt_backward(x, dzdy, temperature=1.0):
+    x, dzdy = F(x), F(dzdy)
+    H, W, Cc, N = _shape4(x)
+    dx = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_nnsoftmaxt_backward(_p(x), _p(dzdy), C.c_size_t(H * W), Cc, N, C.c_float(temperature), _p(dx))
+    return dx
+
+
 def vl_nnsoftmaxceloss(x, p, dzdy=None, temperature=1.0, logit_targets=False,
                        instance_weights=None):
     x, p = F(x), F(p)

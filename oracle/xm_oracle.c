@@ -639,6 +639,27 @@ void orc_nnsoftmaxt(const float *x, size_t HW, int C, int N, float T, float *y) 
     }
 }
 
+/* derivative of vl_nnsoftmaxt: y = softmax(x/T); dx = y .* (dzdy - sum_c dzdy.*y) / T
+ * (MatConvNet vl_nnsoftmax backward [EXT]: Y .* bsxfun(@minus, dzdY, sum(dzdY .* Y, 3))) */
+void orc_nnsoftmaxt_backward(const float *x, const float *dzdy, size_t HW, int C, int N, float T,
+                             float *dx) {
+  for (int n = 0; n < N; ++n)
+    for (size_t i = 0; i < HW; ++i) {
+      const float *p = x + i + HW * (size_t)C * n;
+      const float *d = dzdy + i + HW * (size_t)C * n;
+      float *q = dx + i + HW * (size_t)C * n;
+      double mx = -INFINITY, s = 0, dot = 0;
+      for (int c = 0; c < C; ++c)
+        if (p[HW * c] / T > mx) mx = p[HW * c] / T;
+      for (int c = 0; c < C; ++c) s += exp((double)p[HW * c] / T - mx);
+      for (int c = 0; c < C; ++c) dot += (double)d[HW * c] * (exp((double)p[HW * c] / T - mx) / s);
+      for (int c = 0; c < C; ++c) {
+        double y = exp((double)p[HW * c] / T - mx) / s;
+        q[HW * c] = (float)(y * ((double)d[HW * c] - dot) / T);
+      }
+    }
+}
+
 /*
  * vl_nnsoftmaxceloss(X, P, [DZDY], 'temperature', T, 'logitTargets', tf, 'instanceWeights', w)
  * X, P: 1 x 1 x C x N.   q = softmax(X/T);  p = logitTargets ? softmax(P/T) : P

@@ -266,7 +266,18 @@ def test_losses(gpu):
                   1e-6, loss)
             close(vl.to_numpy(vl.vl_nnloss(xd, ld, 1.0, loss=loss)), O.vl_nnloss(x, lab, np.ones(1), loss=loss),
                   1e-6, loss + " bwd")
-        close(vl.to_numpy(vl.vl_nnsoftmaxt(xd, 2.0)), O.vl_nnsoftmaxt(x, 2.0), 1e-6, "softmaxt")
+        close(vl.to_numpy(vl.vl_nnsoftmaxt(xd, temperature=2.0)), O.vl_nnsoftmaxt(x, 2.0), 1e-6, "softmaxt")
+        # vl_nnsoftmax(X, DZDY) / vl_nnsoftmaxt backward, spatial tensor and 'dim', 2 (student_stats.m:95)
+        xs = O.F(rng.standard_normal((3, 5, 8, N)) * 2)
+        ds = O.F(rng.standard_normal((3, 5, 8, N)))
+        close(vl.to_numpy(vl.vl_nnsoftmax(vl.from_numpy(xs), vl.from_numpy(ds))),
+              O.vl_nnsoftmaxt_backward(xs, ds, 1.0), 1e-6, "softmax bwd")
+        close(vl.to_numpy(vl.vl_nnsoftmaxt(vl.from_numpy(xs), vl.from_numpy(ds), temperature=2.0)),
+              O.vl_nnsoftmaxt_backward(xs, ds, 2.0), 1e-6, "softmaxt bwd")
+        m = O.F(rng.standard_normal((6, 8)))
+        got = vl.to_numpy(vl.vl_nnsoftmaxt(vl.from_numpy(m), temperature=2.0, dim=2))
+        e = np.exp(m.astype(np.float64) / 2.0)
+        close(got, (e / e.sum(1, keepdims=True)).astype(np.float32), 1e-6, "softmaxt dim 2")
 
 
 def test_sgd_and_batch_math(gpu):

@@ -199,3 +199,17 @@ def test_golden_fixtures():
     assert np.array_equal(O.vl_nnpool(G["pool_x"], [3, 3], G["pool_dzdy"], stride=2), G["pool_dx"])
     assert abs(O.vl_nnsoftmaxceloss(G["loss_x"], G["loss_p"], temperature=2, logit_targets=True) - G["loss_y"]) < 1e-6
     assert np.abs(O.spec_rownorm(G["spec"]) - G["spec_norm"]).max() < 1e-6
+
+
+def test_softmax_backward_matches_torch_autograd():
+    """oracle vl_nnsoftmaxt backward (MatConvNet vl_nnsoftmax DZDY form) vs torch autograd."""
+    import torch
+    rng = np.random.default_rng(21)
+    x = O.F(rng.standard_normal((2, 3, 8, 4)) * 2)
+    d = O.F(rng.standard_normal((2, 3, 8, 4)))
+    for T in (1.0, 2.0):
+        xt = torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, requires_grad=True)
+        y = torch.softmax(xt / T, dim=2)
+        (y * torch.tensor(np.ascontiguousarray(d), dtype=torch.float64)).sum().backward()
+        got = O.vl_nnsoftmaxt_backward(x, d, T)
+        assert np.abs(got - xt.grad.numpy()).max() < 1e-6
