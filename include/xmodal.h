@@ -160,6 +160,15 @@ int xm_nnsoftmaxt_backward(const float *x, const float *dzdy, int HW, int C, int
 int xm_nnsoftmaxceloss(const float *x, const float *p, int C, int N, float temperature,
                        int logit_targets, const float *instance_weights, const float *dzdy,
                        float *y, void *stream);
+/* vl_nneuclideanloss(X, T [, DZDY], 'instanceWeights', w)  /  vl_nnhuberloss(X, T [, DZDY], 'sigma', s,
+ * 'instanceWeights', w) -- mcnExtraLayers; dagnn.EuclideanLoss / dagnn.HuberLoss at emoVoxZoo.m:139-146.
+ * X, T: E elements per sample x N samples; w: N weights or NULL (broadcast over a sample's elements).
+ * forward (dzdy == NULL): y[0] = sum_n w_n sum_e l(x - t), l(d) = d^2/2 (euclidean) or smooth-L1 with
+ * knee 1/sigma^2 (huber); backward: y (E*N floats) = dzdy[0] * w_n * l'(x - t).  dzdy: DEVICE pointer. */
+#define XM_REGLOSS_EUCLIDEAN 0
+#define XM_REGLOSS_HUBER 1
+int xm_nnregloss(const float *x, const float *t, int E, int N, int kind, float sigma,
+                 const float *instance_weights, const float *dzdy, float *y, void *stream);
 /* vl_nnloss(X, c [, DZDY], 'loss', 'softmaxlog'|'classerror'); labels are 1-based floats */
 int xm_nnloss(const float *x, const float *labels, int C, int N, int loss, const float *dzdy,
               float *y, void *stream);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "xm_scale_backward": [c_fp, _i, _i, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_nnsoftmaxt": [c_fp, _i, _i, _i, _f, c_fp, _vp],
     "xm_nnsoftmaxt_backward": [c_fp, c_fp, _i, _i, _i, _f, c_fp, _vp],
+    "xm_nnregloss": [c_fp, c_fp, _i, _i, _i, _f, c_fp, c_fp, c_fp, _vp],
     "xm_nnsoftmaxceloss": [c_fp, c_fp, _i, _i, _f, _i, c_fp, c_fp, c_fp, _vp],
     "xm_nnloss": [c_fp, c_fp, _i, _i, _i, c_fp, c_fp, _vp],
     "xm_sgd_update": [c_fp, c_fp, c_fp, _sz, _f, _f, _f, _f, _vp],

@@ -88,15 +88,23 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
     im = vl.spec_rownorm(spec_source) if "I" in transformation else spec_source
     lgo, maxLabel = vl.aggregate_logits(logits, torch.from_numpy(first).to(device),
                                         torch.from_numpy(last).to(device), logitAggregator)
+    if numPredEmotions > lgo.shape[2]:
+        raise ValueError("numPredEmotions exceeds the number of cached logits")
     if numPredEmotions != lgo.shape[2]:
-        raise NotImplementedError("numPredEmotions < number of cached logits")
+        # lgo = lgo(:,:,1:opts.numPredEmotions,:) ; [~, maxLabel] = max(lgo, [], 3)  (:30-32)
+        lgo = lgo[:, :, :numPredEmotions, :].permute(3, 2, 1, 0).contiguous().permute(3, 2, 1, 0)
+        maxLabel = vl.max_label(lgo)
     inputs = ["data", im]
     if lossType == "softmaxlog":
         inputs += ["maxLabel", maxLabel]
+    elif lossType == "euclidean":
+        weights = vl.mat_empty(1, 1, 1, N, device=device)   # "no re-weighting required" (:36)
+        weights.fill_(1.0)
+        inputs += ["logitTarget", lgo, "instanceWeights", weights, "maxLabel", maxLabel]
     elif lossType == "hot-cross-ent":
         inputs += ["logitTarget", lgo, "maxLabel", maxLabel]
     else:
-        raise ValueError("unrecognised loss type: %s" % lossType)
+        raise ValueError("unrecognised loss type: %s" % lossType)   # 'huber' included, as upstream (:41)
     return inputs
 
 

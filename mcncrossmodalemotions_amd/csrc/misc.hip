@@ -184,6 +184,34 @@ softmaxceloss_kernel(const float *__restrict__ x, const float *__restrict__ p, i
   }
 }
 
+// regression losses: forward = single block, fixed-order double sum; backward = elementwise
+__global__ void __launch_bounds__(256)
+regloss_kernel(const float *__restrict__ x, const float *__restrict__ t, int E, int N, int kind,
+               float sigma, const float *__restrict__ w, const float *__restrict__ dzdy,
+               float *__restrict__ y) {
+  __shared__ double red[256];
+  const double s2 = (double)sigma * sigma;
+  const size_t total_e = (size_t)E * N;
+  double total = 0;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total_e; i += (size_t)gridDim.x * 256) {
+    const int n = (int)(i / E);
+    const double wn = w ? (double)w[n] : 1.0;
+    const double d = (double)x[i] - (double)t[i];
+    const double a = fabs(d);
+    const bool lin = kind == 1 && a > 1.0 / s2;
+    if (!dzdy) {
+      total += wn * (kind == 0 ? 0.5 * d * d : (lin ? a - 0.5 / s2 : 0.5 * s2 * d * d));
+    } else {
+      const double g = kind == 0 ? d : (lin ? (d > 0 ? 1.0 : -1.0) : s2 * d);
+      y[i] = (float)((double)dzdy[0] * wn * g);
+    }
+  }
+  if (!dzdy) {
+    double r = block_sum_d(total, red);
+    if (threadIdx.x == 0) y[0] = (float)r;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 nnloss_kernel(const float *__restrict__ x, const float *__restrict__ labels, int C, int N, int loss,
               const float *__restrict__ dzdy, float *__restrict__ y) {
@@ -411,6 +439,24 @@ int xm_nnsoftmaxceloss(const float *x, const float *p, int C, int N, float tempe
   if (!x || !p || !y) return fail(XM_EINVAL, "vl_nnsoftmaxceloss: NULL tensor");
   hipLaunchKernelGGL(softmaxceloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, p, C, N,
                      temperature, logit_targets, instance_weights, dzdy, y);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nnregloss(const float *x, const float *t, int E, int N, int kind, float sigma,
+                 const float *instance_weights, const float *dzdy, float *y, void *stream) {
+  if (E <= 0 || N <= 0) return fail(XM_EINVAL, "regression loss: empty tensor");
+  if (too_big(E, N)) return fail(XM_ETOOBIG, "regression loss: tensor too large");
+  if (kind != XM_REGLOSS_EUCLIDEAN && kind != XM_REGLOSS_HUBER)
+    return fail(XM_ENOTSUP, "regression loss: kind %d not built (euclidean, huber)", kind);
+  if (kind == XM_REGLOSS_HUBER && !(sigma > 0.f)) return fail(XM_EINVAL, "vl_nnhuberloss: sigma must be > 0");
+  if (!x || !t || !y) return fail(XM_EINVAL, "regression loss: NULL tensor");
+  // forward: one block (deterministic sum); backward: elementwise over a grid
+  size_t n = (size_t)E * N;
+  size_t nb = (n + 255) / 256;
+  unsigned grid = dzdy ? (unsigned)(nb < 4096 ? nb : 4096) : 1u;
+  hipLaunchKernelGGL(regloss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, t, E, N, kind,
+                     sigma, instance_weights, dzdy, y);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -290,6 +290,40 @@ class SoftmaxCELoss(LossBase):
         return [dx] + [None] * (len(inputs) - 1), []
 
 
+class EuclideanLoss(LossBase):
+    """mcnExtraLayers dagnn.EuclideanLoss on {prediction, target, instanceWeights} (emoVoxZoo.m:139-140)."""
+
+    def forward(self, inputs, params):
+        w = inputs[2] if len(inputs) > 2 else None
+        y = vl.vl_nneuclideanloss(inputs[0], inputs[1], instanceWeights=w)
+        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        return [y]
+
+    def backward(self, inputs, params, derOutputs):
+        w = inputs[2] if len(inputs) > 2 else None
+        dx = vl.vl_nneuclideanloss(inputs[0], inputs[1], derOutputs[0], instanceWeights=w)
+        return [dx] + [None] * (len(inputs) - 1), []
+
+
+class HuberLoss(LossBase):
+    """mcnExtraLayers dagnn.HuberLoss('sigma', s) (emoVoxZoo.m:146-147)."""
+
+    def __init__(self, sigma=1.0):
+        super().__init__()
+        self.sigma = float(sigma)
+
+    def forward(self, inputs, params):
+        w = inputs[2] if len(inputs) > 2 else None
+        y = vl.vl_nnhuberloss(inputs[0], inputs[1], sigma=self.sigma, instanceWeights=w)
+        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        return [y]
+
+    def backward(self, inputs, params, derOutputs):
+        w = inputs[2] if len(inputs) > 2 else None
+        dx = vl.vl_nnhuberloss(inputs[0], inputs[1], derOutputs[0], sigma=self.sigma, instanceWeights=w)
+        return [dx] + [None] * (len(inputs) - 1), []
+
+
 class Loss(LossBase):
     """dagnn.Loss('loss', 'softmaxlog' | 'classerror')."""
 

@@ -438,6 +438,40 @@ def vl_nnloss(x, c, dzdy=None, loss="softmaxlog"):
     return y
 
 
+def _regloss(x, t, dzdy, kind, sigma, instanceWeights, name):
+    x, t = _chk(x, "X"), _chk(t, "T")
+    if tuple(x.shape) != tuple(t.shape):
+        raise ValueError("%s: X and T must have the same size" % name)
+    N = int(x.shape[3]) if x.dim() > 3 else 1
+    E = int(x.numel()) // N
+    w = None if instanceWeights is None else _chk(instanceWeights, "instanceWeights")
+    if w is not None and int(w.numel()) != N:
+        raise ValueError("%s: need one instance weight per sample" % name)
+    if dzdy is None:
+        y = mat_empty(1, 1, device=x.device)
+        _lib.check(_L().xm_nnregloss(_ptr(x), _ptr(t), E, N, kind, float(sigma), _ptr(w), None, _ptr(y),
+                                     _stream()))
+        return y
+    if not isinstance(dzdy, torch.Tensor):
+        dzdy = from_numpy(np.array([[float(dzdy)]], np.float32), device=x.device)
+    y = mat_empty(*x.shape, device=x.device)
+    _lib.check(_L().xm_nnregloss(_ptr(x), _ptr(t), E, N, kind, float(sigma), _ptr(w), _ptr(dzdy), _ptr(y),
+                                 _stream()))
+    return y
+
+
+def vl_nneuclideanloss(x, t, dzdy=None, instanceWeights=None):
+    """VL_NNEUCLIDEANLOSS(X, T [, DZDY], 'instanceWeights', w) -- mcnExtraLayers (emoVoxZoo.m:139)."""
+    return _regloss(x, t, dzdy, 0, 1.0, instanceWeights, "vl_nneuclideanloss")
+
+
+def vl_nnhuberloss(x, t, dzdy=None, sigma=1.0, instanceWeights=None):
+    """VL_NNHUBERLOSS(X, T [, DZDY], 'sigma', s, 'instanceWeights', w) -- mcnExtraLayers (emoVoxZoo.m:147)."""
+    if not sigma > 0:
+        raise ValueError("vl_nnhuberloss: sigma must be positive")
+    return _regloss(x, t, dzdy, 1, sigma, instanceWeights, "vl_nnhuberloss")
+
+
 # --------------------------------------------------------------------------------------------
 # optimiser / parameter server
 # --------------------------------------------------------------------------------------------

@@ -277,8 +277,14 @@ def configureForRegression(net, lossType, numOutputs):
         # emoVoxZoo.m:152 -- the temperature is hard-coded to 2 (opts.temperature only names
         # the experiment directory, run_distillation.m:85,102-104)
         layer, inputs = dagnn.SoftmaxCELoss(temperature=2, logitTargets=True), ["prediction", "logitTarget"]
-    elif lossType in ("euclidean", "huber"):
-        raise NotImplementedError("lossType '%s' is outside the built hot path (SURVEY 2.2)" % lossType)
+    elif lossType == "euclidean":
+        layer, inputs = dagnn.EuclideanLoss(), ["prediction", "logitTarget", "instanceWeights"]
+        # emoVoxZoo.m:141-145: "scale down a lot to prevent exploding gradients" -- the filters of the
+        # last layer are divided by 10
+        p = net.params[net.layers[-1].params[0]]
+        p.value = p.value / 10
+    elif lossType == "huber":
+        layer, inputs = dagnn.HuberLoss(sigma=1), ["prediction", "logitTarget", "instanceWeights"]
     else:
         raise ValueError("unrecognised regression loss: %s" % lossType)
     net.addLayer("loss", layer, inputs, "objective")

@@ -197,6 +197,23 @@ def vl_nnsoftmaxt(x, temperature=1.0):
     return y
 
 
+def vl_nnregloss(x, t, dzdy=None, kind="euclidean", sigma=1.0, instance_weights=None):
+    """vl_nneuclideanloss / vl_nnhuberloss (mcnExtraLayers [EXT]); x, t: ... x N (last axis = sample)."""
+    x, t = F(x), F(t)
+    N = int(x.shape[-1]) if x.ndim == 4 else 1
+    E = x.size // N
+    w = None if instance_weights is None else F(np.ravel(instance_weights))
+    k = {"euclidean": 0, "huber": 1}[kind]
+    if dzdy is None:
+        y = np.zeros(1, np.float32)
+        lib().orc_nnregloss(_p(x), _p(t), C.c_size_t(E), N, k, C.c_float(sigma), _p(w), None, _p(y))
+        return y[0]
+    d = F(np.ravel(dzdy))
+    y = np.zeros(x.shape, np.float32, order="F")
+    lib().orc_nnregloss(_p(x), _p(t), C.c_size_t(E), N, k, C.c_float(sigma), _p(w), _p(d), _p(y))
+    return y
+
+
 def vl_nnsoftmaxt_backward(x, dzdy, temperature=1.0):
     x, dzdy = F(x), F(dzdy)
     H, W, Cc, N = _shape4(x)

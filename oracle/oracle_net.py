@@ -56,6 +56,12 @@ def forward(net, inputs, params=None, acc64=True, mode=None):
                 continue
             y = np.float32(O.vl_nnsoftmaxceloss(ins[0], ins[1], temperature=b.temperature,
                                                 logit_targets=b.logitTargets))
+        elif isinstance(b, (dagnn.EuclideanLoss, dagnn.HuberLoss)):
+            if ins[0] is None or ins[1] is None:
+                continue
+            kind = "euclidean" if isinstance(b, dagnn.EuclideanLoss) else "huber"
+            y = np.float32(O.vl_nnregloss(ins[0], ins[1], kind=kind, sigma=getattr(b, "sigma", 1.0),
+                                          instance_weights=ins[2] if len(ins) > 2 else None))
         elif isinstance(b, (dagnn.Loss, dagnn.ErrorStats)):
             if ins[0] is None or ins[1] is None:
                 continue
@@ -120,8 +126,15 @@ def backward(net, V, der_outputs, params=None, acc64=True, mode=None):
         elif isinstance(b, dagnn.SoftmaxCELoss):
             add(l.inputs[0], O.vl_nnsoftmaxceloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(),
                                                   temperature=b.temperature, logit_targets=b.logitTargets))
+        elif isinstance(b, (dagnn.EuclideanLoss, dagnn.HuberLoss)):
+            kind = "euclidean" if isinstance(b, dagnn.EuclideanLoss) else "huber"
+            add(l.inputs[0], O.vl_nnregloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(), kind=kind,
+                                            sigma=getattr(b, "sigma", 1.0),
+                                            instance_weights=ins[2] if len(ins) > 2 else None))
         elif isinstance(b, dagnn.Loss):
             add(l.inputs[0], O.vl_nnloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(), loss=b.loss))
+        elif isinstance(b, dagnn.SoftMax):
+            add(l.inputs[0], O.vl_nnsoftmaxt_backward(ins[0], dz, 1.0))
         else:
             raise NotImplementedError(type(b))
     return D, DP

@@ -639,6 +639,37 @@ void orc_nnsoftmaxt(const float *x, size_t HW, int C, int N, float T, float *y) 
     }
 }
 
+/*
+ * mcnExtraLayers regression losses [EXT] -- dagnn.EuclideanLoss / dagnn.HuberLoss('sigma', 1) on
+ * {'prediction', 'logitTarget', 'instanceWeights'} (emoVoxZoo.m:139-146; weights = ones(1,1,1,N),
+ * getBatchEmoVoxCeleb.m:36-38).  X, T: E elements per sample, N samples; w: N weights (bsxfun over
+ * the elements of a sample) or NULL.
+ *   euclidean (kind 0): Y = 1/2 sum_n w_n sum_e (x - t)^2          dX = dzdy * w_n * (x - t)
+ *   huber     (kind 1): d = x - t, s2 = sigma^2, linear <=> |d| > 1/s2
+ *                       Y = sum_n w_n sum_e (linear ? |d| - 0.5/s2 : 0.5*s2*d^2)
+ *                       dX = dzdy * w_n * (linear ? sign(d) : s2*d)
+ */
+void orc_nnregloss(const float *x, const float *t, size_t E, int N, int kind, float sigma, const float *w,
+                   const float *dzdy, float *y /* 1 value or E*N grads */) {
+  const double s2 = (double)sigma * sigma;
+  double total = 0;
+  for (int n = 0; n < N; ++n) {
+    const double wn = w ? (double)w[n] : 1.0;
+    for (size_t e = 0; e < E; ++e) {
+      const double d = (double)x[E * n + e] - (double)t[E * n + e];
+      const double a = fabs(d);
+      const int lin = kind == 1 && a > 1.0 / s2;
+      if (!dzdy) {
+        total += wn * (kind == 0 ? 0.5 * d * d : (lin ? a - 0.5 / s2 : 0.5 * s2 * d * d));
+      } else {
+        const double g = kind == 0 ? d : (lin ? (d > 0 ? 1.0 : -1.0) : s2 * d);
+        y[E * n + e] = (float)((double)dzdy[0] * wn * g);
+      }
+    }
+  }
+  if (!dzdy) y[0] = (float)total;
+}
+
 /* derivative of vl_nnsoftmaxt: y = softmax(x/T); dx = y .* (dzdy - sum_c dzdy.*y) / T
  * (MatConvNet vl_nnsoftmax backward [EXT]: Y .* bsxfun(@minus, dzdY, sum(dzdY .* Y, 3))) */
 void orc_nnsoftmaxt_backward(const float *x, const float *dzdy, size_t HW, int C, int N, float T,

@@ -199,3 +199,35 @@ def test_wgrad_side_stream_is_bit_identical(gpu):
         torch.cuda.synchronize()
         res.append(net._flat.val.clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("lossType", ["euclidean", "huber", "softmaxlog"])
+def test_student_alternative_loss_heads(gpu, lossType):
+    """configureForRegression's other heads (emoVoxZoo.m:138-150): loss value and every parameter
+    derivative of the 1/8-width student against the oracle; euclidean also divides the last filter
+    bank by 10 (:141-145)."""
+    from mcncrossmodalemotions_amd import vl, zoo
+    rng = np.random.default_rng(23)
+    N, W = 3, 100
+    net = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=6, lossType=lossType)
+    if lossType == "euclidean":
+        ref = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=6)
+        a, b = net.params[net.getLayer("fc8").params[0]].value, ref.params[ref.getLayer("fc8").params[0]].value
+        assert np.allclose(np.asarray(a) * 10, np.asarray(b), rtol=1e-6)
+    P0 = oracle_net.host_params(net)
+    data, lgo, lab = _student_inputs(rng, W, N)
+    wts = O.F(np.ones((1, 1, 1, N)))
+    feed = {"data": data, "logitTarget": lgo, "maxLabel": lab, "instanceWeights": wts}
+    V = oracle_net.forward(net, feed, P0, mode="normal")
+    _, DP = oracle_net.backward(net, V, {"objective": np.float32(1)}, P0, mode="normal")
+    net.pack_params()
+    inputs = []
+    for k, v in feed.items():
+        if k in net.vars:
+            inputs += [k, vl.from_numpy(v)]
+    net.mode = "normal"
+    net.eval(inputs, ["objective", 1])
+    close(vl.to_numpy(net.vars["objective"].value).ravel()[0], V["objective"], 1e-5, "objective " + lossType)
+    for name, ref in DP.items():
+        got = vl.to_numpy(net.params[name].der)
+        close(got.reshape(ref.shape, order="F"), ref, 2e-4, "der " + name)

@@ -267,6 +267,23 @@ def test_losses(gpu):
             close(vl.to_numpy(vl.vl_nnloss(xd, ld, 1.0, loss=loss)), O.vl_nnloss(x, lab, np.ones(1), loss=loss),
                   1e-6, loss + " bwd")
         close(vl.to_numpy(vl.vl_nnsoftmaxt(xd, temperature=2.0)), O.vl_nnsoftmaxt(x, 2.0), 1e-6, "softmaxt")
+        # regression losses of emoVoxZoo.m:138-147
+        w1 = O.F(rng.uniform(0.5, 2, (1, 1, 1, N)))
+        for wt in (None, w1):
+            wd = None if wt is None else vl.from_numpy(wt)
+            close(vl.to_numpy(vl.vl_nneuclideanloss(xd, pd, instanceWeights=wd)).ravel()[0],
+                  O.vl_nnregloss(x, p, kind="euclidean", instance_weights=wt), 1e-6, "euclid fwd")
+            close(vl.to_numpy(vl.vl_nneuclideanloss(xd, pd, 0.5, instanceWeights=wd)),
+                  O.vl_nnregloss(x, p, np.full(1, 0.5, np.float32), kind="euclidean", instance_weights=wt),
+                  1e-6, "euclid bwd")
+            for sg in (1.0, 0.7):
+                close(vl.to_numpy(vl.vl_nnhuberloss(xd, pd, sigma=sg, instanceWeights=wd)).ravel()[0],
+                      O.vl_nnregloss(x, p, kind="huber", sigma=sg, instance_weights=wt), 1e-6, "huber fwd")
+                close(vl.to_numpy(vl.vl_nnhuberloss(xd, pd, 1.0, sigma=sg, instanceWeights=wd)),
+                      O.vl_nnregloss(x, p, np.ones(1, np.float32), kind="huber", sigma=sg, instance_weights=wt),
+                      1e-6, "huber bwd")
+        with pytest.raises(ValueError):
+            vl.vl_nnhuberloss(xd, pd, sigma=0.0)
         # vl_nnsoftmax(X, DZDY) / vl_nnsoftmaxt backward, spatial tensor and 'dim', 2 (student_stats.m:95)
         xs = O.F(rng.standard_normal((3, 5, 8, N)) * 2)
         ds = O.F(rng.standard_normal((3, 5, 8, N)))

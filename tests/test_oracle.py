@@ -213,3 +213,29 @@ def test_softmax_backward_matches_torch_autograd():
         (y * torch.tensor(np.ascontiguousarray(d), dtype=torch.float64)).sum().backward()
         got = O.vl_nnsoftmaxt_backward(x, d, T)
         assert np.abs(got - xt.grad.numpy()).max() < 1e-6
+
+
+def test_regression_losses_match_torch():
+    """oracle vl_nneuclideanloss / vl_nnhuberloss ([EXT] mcnExtraLayers forms) vs torch + autograd."""
+    import torch
+    rng = np.random.default_rng(22)
+    x = O.F(rng.standard_normal((1, 1, 8, 5)) * 2)
+    t = O.F(rng.standard_normal((1, 1, 8, 5)) * 2)
+    w = O.F(rng.uniform(0.5, 2, (1, 1, 1, 5)))
+    wt = torch.tensor(w.ravel(), dtype=torch.float64)
+    for kind, sigma in (("euclidean", 1.0), ("huber", 1.0), ("huber", 2.0)):
+        xt = torch.tensor(x[0, 0].T.copy(), dtype=torch.float64, requires_grad=True)   # N x C
+        tt = torch.tensor(t[0, 0].T.copy(), dtype=torch.float64)
+        d = xt - tt
+        if kind == "euclidean":
+            per = 0.5 * d * d
+        else:
+            s2 = sigma * sigma
+            per = torch.where(d.abs() > 1 / s2, d.abs() - 0.5 / s2, 0.5 * s2 * d * d)
+        loss = (wt[:, None] * per).sum()
+        loss.backward()
+        assert abs(O.vl_nnregloss(x, t, kind=kind, sigma=sigma, instance_weights=w) - loss.item()) < 1e-5
+        g = O.vl_nnregloss(x, t, np.ones(1, np.float32), kind=kind, sigma=sigma, instance_weights=w)
+        assert np.abs(g[0, 0].T - xt.grad.numpy()).max() < 1e-6
+        assert abs(O.vl_nnregloss(x, t, kind=kind, sigma=sigma) -
+                   O.vl_nnregloss(x, t, kind=kind, sigma=sigma, instance_weights=np.ones(5))) < 1e-6
