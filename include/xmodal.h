@@ -199,6 +199,12 @@ int xm_aggregate_logits(const float *frame_logits, int F_total, int E, const int
                         void *stream);
 /* getBatchEmoVoxCeleb.m:32: [~, maxLabel] = max(lgo, [], 3); x is 1 x 1 x C x N, labels 1-based */
 int xm_max_label(const float *x, int C, int N, float *labels, void *stream);
+/* mcnExtraLayers dagnn.ErrorStats bookkeeping (emoVoxZoo.m:165-169, read by extractStats,
+ * run_distillation.m:186-207): for every sample n with label c = labels[n] (1-based):
+ * population[c-1] += 1, correct[c-1] += (argmax_c x(:, n) == c).  ACCUMULATES into the two
+ * C-element device arrays (zero them at the start of an epoch); first maximum wins ties. */
+int xm_class_stats(const float *x, const float *labels, int C, int N, float *correct,
+                   float *population, void *stream);
 /* fetch_emovoxceleb_imdb.m:176-193: rgb2gray -> replicate x3 -> minus averageImage(c).
  * avg3 is a HOST pointer to the three per-channel means (meta.normalization.averageImage). */
 int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,

@@ -36,7 +36,8 @@ class SyntheticEmoVoxImdb:
     """Stand-in for the imdb of fetch_emovoxceleb_imdb: per-track wav length (samples) and the
     cached teacher logits imdb.wavLogits{i} (F_i x 8 single, one row per sampled face frame)."""
 
-    def __init__(self, num_tracks=64, seed=0, min_seconds=4.5, max_seconds=9.0, num_emotions=8, fs=16000):
+    def __init__(self, num_tracks=64, seed=0, min_seconds=4.5, max_seconds=9.0, num_emotions=8, fs=16000,
+                 val_fraction=0.0):
         rng = np.random.default_rng(seed)
         self.fs = fs
         self.num_samples = rng.integers(int(min_seconds * fs), int(max_seconds * fs), num_tracks)
@@ -44,7 +45,9 @@ class SyntheticEmoVoxImdb:
         for n in self.num_samples:
             frames = time2idx(n / fs)
             self.wavLogits.append(np.asfortranarray(rng.standard_normal((frames, num_emotions)).astype(np.float32) * 3))
-        self.set = np.ones(num_tracks, int)
+        self.set = np.ones(num_tracks, int)       # imdb.images.set: 1 = train, 2 = val
+        if val_fraction > 0:
+            self.set[rng.permutation(num_tracks)[:int(round(num_tracks * val_fraction))]] = 2
         self.seed = seed
         self._dev = None
 

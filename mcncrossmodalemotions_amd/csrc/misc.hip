@@ -351,6 +351,37 @@ __global__ void max_label_kernel(const float *__restrict__ x, int C, int N, floa
   lab[n] = (float)(arg + 1);
 }
 
+// one block; per-class counts through LDS atomics -- the addends are 0/1, so the float sums are
+// exact integers (< 2^24) whatever the order: deterministic
+__global__ void __launch_bounds__(256)
+class_stats_kernel(const float *__restrict__ x, const float *__restrict__ labels, int C, int N,
+                   float *__restrict__ correct, float *__restrict__ population) {
+  extern __shared__ float cnt[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) cnt[i] = 0.f;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      float v = x[(size_t)C * n + c];
+      if (v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    const int lab = (int)labels[n];
+    if (lab >= 1 && lab <= C) {
+      atomicAdd(&cnt[C + lab - 1], 1.f);
+      if (arg + 1 == lab) atomicAdd(&cnt[lab - 1], 1.f);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    correct[i] += cnt[i];
+    population[i] += cnt[C + i];
+  }
+}
+
 __global__ void normalize_face_kernel(const float *__restrict__ rgb, float *__restrict__ out, int HW,
                                       int N, float a0, float a1, float a2) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -521,6 +552,17 @@ int xm_max_label(const float *x, int C, int N, float *labels, void *stream) {
   if (!x || !labels) return fail(XM_EINVAL, "max_label: NULL tensor");
   hipLaunchKernelGGL(max_label_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, C, N,
                      labels);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_class_stats(const float *x, const float *labels, int C, int N, float *correct,
+                   float *population, void *stream) {
+  if (C <= 0 || N <= 0) return fail(XM_EINVAL, "class_stats: empty input");
+  if (C > 4096) return fail(XM_ETOOBIG, "class_stats: more than 4096 classes");
+  if (!x || !labels || !correct || !population) return fail(XM_EINVAL, "class_stats: NULL tensor");
+  hipLaunchKernelGGL(class_stats_kernel, dim3(1), dim3(256), sizeof(float) * 2 * C, (hipStream_t)stream,
+                     x, labels, C, N, correct, population);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -252,19 +252,45 @@ class DropOut(Layer):
 
 
 class LossBase(Layer):
+    """dagnn.Loss bookkeeping [EXT]: `average` = running per-sample mean of the (batch-summed) loss,
+    `numAveraged` = samples seen since reset().  The running sum stays on the device (one tiny add
+    per minibatch); reading `average` is the only host synchronisation."""
+
+    ignoreAverage = False
+
     def __init__(self):
         super().__init__()
-        self.average = 0.0
-        self.numAveraged = 0
+        self.reset()
 
     def reset(self):
-        self.average = 0.0
+        self._sum = None
+        self._pending = []
         self.numAveraged = 0
+        self.lastValue = None
+        self.lastN = 0
+
+    def _fold(self):
+        if self._pending:
+            t = torch.stack([v.reshape(-1)[0] for v in self._pending]).sum()
+            self._sum = t if self._sum is None else self._sum + t
+            self._pending = []
 
     def _accumulate(self, value, n):
-        # dagnn.Loss keeps a running average of the loss per sample
+        # the batch-summed loss values are kept as device scalars and folded 64 at a time: no extra
+        # launch in the step itself
         self.lastValue = value
         self.lastN = n
+        self._pending.append(value)
+        if len(self._pending) >= 64:
+            self._fold()
+        self.numAveraged += n
+
+    @property
+    def average(self):
+        self._fold()
+        if self._sum is None or self.numAveraged == 0:
+            return 0.0
+        return float(self._sum.item()) / self.numAveraged
 
 
 class SoftmaxCELoss(LossBase):
@@ -345,26 +371,46 @@ class VerboseLoss(Loss):
 
 
 class ErrorStats(LossBase):
-    """mcnExtraLayers dagnn.ErrorStats: per-class accuracy bookkeeping (host side, argmax only).
-    emoVoxZoo.m:165-169; read back by extractStats (run_distillation.m:186-207)."""
+    """mcnExtraLayers dagnn.ErrorStats('numClasses', C) on {prediction, maxLabel} (emoVoxZoo.m:165-169):
+    per-class accuracy and class population, read back by extractStats (run_distillation.m:186-207)
+    as `block.average` (C accuracies) and `block.classDist` (C counts).  The counters live on the
+    device (xm_class_stats); a class without samples reports accuracy 0 [EXT]."""
 
     def __init__(self, numClasses=8):
+        self.numClasses = int(numClasses)
+        self._correct = None
+        self._population = None
         super().__init__()
-        self.numClasses = numClasses
-        self.correct = np.zeros(numClasses)
-        self.population = np.zeros(numClasses)
+
+    def reset(self):
+        super().reset()
+        if self._correct is not None:
+            self._correct.zero_()
+            self._population.zero_()
 
     def forward(self, inputs, params):
         y = vl.vl_nnloss(inputs[0], inputs[1], loss="classerror")
-        self._accumulate(y, int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1)
+        if self._correct is None:
+            self._correct = vl.mat_zeros(self.numClasses, 1, device=inputs[0].device)
+            self._population = vl.mat_zeros(self.numClasses, 1, device=inputs[0].device)
+        vl.class_stats(inputs[0], inputs[1], self._correct, self._population)
+        self.lastValue = y
+        self.lastN = int(inputs[0].shape[3]) if inputs[0].dim() > 3 else 1
+        self.numAveraged += self.lastN
         return [y]
 
-    def update_host_stats(self, prediction, labels):
-        pred = vl.to_numpy(prediction).reshape(self.numClasses, -1).argmax(0) + 1
-        lab = vl.to_numpy(labels).ravel().astype(int)
-        for c in range(1, self.numClasses + 1):
-            self.population[c - 1] += np.sum(lab == c)
-            self.correct[c - 1] += np.sum((lab == c) & (pred == c))
+    @property
+    def classDist(self):
+        if self._population is None:
+            return np.zeros(self.numClasses)
+        return vl.to_numpy(self._population).ravel().astype(np.float64)
+
+    @property
+    def average(self):
+        if self._correct is None:
+            return np.zeros(self.numClasses)
+        c = vl.to_numpy(self._correct).ravel().astype(np.float64)
+        return c / np.maximum(self.classDist, 1.0)
 
     def backward(self, inputs, params, derOutputs):
         return [None, None], []

@@ -104,11 +104,113 @@ def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, inpu
     accumulate_gradients(net, opts, lr, global_batch or opts.batchSize, world)
 
 
-def extractStats(net, num_samples):
-    """run_distillation.m:186-207: average of every dagnn.Loss output (per sample)."""
+def extractStats(stats, net):
+    """stats = extractStats(stats, net) -- run_distillation.m:186-207: `.average` of every dagnn.Loss
+    block under its output name; for dagnn.ErrorStats the per-class accuracies under the class names,
+    their mean as `meanAcc`, and the class population as `<name>Pop`."""
     from . import dagnn
-    stats = {}
+    stats = dict(stats or {})
     for l in net.layers:
-        if isinstance(l.block, dagnn.LossBase) and getattr(l.block, "lastValue", None) is not None:
-            stats[l.outputs[0]] = float(vl.to_numpy(l.block.lastValue).ravel()[0]) / max(num_samples, 1)
+        b = l.block
+        if not isinstance(b, dagnn.LossBase):
+            continue
+        if isinstance(b, dagnn.ErrorStats):
+            metrics, dist = b.average, b.classDist
+            pop = dist / dist.sum() if dist.sum() > 0 else dist
+            names = (net.meta.get("classes", {}).get("name") or
+                     ["class%d" % (i + 1) for i in range(len(metrics))])
+            stats["meanAcc"] = float(np.mean(metrics))
+            for name, m in zip(names, metrics):
+                stats[name] = float(m)
+            for name, q in zip(names, pop):
+                stats["%sPop" % name] = float(q)
+        else:
+            if b.ignoreAverage:
+                continue
+            stats[l.outputs[0]] = b.average
     return stats
+
+
+def _reset_losses(net):
+    from . import dagnn
+    for l in net.layers:
+        if isinstance(l.block, dagnn.LossBase):
+            l.block.reset()
+
+
+def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, extractStatsFn=extractStats):
+    """processEpoch of cnn_train_dag [EXT]: one pass over `subset` in minibatches of opts.batchSize;
+    each worker evaluates the interleaved shard batch(labindex:numlabs:end)."""
+    import time
+    world = parserv.world if parserv is not None else 1
+    rank = parserv.rank if parserv is not None else 0
+    _reset_losses(net)
+    subset = list(subset)
+    t0 = time.perf_counter()
+    num = 0
+    for t in range(0, len(subset), opts.batchSize):
+        batch = subset[t:t + opts.batchSize]
+        shard = shard_batch(batch, rank, world)
+        if not shard:
+            continue
+        inputs = getBatch(imdb, shard)
+        if mode == "train":
+            train_step(net, inputs, opts, epoch, parserv, len(batch))
+        else:
+            net.mode = "test"
+            net.eval(inputs)
+        num += len(batch)
+    stats = extractStatsFn({}, net)   # the only host synchronisation of the pass
+    stats["num"] = num
+    stats["time"] = time.perf_counter() - t0
+    return stats
+
+
+def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpochs=300, train=None, val=None,
+                  cont=True, expDir=None, epochSize=float("inf"), parameterServer=None, extractStatsFn=extractStats,
+                  momentum=0.9, weightDecay=5e-4, derOutputs=("objective", 1), randomSeed=0, verbose=False):
+    """[net, info] = cnn_train_dag(net, imdb, getBatch, 'learningRate', ..., 'batchSize', ..., 'numEpochs', ...,
+    'train', ..., 'val', ..., 'continue', ..., 'expDir', ..., 'epochSize', ..., 'parameterServer', ...,
+    'extractStatsFn', ...) -- the MatConvNet driver [EXT] as run_distillation.m:170-182 calls it.
+
+    Per epoch: shuffle `train` with the epoch's seed, keep the first `epochSize` samples (the reference's
+    "mini-epochs"), one training pass, one validation pass in test mode, then a checkpoint
+    `net-epoch-<n>.pt` in `expDir` (flat parameters + momentum + info) from which `cont` resumes.
+    `gpus` is implicit: one process per GPU (torchrun), the process group gives the worker count."""
+    import os
+    opts = TrainOpts(learningRate=learningRate, momentum=momentum, weightDecay=weightDecay, batchSize=batchSize,
+                     derOutputs=derOutputs)
+    if len(opts.learningRate) < numEpochs:   # MatConvNet indexes min(epoch, numel(learningRate))
+        pass
+    parserv = parameterServer if isinstance(parameterServer, ParameterServer) else ParameterServer("torch")
+    parserv.start()
+    if net._flat is None:
+        net.pack_params()
+    train = list(train if train is not None else [])
+    val = list(val if val is not None else [])
+    info = {"train": [], "val": []}
+    start = 0
+    path = (lambda e: os.path.join(expDir, "net-epoch-%d.pt" % e)) if expDir else None
+    if expDir and parserv.rank == 0:
+        os.makedirs(expDir, exist_ok=True)
+    if cont and expDir:
+        done = [e for e in range(1, numEpochs + 1) if os.path.exists(path(e))]
+        if done:
+            start = max(done)
+            ck = torch.load(path(start), map_location=net.device, weights_only=False)
+            net._flat.val.copy_(ck["val"])
+            net._flat.mom.copy_(ck["mom"])
+            info = ck["info"]
+    for epoch in range(start, numEpochs):
+        rng = np.random.default_rng(epoch + 1 + randomSeed)       # rng(epoch + opts.randomSeed)
+        order = [train[i] for i in rng.permutation(len(train))]
+        if epochSize < len(order):
+            order = order[:int(epochSize)]
+        info["train"].append(process_epoch(net, imdb, getBatch, order, opts, epoch, "train", parserv, extractStatsFn))
+        info["val"].append(process_epoch(net, imdb, getBatch, val, opts, epoch, "val", parserv, extractStatsFn))
+        if verbose and parserv.rank == 0:
+            print("epoch %d: train %s | val %s" % (epoch + 1, info["train"][-1], info["val"][-1]), flush=True)
+        if path and parserv.rank == 0:
+            torch.save({"val": net._flat.val, "mom": net._flat.mom, "info": info, "epoch": epoch + 1}, path(epoch + 1))
+    parserv.stop()
+    return net, info

@@ -528,6 +528,18 @@ def max_label(lgo):
     return lab
 
 
+def class_stats(x, labels, correct, population):
+    """dagnn.ErrorStats bookkeeping: correct[c] / population[c] += ... for the samples of this batch
+    (x: 1 x 1 x C x N scores, labels: 1-based, correct / population: C-element device arrays)."""
+    x, labels = _chk(x, "X"), _chk(labels, "LABELS")
+    H, W, Cc, N = _shape4(x)
+    if H != 1 or W != 1 or labels.numel() != N:
+        raise ValueError("class_stats: X must be 1 x 1 x C x N with one label per sample")
+    if correct.numel() != Cc or population.numel() != Cc:
+        raise ValueError("class_stats: counters must have C elements")
+    _lib.check(_L().xm_class_stats(_ptr(x), _ptr(labels), Cc, N, _ptr(correct), _ptr(population), _stream()))
+
+
 def normalize_face(rgb, average_image):
     """fetch_emovoxceleb_imdb.m:176-193: grey -> x3 -> minus averageImage; rgb H x W x 3 x N."""
     rgb = _chk(rgb, "RGB")

@@ -231,3 +231,36 @@ def test_student_alternative_loss_heads(gpu, lossType):
     for name, ref in DP.items():
         got = vl.to_numpy(net.params[name].der)
         close(got.reshape(ref.shape, order="F"), ref, 2e-4, "der " + name)
+
+
+def test_run_distillation_driver(gpu, tmp_path):
+    """run_distillation -> cnn_train_dag mirror (run_distillation.m:71-182): mini-epochs, validation
+    pass in test mode, extractStats keys, checkpoint + resume ('cont')."""
+    from mcncrossmodalemotions_amd.run_distillation import run_distillation
+    from mcncrossmodalemotions_amd import zoo
+    kw = dict(gpus=[0], numSeconds=1, batchSize=4, miniEpochRatio=0.5, miniVal=0.5, numTracks=24,
+              widthMult=0.125, dataDir=str(tmp_path), learningRate=[1e-3, 1e-3, 1e-3])
+    net, info = run_distillation(numEpochs=2, **kw)
+    assert len(info["train"]) == 2 and len(info["val"]) == 2
+    tr = info["train"][-1]
+    for k in ["objective", "classerror", "meanAcc", "num", "time"] + zoo.EMOTIONS + [e + "Pop" for e in zoo.EMOTIONS]:
+        assert k in tr, k
+    assert tr["num"] == 9          # 18 training tracks x 0.5
+    assert info["val"][-1]["num"] == 3
+    assert np.isfinite(tr["objective"]) and 0.0 <= tr["classerror"] <= 1.0 and 0.0 <= tr["meanAcc"] <= 1.0
+    assert abs(sum(tr[e + "Pop"] for e in zoo.EMOTIONS) - 1.0) < 1e-6
+    exp = [d for d in tmp_path.iterdir()]
+    assert len(exp) == 1 and exp[0].name == ("voxceleb-senet50-ferplus-emovoxceleb-student-hot-cross-ent-scratch-"
+                                              "1sec-8emo-agg-max-temp2")
+    assert (exp[0] / "net-epoch-2.pt").exists()
+    # resume: epochs 1-2 come from the checkpoint, only epoch 3 runs
+    net2, info2 = run_distillation(numEpochs=3, **kw)
+    assert len(info2["train"]) == 3
+    assert info2["train"][:2] == info["train"]
+    # a fresh run without 'cont' reproduces the first epochs exactly (seeded shuffles and crops)
+    net3, info3 = run_distillation(numEpochs=2, cont=False, **kw)
+    for a, b in zip(info3["train"], info["train"]):
+        assert a["objective"] == b["objective"] and a["meanAcc"] == b["meanAcc"]
+    # the euclidean head trains through the same driver
+    _, info4 = run_distillation(numEpochs=1, lossType="euclidean", cont=False, **kw)
+    assert np.isfinite(info4["train"][0]["objective"])
