@@ -297,6 +297,26 @@ def test_losses(gpu):
         close(got, (e / e.sum(1, keepdims=True)).astype(np.float32), 1e-6, "softmaxt dim 2")
 
 
+def test_class_stats(gpu):
+    """xm_class_stats (dagnn.ErrorStats bookkeeping): accumulates per-class hits / population."""
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(31)
+    C = 8
+    correct = vl.mat_zeros(C, 1)
+    pop = vl.mat_zeros(C, 1)
+    ref_c, ref_p = np.zeros(C), np.zeros(C)
+    for N in (1, 7, 300, 64):
+        x = rnd(rng, 1, 1, C, N)
+        lab = O.F(rng.integers(1, C + 1, (1, 1, 1, N)))
+        vl.class_stats(vl.from_numpy(x), vl.from_numpy(lab), correct, pop)
+        pred = x[0, 0].argmax(0) + 1
+        for c in range(1, C + 1):
+            ref_p[c - 1] += np.sum(lab.ravel() == c)
+            ref_c[c - 1] += np.sum((lab.ravel() == c) & (pred == c))
+        close(vl.to_numpy(correct).ravel(), ref_c.astype(np.float32), 0, "correct")
+        close(vl.to_numpy(pop).ravel(), ref_p.astype(np.float32), 0, "population")
+
+
 def test_sgd_and_batch_math(gpu):
     from mcncrossmodalemotions_amd import vl
     import torch
