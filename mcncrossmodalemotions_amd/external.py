@@ -1,0 +1,120 @@
+"""Feature-extraction drivers of the reference's evaluation code (`external/`), device side.
+
+    compute_audio_feats   external/compute_audio_feats.m:96-136,160-185
+        variable-width student inference: per clip, row-normalise the whole spectrogram, centre-crop to
+        the largest bucket width <= T, resize `pool6` to that bucket, one test-mode forward.
+    compute_visual_feats  external/compute_visual_feats.m:60-116
+        frozen teacher over the flattened frames of all tracks in minibatches, logits split per track.
+
+File I/O (wav / jpeg decoding, the .mat imdb) and the FFT front-end stay outside: the
+functions take device tensors (spectrogram magnitudes 512 x T, normalised faces 224 x 224 x 3 x F).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import dagnn, vl, zoo
+
+BUCKETS_POOL = list(zoo.BUCKETS_POOL)     # compute_audio_feats.m:45-46
+BUCKETS_WIDTH = list(zoo.BUCKETS_WIDTH)
+
+
+def _matlab_round(x):
+    return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def test_getinput(spec):
+    """compute_audio_feats.m:160-185 minus file reading: mean/std normalisation of every frequency row
+    over the WHOLE clip, then the centre crop to the largest bucket width that fits.
+    spec: 512 x T device mat.  Returns (512 x rsize mat, rsize)."""
+    T = int(spec.shape[1])
+    fits = [w for w in BUCKETS_WIDTH if w <= T]
+    if not fits:
+        raise ValueError("empty audio clip: %d frames, the smallest bucket needs %d" % (T, BUCKETS_WIDTH[0]))
+    rsize = fits[-1]
+    n = vl.spec_rownorm(spec[:, :, None, None] if spec.dim() == 2 else spec)   # 512 x T x 1 x 1 view
+    rstart = _matlab_round((T - rsize) / 2.0)
+    if rstart == 0:
+        rstart = 1                                   # 1-based, :183
+    s0 = rstart - 1
+    if s0 + rsize > T:                               # cannot happen for the bucket table; guard anyway
+        s0 = T - rsize
+    return n[:, s0:s0 + rsize], rsize
+
+
+def _prepare(dag):
+    names = [l.name for l in dag.layers if isinstance(l.block, dagnn.LossBase)]   # :98-103
+    if names:
+        dag.removeLayer(names)
+    dag.mode = "test"
+    dag.move("gpu")
+    ins = dag.getInputs()
+    if len(ins) != 1:
+        raise ValueError("too many inputs")          # :108
+    return ins[0], dag.getLayerIndex("pool6")
+
+
+def compute_audio_feats(dag, specs, numEmotions=8, batch_by_bucket=False):
+    """logits = compute_audio_feats(dag, specs): one row of `numEmotions` logits per clip.
+
+    specs: list of 512 x T spectrogram-magnitude device tensors (any T >= 100).
+    batch_by_bucket (extension): clips that fall into the same width bucket are evaluated as ONE
+    minibatch instead of one launch chain per clip -- same logits (test-mode BN, samples independent),
+    far fewer launches."""
+    inp, ind1 = _prepare(dag)
+    if ind1 is None:
+        raise ValueError("the audio model has no pool6 layer")
+    out_name = list(dag.vars)[-1]                    # "risky use of end variable", :127
+    dag.vars[out_name].precious = True
+    logits = np.zeros((len(specs), numEmotions), np.float32)
+    pending = []                                     # (clip indices, device logits) -- read back once
+    prepared = [test_getinput(s) for s in specs]
+    if batch_by_bucket:
+        groups = {}
+        for i, (_, rsize) in enumerate(prepared):
+            groups.setdefault(rsize, []).append(i)
+        work = [(idx, rsize) for rsize, idx in sorted(groups.items())]
+    else:
+        work = [([i], prepared[i][1]) for i in range(len(specs))]
+    for idx, rsize in work:
+        p1 = BUCKETS_POOL[BUCKETS_WIDTH.index(rsize)]
+        dag.layers[ind1].block.poolSize = [1, p1]    # :119
+        if len(idx) == 1:
+            x = prepared[idx[0]][0]                  # a column range of a column-major mat: contiguous
+        else:
+            x = vl.mat_empty(int(prepared[idx[0]][0].shape[0]), rsize, 1, len(idx), device=prepared[idx[0]][0].device)
+            for k, i in enumerate(idx):
+                x[:, :, :, k].copy_(prepared[i][0][:, :, :, 0])
+        dag.eval([inp, x])
+        pending.append((idx, dag.vars[out_name].value))
+    for idx, val in pending:
+        out = vl.to_numpy(val).reshape(-1, len(idx), order="F")   # squeeze: E x N
+        logits[idx, :] = out.T[:, :numEmotions]
+    return logits
+
+
+def compute_visual_feats(dag, track_frames, batchSize=128, numEmotions=8, limit=float("inf"), lanes=2):
+    """faceLogits = compute_visual_feats(dag, track_frames): the frames of all tracks are flattened
+    (:63-69), pushed through the frozen teacher `batchSize` at a time (:81-94) and the logits are split
+    back per track (:104-109).  track_frames: list of 224 x 224 x 3 x F_i normalised face mats."""
+    _prepare(dag)
+    first_ok = [i for i in range(len(track_frames)) if i <= limit]   # frameIdx <= firstId + limit, :72
+    counts = [int(track_frames[i].shape[3]) for i in first_ok]
+    teacher = zoo.FrozenTeacher(dag, lanes=lanes)
+    flat = []
+    for i in first_ok:
+        t = track_frames[i]
+        flat.append(t.permute(3, 2, 1, 0).contiguous())           # (F, C, W, H) storage order
+    allf = torch.cat(flat, 0)
+    numIms = int(allf.shape[0])
+    outs = []
+    for s in range(0, numIms, batchSize):
+        data = allf[s:s + batchSize].permute(3, 2, 1, 0)
+        outs.append(teacher.logits(data))
+    logits = np.concatenate([vl.to_numpy(o).reshape(-1, int(o.shape[3]), order="F").T for o in outs], 0)
+    faceLogits, off = [], 0
+    for c in counts:
+        faceLogits.append(logits[off:off + c, :numEmotions])
+        off += c
+    return faceLogits

@@ -264,3 +264,54 @@ def test_run_distillation_driver(gpu, tmp_path):
     # the euclidean head trains through the same driver
     _, info4 = run_distillation(numEpochs=1, lossType="euclidean", cont=False, **kw)
     assert np.isfinite(info4["train"][0]["objective"])
+
+
+def test_compute_audio_feats_variable_width(gpu):
+    """external/compute_audio_feats.m:116-136,160-185: whole-clip row normalisation, centre crop to the
+    bucket width, pool6 resized per clip; one-by-one and bucket-batched evaluation vs the oracle."""
+    from mcncrossmodalemotions_amd import external, vl, zoo
+    rng = np.random.default_rng(41)
+    net = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=9)
+    widths = [100, 137, 250, 205, 333, 1012, 299]
+    specs = [O.F(np.abs(rng.standard_normal((512, T))) + 0.1) for T in widths]
+    # oracle: same arithmetic on the host
+    ref = []
+    onet = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=9)
+    zoo.strip_losses(onet)
+    P0 = oracle_net.host_params(onet)
+    for sp, T in zip(specs, widths):
+        n = O.spec_rownorm(sp.reshape(512, T, 1, 1, order="F"))
+        rsize = max(w for w in external.BUCKETS_WIDTH if w <= T)
+        rstart = int(np.floor((T - rsize) / 2.0 + 0.5)) or 1
+        crop = np.asfortranarray(n[:, rstart - 1:rstart - 1 + rsize])
+        onet.getLayer("pool6").block.poolSize = [1, external.BUCKETS_POOL[external.BUCKETS_WIDTH.index(rsize)]]
+        V = oracle_net.forward(onet, {"data": crop}, P0, mode="test")
+        ref.append(V["prediction"].ravel())
+    ref = np.stack(ref)
+    dspecs = [vl.from_numpy(sp) for sp in specs]
+    got = external.compute_audio_feats(net, dspecs)
+    close(got, ref, 1e-4, "one clip at a time")
+    got_b = external.compute_audio_feats(net, dspecs, batch_by_bucket=True)
+    close(got_b, ref, 1e-4, "bucket-batched")
+    close(got_b, got, 1e-5, "batched vs single")
+    with pytest.raises(ValueError):
+        external.compute_audio_feats(net, [vl.from_numpy(O.F(np.ones((512, 60))))])
+
+
+def test_compute_visual_feats_splits_tracks(gpu):
+    """external/compute_visual_feats.m:60-116: flattened frames -> teacher minibatches -> per-track logits."""
+    from mcncrossmodalemotions_amd import external, vl, zoo
+    rng = np.random.default_rng(43)
+    net = zoo.ferPlusZoo("resnet50-ferplus", seed=7, width_mult=0.125, blocks=(1, 1, 1, 1))
+    net.getLayer("pool5").block.poolSize = [2, 2]
+    counts = [3, 1, 5, 2]
+    tracks = [O.F(rng.standard_normal((64, 64, 3, c)) * 40) for c in counts]
+    onet = zoo.ferPlusZoo("resnet50-ferplus", seed=7, width_mult=0.125, blocks=(1, 1, 1, 1))
+    zoo.strip_losses(onet)
+    onet.getLayer("pool5").block.poolSize = [2, 2]
+    P0 = oracle_net.host_params(onet)
+    feats = external.compute_visual_feats(net, [vl.from_numpy(t) for t in tracks], batchSize=4)
+    assert [f.shape for f in feats] == [(c, 8) for c in counts]
+    for t, f in zip(tracks, feats):
+        V = oracle_net.forward(onet, {"data": t}, P0, mode="test")
+        close(f, V["prediction"].reshape(8, -1, order="F").T, 1e-4, "track logits")
