@@ -191,6 +191,11 @@ int xm_comm_destroy(void);
 /* ---- batch-provider arithmetic (device side of getBatchEmoVoxCeleb / getImageBatch) ---------
  * getBatchEmoVoxCeleb.m:164-169: per-frequency-row mean / unbiased std over time; H x W x 1 x N */
 int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream);
+/* |STFT| from the output of the framing convolution (runSpec of getBatchEmoVoxCeleb.m:162 [EXT VGGVox]):
+ * reim is 1 x Wo x 2B x N (channel b = Re of bin b, channel B+b = Im), out is B x Wo x 1 x N with
+ * out(b, j, 1, n) = sqrt(Re^2 + Im^2).  The framing/windowing/pre-emphasis/DFT itself is one
+ * xm_nnconv_forward with a 1 x (Nw+1) x 1 x 2B filter bank and stride [1 Ns] (batch.runSpec). */
+int xm_spec_magnitude(const float *reim, int Wo, int B, int N, float *out, void *stream);
 /* getBatchEmoVoxCeleb.m:145-158,179-188: for sample n aggregate frame logits (F_total x E,
  * column-major, all wavs concatenated) over rows [first[n], last[n]] (1-based, inclusive)
  * -> out 1 x 1 x E x N and maxLabel (1-based argmax, getBatchEmoVoxCeleb.m:32) */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "xm_allreduce_sum_f32": [c_fp, _sz, _vp],
     "xm_comm_destroy": [],
     "xm_spec_rownorm": [c_fp, _i, _i, _i, c_fp, _vp],
+    "xm_spec_magnitude": [c_fp, _i, _i, _i, c_fp, _vp],
     "xm_aggregate_logits": [c_fp, _i, _i, c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],
     "xm_max_label": [c_fp, _i, _i, c_fp, _vp],
     "xm_class_stats": [c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],

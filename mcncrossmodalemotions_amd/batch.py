@@ -32,6 +32,55 @@ def aud_samples(width, Tw=25, fs=16000):
     return (0.01 * width + 0.001 * Tw - 0.001) * fs
 
 
+_SPEC_BANKS = {}
+
+
+def _spec_filter_bank(fs, Tw, Ts, alpha, nfft, device):
+    """1 x (Nw+1) x 1 x 2B filter bank = pre-emphasis * Hamming window * DFT rows (Re | Im), built in
+    float64 on the host once per setting.  Tap k multiplies sample s[Ns*j - 1 + k]."""
+    key = (fs, Tw, Ts, alpha, nfft, str(device))
+    if key not in _SPEC_BANKS:
+        Nw = int(round(1e-3 * Tw * fs))
+        B = nfft // 2
+        t = np.arange(Nw)
+        win = 0.54 - 0.46 * np.cos(2 * np.pi * t / (Nw - 1))
+        ang = 2 * np.pi * np.outer(t, np.arange(B)) / nfft            # Nw x B
+        re, im = win[:, None] * np.cos(ang), -win[:, None] * np.sin(ang)
+        bank = np.zeros((Nw + 1, 2 * B))
+        bank[1:, :B] += re
+        bank[1:, B:] += im
+        bank[:-1, :B] -= alpha * re                                     # y[t] = s[t] - alpha s[t-1]
+        bank[:-1, B:] -= alpha * im
+        f = np.asfortranarray(bank.reshape(1, Nw + 1, 1, 2 * B).astype(np.float32))
+        _SPEC_BANKS[key] = vl.from_numpy(f, device)
+    return _SPEC_BANKS[key]
+
+
+def runSpec(z, audio=None):
+    """SPEC = runSpec(z, audio) on the device (getBatchEmoVoxCeleb.m:162, compute_audio_feats.m:176;
+    [EXT] VGGVox, restated from the paper: 25 ms Hamming frames every 10 ms, pre-emphasis 0.97,
+    1024-point FFT magnitude, 512 bins).  z: L x N device tensor of samples, one clip per column
+    (column-major).  The whole STFT is ONE strided 1-D convolution on the MFMA path -- pre-emphasis,
+    window and DFT folded into a 1 x 401 x 1 x 1024 filter bank, stride [1 160] -- followed by a
+    magnitude/transposition kernel.  Returns 512 x W x 1 x N, W = floor((L - 400) / 160) + 1."""
+    a = dict(fs=16000, Tw=25, Ts=10, alpha=0.97)
+    a.update({k: v for k, v in (audio or {}).items() if k in a})
+    nfft = 1024
+    if z.dim() == 1:
+        z = z[:, None]
+    L, N = int(z.shape[0]), int(z.shape[1])
+    Nw, Ns = int(round(1e-3 * a["Tw"] * a["fs"])), int(round(1e-3 * a["Ts"] * a["fs"]))
+    if L < Nw:
+        raise ValueError("runSpec: clip shorter than one analysis frame")
+    bank = _spec_filter_bank(a["fs"], a["Tw"], a["Ts"], a["alpha"], nfft, z.device)
+    # one leading zero per clip = the missing predecessor of the first sample (filter([1 -alpha], 1, z))
+    buf = torch.zeros((N, L + 1), dtype=torch.float32, device=z.device)
+    buf[:, 1:].copy_(z.t())
+    x = buf.t()[None, :, None, :]                 # 1 x (L+1) x 1 x N view, column-major
+    reim = vl.vl_nnconv(x, bank, None, stride=(1, Ns))
+    return vl.spec_magnitude(reim)
+
+
 class SyntheticEmoVoxImdb:
     """Stand-in for the imdb of fetch_emovoxceleb_imdb: per-track wav length (samples) and the
     cached teacher logits imdb.wavLogits{i} (F_i x 8 single, one row per sampled face frame)."""
@@ -51,6 +100,15 @@ class SyntheticEmoVoxImdb:
         self.seed = seed
         self._dev = None
 
+    def device_wav(self, ii, device):
+        """synthetic waveform of track ii (seeded noise, num_samples[ii] samples) on the device."""
+        cache = self.__dict__.setdefault("_wav", {})
+        if ii not in cache:
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed * 100003 + int(ii))
+            cache[ii] = torch.randn(int(self.num_samples[ii]), generator=g, device=device, dtype=torch.float32) * 0.1
+        return cache[ii]
+
     def device_logits(self, device):
         """all tracks' logits concatenated (F_total x E) on the device + row offsets."""
         if self._dev is None:
@@ -62,10 +120,12 @@ class SyntheticEmoVoxImdb:
 
 def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, logitAggregator="max",
                         lossType="hot-cross-ent", transformation="I", rng=None, spec_source=None,
-                        device=None):
+                        device=None, use_wav=False):
     """inputs = getBatchEmoVoxCeleb(imdb, batch, ...) -> ['data', im, 'logitTarget', lgo,
     'maxLabel', maxLabel] (getBatchEmoVoxCeleb.m:31-43).  Spectrogram magnitudes come from
-    `spec_source` (H x W x 1 x N device tensor) or a seeded half-normal generator."""
+    `spec_source` (H x W x 1 x N device tensor), from the imdb's waveforms through the device
+    front-end (`use_wav`: crop [wr, wr+audSamp) with zero padding of short clips :109-119, runSpec
+    :162), or from a seeded half-normal generator."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     rng = rng or np.random.default_rng(0)
     batch = list(batch)
@@ -75,14 +135,25 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
     logits, offs = imdb.device_logits(device)
     first = np.zeros(N, np.int32)
     last = np.zeros(N, np.int32)
+    crops = []
     for k, ii in enumerate(batch):
         total = int(imdb.num_samples[ii])
         wr = int(rng.integers(0, max(total - int(audSamp), 0) + 1))  # random crop start (:109-119)
+        crops.append((ii, wr))
         starttime = wr / imdb.fs
         endtime = (wr + audSamp - 1) / imdb.fs
         s, e = time2idx(starttime), time2idx(endtime)
         e = min(e, imdb.wavLogits[ii].shape[0])  # :152
         first[k], last[k] = offs[ii] + s, offs[ii] + e
+    if spec_source is None and use_wav:
+        L = int(round(audSamp))
+        z = torch.zeros((N, L), dtype=torch.float32, device=device)      # storage of the L x N mat
+        for k, (ii, wr) in enumerate(crops):
+            w = imdb.device_wav(ii, device)[wr:wr + L]
+            z[k, :w.numel()].copy_(w)                                    # zero padding when short (:117)
+        spec_source = runSpec(z.t(), {"fs": imdb.fs})
+        if int(spec_source.shape[1]) != W:
+            raise RuntimeError("runSpec produced %d frames, expected %d" % (int(spec_source.shape[1]), W))
     if spec_source is None:
         g = torch.Generator(device=device)
         g.manual_seed(int(rng.integers(0, 2 ** 31)))

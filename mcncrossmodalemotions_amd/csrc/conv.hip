@@ -398,13 +398,14 @@ static int make_geo(Geo &g, int H, int W, int C, int N, int FH, int FW, int FC, 
 }
 
 // forward tap table for the implicit GEMM: r = u + FH*(v + FW*c) -> {byte offset in X, (u,v) index}
-static const int2 *fwd_taps2(const Geo &g, int Rp) {
+static const int2 *fwd_taps2(const Geo &g, int Rp, bool all_valid = false) {
   int count = Rp + 3 * kBK;  // kernels fetch the table three stages ahead
   std::vector<int2> t(count);
   for (int r = 0; r < count; ++r) {
     if (r < g.R) {
       int u = r % g.FH, v = (r / g.FH) % g.FW, c = r / (g.FH * g.FW);
-      t[r] = make_int2(4 * (u * g.dy + g.H * (v * g.dx) + g.H * g.W * c), u + g.FH * v);
+      // all_valid (no spatial padding, > 63 taps): every real tap shares mask bit 0 = tap (0,0)
+      t[r] = make_int2(4 * (u * g.dy + g.H * (v * g.dx) + g.H * g.W * c), all_valid ? 0 : u + g.FH * v);
     } else {
       t[r] = make_int2(0, 63);
     }
@@ -429,8 +430,12 @@ static const int4 *fwd_taps(const Geo &g, int count) {
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st) {
-  if (g.FH * g.FW > 63)
-    return fail(XM_ENOTSUP, "vl_nnconv: filters with more than 63 spatial taps (%dx%d) are not built",
+  // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
+  // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
+  const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
+  const bool bigTaps = g.FH * g.FW > 63;
+  if (bigTaps && padded)
+    return fail(XM_ENOTSUP, "vl_nnconv: padded filters with more than 63 spatial taps (%dx%d) are not built",
                 g.FH, g.FW);
   const int Rp = (g.R + kBK - 1) / kBK * kBK;
   const bool need_pad = (g.R % kBK) != 0 || ((uintptr_t)f & 15);
@@ -448,7 +453,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   WsCarver ws;
   int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4), st);
   if (rc) return rc;
-  const int2 *taps = fwd_taps2(g, Rp);
+  const int2 *taps = fwd_taps2(g, Rp, bigTaps);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
   const float *A = f;
   int lda = g.R;
@@ -492,8 +497,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.LimH = g.H;
     a.LimW = g.W;
     a.xSampleStride = g.H * g.W * g.C;
-    a.nU = g.FH;
-    a.nV = g.FW;
+    a.nU = bigTaps ? 1 : g.FH;   // mask construction only looks at tap (0,0) then (always valid)
+    a.nV = bigTaps ? 1 : g.FW;
     a.du0 = 0;
     a.dus = g.dy;
     a.dv0 = 0;

@@ -525,6 +525,42 @@ int xm_average_update(float *w, const float *der, size_t n, float lr, float nwor
   return XM_OK;
 }
 
+// out(b, j, n) = |reim(j, b, n) + i reim(j, B + b, n)|; a 32 x 32 LDS tile transposes (j, b) so
+// that both the reads (j contiguous) and the writes (b contiguous) are coalesced
+__global__ void __launch_bounds__(256)
+spec_magnitude_kernel(const float *__restrict__ reim, float *__restrict__ out, int Wo, int B, int N) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *src = reim + (size_t)Wo * 2 * B * n;
+  for (int r = ty; r < 32; r += 8) {
+    int b = b0 + r, j = j0 + tx;
+    float v = 0.f;
+    if (b < B && j < Wo) {
+      float re = src[j + (size_t)Wo * b], im = src[j + (size_t)Wo * (B + b)];
+      v = sqrtf(re * re + im * im);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  float *dst = out + (size_t)B * Wo * n;
+  for (int r = ty; r < 32; r += 8) {
+    int j = j0 + r, b = b0 + tx;
+    if (b < B && j < Wo) dst[b + (size_t)B * j] = tile[tx][r];
+  }
+}
+
+int xm_spec_magnitude(const float *reim, int Wo, int B, int N, float *out, void *stream) {
+  if (Wo <= 0 || B <= 0 || N <= 0) return fail(XM_EINVAL, "spec_magnitude: empty input");
+  if (N > 65535) return fail(XM_ETOOBIG, "spec_magnitude: more than 65535 clips per call");
+  if (too_big(Wo, 2 * B, N)) return fail(XM_ETOOBIG, "spec_magnitude: tensor too large");
+  if (!reim || !out) return fail(XM_EINVAL, "spec_magnitude: NULL tensor");
+  hipLaunchKernelGGL(spec_magnitude_kernel, dim3((Wo + 31) / 32, (B + 31) / 32, N), dim3(256), 0,
+                     (hipStream_t)stream, reim, out, Wo, B, N);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream) {
   if (H <= 0 || W <= 1 || N <= 0) return fail(XM_EINVAL, "spec_rownorm: need H>0, W>1, N>0");
   if (!spec || !out) return fail(XM_EINVAL, "spec_rownorm: NULL tensor");

@@ -503,6 +503,17 @@ def spec_rownorm(spec):
     return out
 
 
+def spec_magnitude(reim):
+    """|Re + i Im| of the framing convolution's output: 1 x Wo x 2B x N -> B x Wo x 1 x N."""
+    reim = _chk(reim, "REIM")
+    H, Wo, C2, N = _shape4(reim)
+    if H != 1 or C2 % 2:
+        raise ValueError("spec_magnitude: expected a 1 x Wo x 2B x N tensor")
+    out = mat_empty(C2 // 2, Wo, 1, N, device=reim.device)
+    _lib.check(_L().xm_spec_magnitude(_ptr(reim), Wo, C2 // 2, N, _ptr(out), _stream()))
+    return out
+
+
 def aggregate_logits(frame_logits, first, last, agg="max"):
     """frame_logits F x E (column-major), first/last int32 device vectors (1-based, inclusive).
     Returns (logitTarget 1 x 1 x E x N, maxLabel 1 x 1 x 1 x N)."""

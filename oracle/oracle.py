@@ -280,6 +280,25 @@ def spec_rownorm(spec):
     return out.reshape(np.shape(spec), order="F")
 
 
+def run_spec(z, fs=16000, Tw=25, Ts=10, alpha=0.97, nfft=1024):
+    """runSpec [EXT, a-nagrani/VGGVox, un-vendored; restated from the VGGVox paper]: pre-emphasis
+    y[t] = z[t] - alpha z[t-1], frames of Nw = Tw ms every Ns = Ts ms (no padding), symmetric Hamming
+    window, |FFT_nfft|, bins 1..nfft/2 kept (512 x W).  z: L or L x N samples.  float64 throughout."""
+    z = np.asarray(z, np.float64)
+    if z.ndim == 1:
+        z = z[:, None]
+    Nw, Ns = int(round(1e-3 * Tw * fs)), int(round(1e-3 * Ts * fs))
+    y = z.copy()
+    y[1:] -= alpha * z[:-1]
+    W = (z.shape[0] - Nw) // Ns + 1
+    win = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(Nw) / (Nw - 1))
+    out = np.zeros((nfft // 2, W, 1, z.shape[1]), np.float32, order="F")
+    for n in range(z.shape[1]):
+        fr = np.stack([y[j * Ns:j * Ns + Nw, n] * win for j in range(W)], 1)   # Nw x W
+        out[:, :, 0, n] = np.abs(np.fft.fft(fr, nfft, axis=0))[:nfft // 2]
+    return out
+
+
 def time2idx(t):
     return lib().orc_time2idx(float(t))
 

@@ -170,6 +170,16 @@ def test_batch_provider(gpu):
         ref = O.aggregate_logits(imdb.wavLogits[k], s, e, "max")
         rng.integers(0, 2 ** 31) if k == 7 else None
         assert np.abs(lg[:, k] - ref).max() < 1e-6
+    # waveform path: crop -> runSpec -> row normalisation, against the oracle's float64 FFT
+    rng = np.random.default_rng(1)
+    inp2 = batch.getBatchEmoVoxCeleb(imdb, [2, 5], imageSize=(512, 100), rng=rng, use_wav=True)
+    rng = np.random.default_rng(1)
+    for k, ii in enumerate([2, 5]):
+        L = int(batch.aud_samples(100))
+        wr = int(rng.integers(0, max(int(imdb.num_samples[ii]) - L, 0) + 1))
+        w = imdb.device_wav(ii, inp2[1].device)[wr:wr + L].cpu().numpy()
+        ref = O.spec_rownorm(O.run_spec(w))
+        close(vl.to_numpy(inp2[1])[:, :, 0, k], ref[:, :, 0, 0], 1e-3, "wav front-end sample %d" % k)
     faces = batch.getImageBatch(4)
     f = vl.to_numpy(faces)
     assert f.shape == (224, 224, 3, 4)

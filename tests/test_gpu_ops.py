@@ -297,6 +297,24 @@ def test_losses(gpu):
         close(got, (e / e.sum(1, keepdims=True)).astype(np.float32), 1e-6, "softmaxt dim 2")
 
 
+def test_run_spec_front_end(gpu):
+    """batch.runSpec (STFT as one strided convolution + magnitude kernel) vs the float64 FFT restatement;
+    widths follow audSamp (getBatchEmoVoxCeleb.m:67-68): 48384 samples -> 512 x 300."""
+    from mcncrossmodalemotions_amd import batch as xbatch, vl
+    rng = np.random.default_rng(51)
+    for L, N in ((int(xbatch.aud_samples(100)), 3), (48384, 2), (400, 1), (1000, 2)):
+        z = O.F(rng.standard_normal((L, N)) * 0.1)
+        ref = O.run_spec(z)
+        got = vl.to_numpy(xbatch.runSpec(vl.from_numpy(z)))
+        assert got.shape == ref.shape and ref.shape[0] == 512
+        close(got, ref, 1e-4, "runSpec L=%d" % L)
+    assert O.run_spec(np.zeros(48384)).shape[1] == 300
+    # the whole student front-end: crop -> runSpec -> per-row normalisation
+    z = O.F(rng.standard_normal((48384, 2)) * 0.1)
+    got = vl.to_numpy(vl.spec_rownorm(xbatch.runSpec(vl.from_numpy(z))))
+    close(got, O.spec_rownorm(O.run_spec(z)), 1e-3, "rownorm(runSpec)")
+
+
 def test_class_stats(gpu):
     """xm_class_stats (dagnn.ErrorStats bookkeeping): accumulates per-class hits / population."""
     from mcncrossmodalemotions_amd import vl

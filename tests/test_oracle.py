@@ -239,3 +239,18 @@ def test_regression_losses_match_torch():
         assert np.abs(g[0, 0].T - xt.grad.numpy()).max() < 1e-6
         assert abs(O.vl_nnregloss(x, t, kind=kind, sigma=sigma) -
                    O.vl_nnregloss(x, t, kind=kind, sigma=sigma, instance_weights=np.ones(5))) < 1e-6
+
+
+def test_run_spec_restatement_properties():
+    """oracle runSpec [EXT]: a pure tone lands in the right bin, widths follow audSamp, pre-emphasis gain."""
+    fs = 16000
+    assert O.run_spec(np.zeros(int(O.aud_samples(300)))).shape == (512, 300, 1, 1)
+    assert O.run_spec(np.zeros(int(O.aud_samples(400)))).shape == (512, 400, 1, 1)
+    t = np.arange(8000) / fs
+    f0 = 2000.0
+    S = O.run_spec(np.sin(2 * np.pi * f0 * t))
+    assert abs(int(S[:, 10, 0, 0].argmax()) - round(f0 / fs * 1024)) <= 1
+    # DC is removed by the pre-emphasis up to 1 - alpha
+    D = O.run_spec(np.ones(4000))
+    win_sum = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(400) / 399)).sum()
+    assert abs(D[0, 5, 0, 0] - 0.03 * win_sum) < 1e-3

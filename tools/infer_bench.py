@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""variable-width student inference (external/compute_audio_feats.m) on synthetic clips.
+usage: python tools/infer_bench.py [--clips 256]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from mcncrossmodalemotions_amd import external, zoo
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--clips", type=int, default=256)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(0)
+net = zoo.emoVoxZoo(numSeconds=4, seed=200)
+g = torch.Generator(device=dev); g.manual_seed(0)
+widths = rng.integers(100, 1100, args.clips)
+specs = [torch.randn((int(T), 512), generator=g, device=dev).abs_().t() for T in widths]   # 512 x T mats
+for mode in (False, True):
+    external.compute_audio_feats(net, specs[:32], batch_by_bucket=mode)   # warm-up: tile tuning per shape
+    external.compute_audio_feats(net, specs, batch_by_bucket=mode)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = external.compute_audio_feats(net, specs, batch_by_bucket=mode)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-28s %8.1f clips/s  (%d clips, widths 100..1099, %.1f ms total)" % (
+        "bucket-batched" if mode else "one clip per eval (reference)", args.clips / dt, args.clips, dt * 1e3))
