@@ -214,6 +214,12 @@ int xm_class_stats(const float *x, const float *labels, int C, int N, float *cor
  * avg3 is a HOST pointer to the three per-channel means (meta.normalization.averageImage). */
 int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,
                       void *stream);
+/* getImageBatch from decoded frames (fetch_emovoxceleb_imdb.m:152-193): centred crop of relative size
+ * `crop` (1/1.6), bilinear resample to Ho x Wo (pixel-centre aligned, edge clamped, rounded to uint8 as
+ * `uint8(data{1})` does), rgb2gray, replicate x3, minus averageImage -- one pass.
+ * src: Hin x Win x 3 x N with values 0..255 (single holding the decoded uint8); avg3: HOST pointer. */
+int xm_crop_resize_face(const float *src, int Hin, int Win, int N, float crop, int Ho, int Wo,
+                        const float *avg3, float *out, void *stream);
 
 #ifdef __cplusplus
 }

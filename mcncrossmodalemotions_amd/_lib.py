@@ -61,6 +61,7 @@ SIGNATURES = {
     "xm_max_label": [c_fp, _i, _i, c_fp, _vp],
     "xm_class_stats": [c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],
     "xm_normalize_face": [c_fp, _i, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
+    "xm_crop_resize_face": [c_fp, _i, _i, _i, _f, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
 }
 _RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
 # test hooks (not part of include/xmodal.h)

@@ -183,12 +183,17 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
 
 
 def getImageBatch(num, imageSize=(224, 224), averageImage=(131.0912, 103.8827, 91.4953), seed=1,
-                  device=None):
+                  device=None, frameSize=None):
     """fetch_emovoxceleb_imdb.m:152-193 on synthetic frames: uint8-valued RGB -> rgb2gray ->
-    replicate x3 -> minus the per-channel averageImage."""
+    replicate x3 -> minus the per-channel averageImage.  With `frameSize` = (Hin, Win) the frames are
+    "decoded" at that size and go through the fused centre-crop(1/1.6) + bilinear-resize kernel first
+    (the vl_imreadjpeg arguments of :161-167)."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    if frameSize is not None:
+        raw = torch.randint(0, 256, (num, 3, frameSize[1], frameSize[0]), generator=g, device=device)
+        return vl.crop_resize_face(raw.to(torch.float32).permute(3, 2, 1, 0), averageImage, imageSize)
     rgb = torch.randint(0, 256, (num, 3, imageSize[1], imageSize[0]), generator=g, device=device)
     rgb = rgb.to(torch.float32).permute(3, 2, 1, 0)
     return vl.normalize_face(rgb, averageImage)

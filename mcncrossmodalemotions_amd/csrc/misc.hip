@@ -603,6 +603,55 @@ int xm_class_stats(const float *x, const float *labels, int C, int N, float *cor
   return XM_OK;
 }
 
+__device__ __forceinline__ float bilin_u8(const float *__restrict__ p, int H, int W, double y, double x) {
+  y = fmin(fmax(y, 0.0), (double)(H - 1));
+  x = fmin(fmax(x, 0.0), (double)(W - 1));
+  int y0 = (int)floor(y), x0 = (int)floor(x);
+  int y1 = y0 + 1 < H ? y0 + 1 : y0, x1 = x0 + 1 < W ? x0 + 1 : x0;
+  double fy = y - y0, fx = x - x0;
+  double v = (1 - fy) * ((1 - fx) * p[y0 + (size_t)H * x0] + fx * p[y0 + (size_t)H * x1]) +
+             fy * ((1 - fx) * p[y1 + (size_t)H * x0] + fx * p[y1 + (size_t)H * x1]);
+  v = floor(v + 0.5);
+  return (float)fmin(fmax(v, 0.0), 255.0);
+}
+
+// coordinates in double: the oracle's arithmetic, so the uint8 rounding lands on the same side
+__global__ void crop_resize_face_kernel(const float *__restrict__ src, float *__restrict__ out, int Hin,
+                                        int Win, int N, double ch, double cw, double h0, double w0, int Ho,
+                                        int Wo, float a0, float a1, float a2) {
+  size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t HWo = (size_t)Ho * Wo;
+  if (idx >= HWo * N) return;
+  int n = (int)(idx / HWo);
+  size_t q = idx - (size_t)n * HWo;
+  int j = (int)(q / Ho), i = (int)(q - (size_t)j * Ho);
+  double y = (i + 0.5) * ch / Ho - 0.5 + h0, x = (j + 0.5) * cw / Wo - 0.5 + w0;
+  const size_t HWi = (size_t)Hin * Win;
+  const float *p = src + HWi * 3 * n;
+  float r = bilin_u8(p, Hin, Win, y, x), g = bilin_u8(p + HWi, Hin, Win, y, x),
+        b = bilin_u8(p + 2 * HWi, Hin, Win, y, x);
+  float gr = fminf(floorf(0.2989f * r + 0.5870f * g + 0.1140f * b + 0.5f), 255.f);
+  float *o = out + q + HWo * 3 * n;
+  o[0] = gr - a0;
+  o[HWo] = gr - a1;
+  o[2 * HWo] = gr - a2;
+}
+
+int xm_crop_resize_face(const float *src, int Hin, int Win, int N, float crop, int Ho, int Wo,
+                        const float *avg3, float *out, void *stream) {
+  if (Hin <= 0 || Win <= 0 || N <= 0 || Ho <= 0 || Wo <= 0) return fail(XM_EINVAL, "crop_resize_face: empty input");
+  if (!(crop > 0.f) || crop > 1.f) return fail(XM_EINVAL, "crop_resize_face: crop must be in (0, 1]");
+  if (!src || !avg3 || !out) return fail(XM_EINVAL, "crop_resize_face: NULL tensor");
+  if (too_big(Hin, Win, 3, N) || too_big(Ho, Wo, 3, N)) return fail(XM_ETOOBIG, "crop_resize_face: tensor too large");
+  const double ch = (double)crop * Hin, cw = (double)crop * Win;
+  size_t n = (size_t)Ho * Wo * N;
+  hipLaunchKernelGGL(crop_resize_face_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, out, Hin, Win, N, ch, cw, 0.5 * (Hin - ch), 0.5 * (Win - cw), Ho,
+                     Wo, avg3[0], avg3[1], avg3[2]);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 int xm_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out,
                       void *stream) {
   if (H <= 0 || W <= 0 || N <= 0) return fail(XM_EINVAL, "normalize_face: empty input");

@@ -551,6 +551,20 @@ def class_stats(x, labels, correct, population):
     _lib.check(_L().xm_class_stats(_ptr(x), _ptr(labels), Cc, N, _ptr(correct), _ptr(population), _stream()))
 
 
+def crop_resize_face(src, average_image, image_size=(224, 224), crop=1 / 1.6):
+    """getImageBatch of fetch_emovoxceleb_imdb.m:152-193 from decoded frames (Hin x Win x 3 x N, values
+    0..255): centre crop 1/1.6 -> bilinear resize -> uint8 -> grey -> x3 -> minus averageImage, fused."""
+    src = _chk(src, "SRC")
+    Hin, Win, c3, N = _shape4(src)
+    if c3 != 3:
+        raise ValueError("crop_resize_face: expected Hin x Win x 3 x N")
+    avg = (C.c_float * 3)(*[float(v) for v in np.ravel(average_image)[:3]])
+    out = mat_empty(int(image_size[0]), int(image_size[1]), 3, N, device=src.device)
+    _lib.check(_L().xm_crop_resize_face(_ptr(src), Hin, Win, N, float(crop), int(image_size[0]),
+                                        int(image_size[1]), avg, _ptr(out), _stream()))
+    return out
+
+
 def normalize_face(rgb, average_image):
     """fetch_emovoxceleb_imdb.m:176-193: grey -> x3 -> minus averageImage; rgb H x W x 3 x N."""
     rgb = _chk(rgb, "RGB")

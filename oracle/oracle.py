@@ -316,6 +316,16 @@ def aggregate_logits(lg, first, last, agg="max"):
     return out
 
 
+def crop_resize_face(src, avg3, image_size=(224, 224), crop=1 / 1.6):
+    src = F(src)
+    Hin, Win, c3, N = _shape4(src)
+    a = F(np.ravel(avg3)[:3])
+    out = np.zeros((image_size[0], image_size[1], 3, N), np.float32, order="F")
+    lib().orc_crop_resize_face(_p(src), Hin, Win, N, C.c_double(crop), int(image_size[0]), int(image_size[1]),
+                               _p(a), _p(out))
+    return out
+
+
 def normalize_face(rgb, avg3):
     rgb = F(rgb)
     H, W, c3, N = _shape4(rgb)

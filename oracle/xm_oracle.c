@@ -831,6 +831,46 @@ void orc_aggregate_logits(const float *lg, int F, int E, int first, int last, in
 
 /* fetch_emovoxceleb_imdb.m:176-193: rgb2gray -> replicate x3 -> subtract averageImage(c).
  * rgb: H x W x 3 x N uint8-valued floats. rgb2gray weights 0.2989/0.5870/0.1140, rounded (uint8). */
+/*
+ * getImageBatch of fetch_emovoxceleb_imdb.m:152-193 from decoded frames: vl_imreadjpeg(..., 'CropSize',
+ * 1/1.6, 'CropLocation', 'center', 'Interpolation', 'bilinear', 'Resize', imageSize) -> uint8 -> rgb2gray
+ * -> x3 -> minus averageImage.  [EXT] vl_imreadjpeg's resampler is not in the reference tree; restated as:
+ * crop window = centred (crop*Hin) x (crop*Win) box, output pixel (i, j) samples the window at its
+ * pixel centre ((i + 0.5) * ch / Ho - 0.5 + h0), bilinear with edge clamping, value rounded to uint8.
+ * src: Hin x Win x 3 x N, values 0..255 (float holding uint8); out: Ho x Wo x 3 x N.
+ */
+static float orc_bilin(const float *p, int H, int W, double y, double x) {
+  if (y < 0) y = 0;
+  if (x < 0) x = 0;
+  if (y > H - 1) y = H - 1;
+  if (x > W - 1) x = W - 1;
+  int y0 = (int)floor(y), x0 = (int)floor(x);
+  int y1 = y0 + 1 < H ? y0 + 1 : y0, x1 = x0 + 1 < W ? x0 + 1 : x0;
+  double fy = y - y0, fx = x - x0;
+  double v = (1 - fy) * ((1 - fx) * p[y0 + (size_t)H * x0] + fx * p[y0 + (size_t)H * x1]) +
+             fy * ((1 - fx) * p[y1 + (size_t)H * x0] + fx * p[y1 + (size_t)H * x1]);
+  v = floor(v + 0.5);
+  return (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+void orc_crop_resize_face(const float *src, int Hin, int Win, int N, double crop, int Ho, int Wo,
+                          const float *avg3, float *out) {
+  const double ch = crop * Hin, cw = crop * Win;
+  const double h0 = 0.5 * (Hin - ch), w0 = 0.5 * (Win - cw);
+  const size_t HWi = (size_t)Hin * Win, HWo = (size_t)Ho * Wo;
+  for (int n = 0; n < N; ++n)
+    for (int j = 0; j < Wo; ++j)
+      for (int i = 0; i < Ho; ++i) {
+        double y = (i + 0.5) * ch / Ho - 0.5 + h0, x = (j + 0.5) * cw / Wo - 0.5 + w0;
+        const float *p = src + HWi * 3 * n;
+        float r = orc_bilin(p, Hin, Win, y, x), g = orc_bilin(p + HWi, Hin, Win, y, x),
+              b = orc_bilin(p + 2 * HWi, Hin, Win, y, x);
+        float gr = floorf(0.2989f * r + 0.5870f * g + 0.1140f * b + 0.5f);
+        if (gr > 255.f) gr = 255.f;
+        for (int c = 0; c < 3; ++c) out[i + (size_t)Ho * j + HWo * (c + 3 * (size_t)n)] = gr - avg3[c];
+      }
+}
+
 void orc_normalize_face(const float *rgb, int H, int W, int N, const float *avg3, float *out) {
   size_t HW = (size_t)H * W;
   for (int n = 0; n < N; ++n)

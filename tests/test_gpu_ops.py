@@ -315,6 +315,27 @@ def test_run_spec_front_end(gpu):
     close(got, O.spec_rownorm(O.run_spec(z)), 1e-3, "rownorm(runSpec)")
 
 
+def test_crop_resize_face(gpu):
+    """xm_crop_resize_face (getImageBatch from decoded frames, fetch_emovoxceleb_imdb.m:152-193) vs oracle:
+    bit-exact (integer grey levels minus the mean)."""
+    from mcncrossmodalemotions_amd import batch as xbatch, vl
+    rng = np.random.default_rng(61)
+    avg = (131.0912, 103.8827, 91.4953)
+    for (Hin, Win, N, out) in ((358, 358, 2, (224, 224)), (300, 420, 3, (224, 224)), (64, 48, 1, (32, 40)),
+                               (224, 224, 2, (224, 224))):
+        src = O.F(rng.integers(0, 256, (Hin, Win, 3, N)))
+        got = vl.to_numpy(vl.crop_resize_face(vl.from_numpy(src), avg, out))
+        ref = O.crop_resize_face(src, avg, out)
+        assert got.shape == ref.shape
+        close(got, ref, 0, "crop+resize %dx%d" % (Hin, Win))
+    # identity geometry (crop 1, same size) reduces to normalize_face
+    src = O.F(rng.integers(0, 256, (40, 30, 3, 2)))
+    a = vl.to_numpy(vl.crop_resize_face(vl.from_numpy(src), avg, (40, 30), crop=1.0))
+    close(a, O.normalize_face(src, avg), 0, "identity geometry")
+    f = vl.to_numpy(xbatch.getImageBatch(2, frameSize=(358, 358)))
+    assert f.shape == (224, 224, 3, 2)
+
+
 def test_class_stats(gpu):
     """xm_class_stats (dagnn.ErrorStats bookkeeping): accumulates per-class hits / population."""
     from mcncrossmodalemotions_amd import vl
