@@ -54,6 +54,30 @@ def main():
     # spectrogram row normalisation (getBatchEmoVoxCeleb.m:164-169)
     sp = O.F(np.abs(rng.standard_normal((16, 12, 1, 2))) * 4)
     out.update(spec=sp, spec_norm=O.spec_rownorm(sp))
+    # ---- second fixture file (added later; separate file so that ops_small.npz stays byte-stable)
+    ext = {}
+    rng2 = np.random.default_rng(20260929)
+    xr, tr = O.F(rng2.standard_normal((1, 1, 8, 6)) * 2), O.F(rng2.standard_normal((1, 1, 8, 6)) * 2)
+    wr = O.F(rng2.uniform(0.5, 2, (1, 1, 1, 6)))
+    one = np.ones(1, np.float32)
+    ext.update(reg_x=xr, reg_t=tr, reg_w=wr,
+               euclid_y=np.float32(O.vl_nnregloss(xr, tr, kind="euclidean", instance_weights=wr)),
+               euclid_dx=O.vl_nnregloss(xr, tr, one, kind="euclidean", instance_weights=wr),
+               huber_y=np.float32(O.vl_nnregloss(xr, tr, kind="huber", sigma=1.0, instance_weights=wr)),
+               huber_dx=O.vl_nnregloss(xr, tr, one, kind="huber", sigma=1.0, instance_weights=wr))
+    xs, ds = O.F(rng2.standard_normal((2, 3, 8, 2)) * 2), O.F(rng2.standard_normal((2, 3, 8, 2)))
+    ext.update(sm_x=xs, sm_dzdy=ds, sm_y=O.vl_nnsoftmaxt(xs, 1.0), sm_dx=O.vl_nnsoftmaxt_backward(xs, ds, 1.0))
+    z = O.F(rng2.standard_normal((400 + 160 * 9, 2)) * 0.1)                # 10 analysis frames per clip
+    ext.update(wav=z, wav_spec=O.run_spec(z))
+    face = O.F(rng2.integers(0, 256, (96, 80, 3, 2)))
+    ext.update(face_src=face, face_out=O.crop_resize_face(face, (131.0912, 103.8827, 91.4953), (56, 56)))
+    fl = O.F(rng2.standard_normal((23, 8)) * 3)
+    ext.update(agg_logits=fl, agg_first=np.array([1, 4, 9], np.int32), agg_last=np.array([3, 9, 23], np.int32))
+    for k, (a, b) in enumerate(zip(ext["agg_first"], ext["agg_last"])):
+        ext["agg_max_%d" % k] = O.aggregate_logits(fl, int(a), int(b), "max")
+        ext["agg_mean_%d" % k] = O.aggregate_logits(fl, int(a), int(b), "mean")
+    np.savez_compressed(os.path.join(HERE, "ops_extra.npz"), **ext)
+    print("wrote", os.path.join(HERE, "ops_extra.npz"), sum(v.nbytes for v in ext.values()), "bytes raw")
     np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **out)
     print("wrote", os.path.join(HERE, "ops_small.npz"), sum(v.nbytes for v in out.values()), "bytes raw")
 

@@ -254,3 +254,17 @@ def test_run_spec_restatement_properties():
     D = O.run_spec(np.ones(4000))
     win_sum = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(400) / 399)).sum()
     assert abs(D[0, 5, 0, 0] - 0.03 * win_sum) < 1e-3
+
+
+def test_golden_extra_fixtures():
+    """tests/golden/ops_extra.npz (regression losses, softmax derivative, runSpec, face crop/resize,
+    logit aggregation) still comes out of the oracle."""
+    E = np.load(os.path.join(os.path.dirname(GOLD), "ops_extra.npz"))
+    one = np.ones(1, np.float32)
+    assert abs(O.vl_nnregloss(E["reg_x"], E["reg_t"], kind="euclidean", instance_weights=E["reg_w"]) - E["euclid_y"]) < 1e-6
+    assert np.abs(O.vl_nnregloss(E["reg_x"], E["reg_t"], one, kind="huber", instance_weights=E["reg_w"]) - E["huber_dx"]).max() < 1e-7
+    assert np.abs(O.vl_nnsoftmaxt_backward(E["sm_x"], E["sm_dzdy"], 1.0) - E["sm_dx"]).max() < 1e-7
+    assert np.abs(O.run_spec(E["wav"]) - E["wav_spec"]).max() < 1e-6
+    assert np.array_equal(O.crop_resize_face(E["face_src"], (131.0912, 103.8827, 91.4953), (56, 56)), E["face_out"])
+    for k, (a, b) in enumerate(zip(E["agg_first"], E["agg_last"])):
+        assert np.array_equal(O.aggregate_logits(E["agg_logits"], int(a), int(b), "max"), E["agg_max_%d" % k])
