@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=1,
                     help="distill: face frames per pair; F > 1 runs the teacher on nb*F faces and max-aggregates "
                          "their logits per pair (getBatchEmoVoxCeleb.m:145-158,179-185; SURVEY 8f row 1)")
+    ap.add_argument("--overlap-allreduce", type=int, default=1,
+                    help="1: fc6-8 gradient bucket all-reduced while the rest of the backward pass runs (N > 1)")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream, no overlap anywhere (what the roofline leg and the rocprof profile use: "
                          "kernel durations are then those of isolated kernels)")
@@ -92,6 +94,10 @@ def pmc_traffic(kernel):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    # main + wgrad + teacher streams + RCCL's: more than the default 4 hardware queues, see the package
+    # __init__ (without this the stream overlap is serialised as soon as a process group exists)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from mcncrossmodalemotions_amd import _lib, vl, zoo, train, batch as xbatch, dagnn
@@ -103,8 +109,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("XM_DEBUG_DIST") in ("1", "2")   # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     L = _lib.load()
 
@@ -131,6 +139,9 @@ def main():
         student.pack_params()
     parserv = train.ParameterServer(args.parserv)
     parserv.start()
+    if force_dist and os.environ.get("XM_DEBUG_DIST") == "1":
+        parserv.force = True
+    parserv.overlap = bool(args.overlap_allreduce)
     opts = train.TrainOpts(batchSize=nb * world)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------

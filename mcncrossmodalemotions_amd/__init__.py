@@ -7,6 +7,16 @@ Layout:
     dagnn.py   host-side mirror of dagnn.DagNN / dagnn.Layer (eval, forward/backward)
     zoo.py     emoVoxZoo / ferPlusZoo mirrors (student and teacher graphs)
     batch.py   getBatchEmoVoxCeleb / getImageBatch mirrors on synthetic data
-    train.py   cnn_train_dag step mirror (SGD + ParameterServer -> RCCL all-reduce)
+    train.py   cnn_train_dag mirror (SGD + ParameterServer -> RCCL all-reduce, bucketed + overlapped)
+    run_distillation.py / external.py   the reference's entry points (driver, feature extraction)
 """
+import os as _os
+
+# The step runs on 3-4 HIP streams (main, wgrad side stream, teacher stream, RCCL's own).  ROCm maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has taken its queues the compute
+# streams start sharing one and the overlap is silently serialised (measured: 3380 -> 3080 pairs/s as soon
+# as a process group exists).  Must be set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 __version__ = "0.1.0"

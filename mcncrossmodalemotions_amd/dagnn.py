@@ -442,6 +442,8 @@ class DagNN:
         self.accumulateParamDers = False
         self.fuse = True  # MI355X peephole fusion (results identical)
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
+        self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
+                                 # derivatives were enqueued, on the stream they were enqueued on
         self._side_pending = False
         self.device = None
         self._flat = None
@@ -740,6 +742,8 @@ class _Step:
             if side is None:
                 dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
                                               der_out=net._direct_der(r), skip_db=skip_db)
+                if net.gradHook is not None:
+                    net.gradHook(r.name)
             else:
                 # dzdw / dzdb are off the critical path of the backward pass: they run on the side
                 # stream next to the (HBM-bound) bnorm / pooling derivatives of the layers below
@@ -748,6 +752,8 @@ class _Step:
                 with torch.cuda.stream(side):
                     _, dpar = r.block.backward(ins, self._params(net), douts, need_dx=False,
                                                der_out=net._direct_der(r), skip_db=skip_db)
+                    if net.gradHook is not None:
+                        net.gradHook(r.name)
                 douts[0].record_stream(side)
                 net._side_pending = True
                 dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False)

@@ -58,8 +58,11 @@ class ParameterServer:
             _lib.check(L.xm_comm_init(C.c_char_p(raw), self.rank, self.world))
         self._started = True
 
+    force = False  # debugging: run the collective even with a single worker
+    overlap = True  # 'torch' backend: bucketed exchange overlapped with the backward pass (GradBuckets)
+
     def allreduce_(self, flat):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.backend == "rccl-capi":
             _lib.check(_lib.load().xm_allreduce_sum_f32(C.c_void_p(flat.data_ptr()), flat.numel(),
@@ -71,6 +74,61 @@ class ParameterServer:
     def stop(self):
         if self.backend == "rccl-capi" and self.world > 1:
             _lib.check(_lib.load().xm_comm_destroy())
+
+
+class GradBuckets:
+    """Overlapped gradient exchange: the filters of the last FC layers are 82 % of the
+    student's gradient bytes (fc6 37.7 MB + fc7 16.8 MB of 66.6 MB) and their derivatives are the FIRST
+    to be ready in the backward pass.  They form one contiguous range of the flat buffer (the tail of the
+    filter segment), which is all-reduced asynchronously as soon as the earliest of those layers has
+    enqueued its wgrad -- the rest of the backward pass (conv5 ... conv1, ~4 ms) hides it.  The
+    remainder (conv filters, biases, BN parameters and moments) goes out after the backward pass.
+    Same sums as one all-reduce over the whole buffer: every element is reduced exactly once."""
+
+    def __init__(self, net, early_layers=("fc6", "fc7", "fc8")):
+        flat = net._flat
+        total = int(flat.der.numel())
+        recs = [net.getLayer(n) for n in early_layers]
+        recs = [r for r in recs if r is not None]
+        self.early = None
+        self.trigger = None
+        if recs:
+            ps = [net.params[r.params[0]] for r in recs]
+            a = min(p._flat_off for p in ps)
+            b = max(p._flat_off + (int(p.value.numel()) + 3) // 4 * 4 for p in ps)
+            inside = {id(q) for q in net.params.values() if a <= getattr(q, "_flat_off", -1) < b}
+            if inside == {id(p) for p in ps}:          # nothing else lives inside the range
+                self.early = (a, b)
+                order = {l.name: i for i, l in enumerate(net.layers)}
+                self.trigger = min((r.name for r in recs), key=lambda n: order[n])   # its backward runs last
+        self.rest = [(0, total)] if self.early is None else [(0, self.early[0]), (self.early[1], total)]
+        self.rest = [(a, b) for a, b in self.rest if b > a]
+        self.handles = []
+        self.flat = flat
+
+    def ranges(self):
+        return ([self.early] if self.early else []) + self.rest
+
+    def begin(self):
+        self.handles = []
+
+    def on_layer(self, name):
+        if name == self.trigger:
+            import torch.distributed as dist
+            a, b = self.early
+            self.handles.append(dist.all_reduce(self.flat.der[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        import torch.distributed as dist
+        if self.early is not None and not self.handles:       # trigger layer absent from this pass
+            self.rest_all = [self.early] + self.rest
+        else:
+            self.rest_all = self.rest
+        for a, b in self.rest_all:
+            dist.all_reduce(self.flat.der[a:b], op=dist.ReduceOp.SUM)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
 
 
 def shard_batch(batch, rank, world):
@@ -96,9 +154,21 @@ def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, inpu
     if net._flat is None:
         net.pack_params()
     net.mode = "normal"
-    net.eval(inputs, opts.derOutputs, input_events=input_events)
     world = parserv.world if parserv is not None else 1
-    if parserv is not None and world > 1:
+    exchange = parserv is not None and (world > 1 or parserv.force)
+    buckets = None
+    if exchange and parserv.backend == "torch" and parserv.overlap:
+        buckets = net.__dict__.get("_grad_buckets")
+        if buckets is None or buckets.flat is not net._flat:
+            buckets = net.__dict__["_grad_buckets"] = GradBuckets(net)
+        buckets.begin()
+        net.gradHook = buckets.on_layer
+    else:
+        net.gradHook = None
+    net.eval(inputs, opts.derOutputs, input_events=input_events)
+    if buckets is not None:
+        buckets.finish()
+    elif exchange:
         parserv.allreduce_(net._flat.der)
     lr = float(opts.learningRate[min(epoch, len(opts.learningRate) - 1)])
     accumulate_gradients(net, opts, lr, global_batch or opts.batchSize, world)

@@ -325,3 +325,56 @@ def test_compute_visual_feats_splits_tracks(gpu):
     for t, f in zip(tracks, feats):
         V = oracle_net.forward(onet, {"data": t}, P0, mode="test")
         close(f, V["prediction"].reshape(8, -1, order="F").T, 1e-4, "track logits")
+
+
+def test_bucketed_gradient_exchange(gpu):
+    """train.GradBuckets: the early bucket is exactly the fc6-8 filter range, the ranges tile the
+    flat buffer once, and a step with the overlapped exchange (single-rank RCCL group: the collective is an
+    identity) leaves bit-identical parameters to a step with one exchange at the end / no exchange."""
+    import torch
+    import torch.distributed as dist
+    from mcncrossmodalemotions_amd import train, vl, zoo
+    net = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
+    net.pack_params()
+    bk = train.GradBuckets(net)
+    total = int(net._flat.der.numel())
+    rs = sorted(bk.ranges())
+    assert rs[0][0] == 0 and rs[-1][1] == total and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+    f6, f8 = net.params["fc6f"], net.params["fc8f"]
+    assert bk.early == (f6._flat_off, f8._flat_off + (int(f8.value.numel()) + 3) // 4 * 4)
+    assert bk.trigger == "fc6"
+    full = zoo.emoVoxZoo(numSeconds=3, seed=1)       # full width: the early bucket carries 82 % of the bytes
+    full.pack_params()
+    bf = train.GradBuckets(full)
+    assert 0.80 < (bf.early[1] - bf.early[0]) / float(full._flat.der.numel()) < 0.84
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:29571",
+                                device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(5)
+        x = O.F(rng.standard_normal((512, 100, 1, 4)))
+        lg = O.F(rng.standard_normal((1, 1, 8, 4)) * 3)
+        res = []
+        for mode in ("none", "end", "overlap", "overlap+side"):
+            n = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
+            n.pack_params()
+            if mode == "overlap+side":
+                n.wgradStream = torch.cuda.Stream()
+            ps = None
+            if mode != "none":
+                ps = train.ParameterServer("torch")
+                ps.start()
+                ps.force = True
+                ps.overlap = mode.startswith("overlap")
+            opts = train.TrainOpts(batchSize=4)
+            xd, lgd = vl.from_numpy(x), vl.from_numpy(lg)
+            for it in range(3):
+                train.train_step(n, ["data", xd, "logitTarget", lgd, "maxLabel", vl.max_label(lgd)], opts, it, ps, 4)
+            torch.cuda.synchronize()
+            res.append(n._flat.val.clone())
+        for r in res[1:]:
+            assert torch.equal(res[0], r)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
