@@ -373,10 +373,15 @@ def main():
             "model_frac_of_fp32_mfma_peak": round(value / world * gflop_unit / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    # tear the process group down BEFORE printing: RCCL writes its banner / teardown lines to stdout
+    # and the contract line must be the last thing rank 0 prints
+    if dist.is_initialized():
+        torch.cuda.synchronize()
         parserv.stop()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(wl, pairs, W):
