@@ -356,16 +356,34 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   return bi;
 }
 
-static void launch_wgrad_cfg(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
+template <int AV>
+static void launch_wgrad_av(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
   dim3 block(256);
   switch (ci) {
-    case 0: hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 1, 4>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, 1, 4>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, 2>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 4, 1>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 4>), grid, block, 0, st, a); break;
+    case 0: hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2, AV>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 1, 4, AV>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, 1, 4, AV>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((conv_wgrad_kernel<1, 2, 2, 2, AV>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2, AV>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 4, 1, AV>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 4, AV>), grid, block, 0, st, a); break;
+  }
+}
+
+// dY staging width: 4 / 2 consecutive pixels per load when groups cannot straddle two samples
+// (Ho*Wo % AV == 0) and the rows are AV*4-byte aligned
+static int wgrad_av(const WgradArgs &a) {
+  const int hw = a.Ho * a.Wo;
+  const uintptr_t p = (uintptr_t)a.dY;
+  if (hw % 4 == 0 && (p & 15) == 0) return 4;
+  if (hw % 2 == 0 && (p & 7) == 0) return 2;
+  return 1;
+}
+static void launch_wgrad_cfg(int ci, const WgradArgs &a, dim3 grid, hipStream_t st) {
+  switch (wgrad_av(a)) {
+    case 4: launch_wgrad_av<4>(ci, a, grid, st); break;
+    case 2: launch_wgrad_av<2>(ci, a, grid, st); break;
+    default: launch_wgrad_av<1>(ci, a, grid, st); break;
   }
 }
 
@@ -759,7 +777,8 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
     a.nkt = nkt;
     a.splitStride = slab;
     {
-      ProfScope ps(1 * 100 + ci * 2, 2.0 * g.Kg * (double)NP * g.R, st);
+      const int av = wgrad_av(a);
+      ProfScope ps(1 * 100 + ci * 4 + (av == 4 ? 2 : av == 2 ? 1 : 0), 2.0 * g.Kg * (double)NP * g.R, st);
       launch_wgrad_cfg(ci, a, dim3(nbm * nbn, splits), st);
     }
     XM_LAUNCH_CHECK();
@@ -865,13 +884,14 @@ int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, l
 
 // human-readable kernel name of a profiler key, matching the rocprofv3 kernel-trace name
 int xm_prof_kernel_name(int key, char *buf, int len) {
-  int kind = key / 100, ci = (key % 100) / 2, check = key % 2;
+  int kind = key / 100;
+  int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;
   if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
   const Cfg &c = kCfgs[ci];
   if (kind == 0)
-    snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, check);
+    snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, key % 2);
   else
-    snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn);
+    snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, 1 << (key % 4));
   return XM_OK;
 }
 

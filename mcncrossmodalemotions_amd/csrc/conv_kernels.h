@@ -78,6 +78,21 @@ constexpr int kNG = 4;   // float4 groups per stage (kBK / 4)
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
+// AV consecutive floats with one instruction (whole group in or out of range)
+template <int AV>
+__device__ __forceinline__ auto buf_load_v(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  if constexpr (AV == 4) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f4, v);
+  } else {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f2, v);
+  }
+}
 
 // 4x4 transpose across the 4 lanes of a quad (DPP quad_perm, full-rate VALU): on entry lane i holds
 // v[k] = element (row k, column i); on exit v[k] = element (row i, column k).
@@ -541,16 +556,24 @@ struct WgradArgs {
   size_t splitStride;
 };
 
-template <int TM, int TN, int WGM, int WGN>
+// AV = pixels per dY staging load (1, 2 or 4): the dY rows are contiguous along the pixel axis, so when
+// Ho*Wo is a multiple of AV (groups never straddle two samples) a thread loads AV consecutive pixels of
+// a row with ONE dwordx2/x4 buffer load and parks them with ONE ds_write_b64/b128 -- they are exactly
+// AV consecutive k of the LDS image [k/4][row][k%4].  4x fewer VMEM + LDS instructions on the A side.
+template <int TM, int TN, int WGM, int WGN, int AV>
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_kernel(const WgradArgs a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(BM % 16 == 0 && BN % 16 == 0, "rows are staged 16 at a time");
+  static_assert(AV == 1 || AV == 2 || AV == 4, "dY staging width");
   // plane pitch = rows*4 + 16 floats: the scalar ds_write_b32 staging stores of a wave (16 pixels
   // x 4 rows) then hit each bank at most twice (free), and ds_read_b128 stays 16-B aligned
   constexpr int PLA = BM * 4 + 16, PLB = BN * 4 + 16;
-  constexpr int NEA = BM / 16, NEB = BN / 16;  // elements per thread per stage
+  constexpr int APG = 16 / AV;             // pixel groups per 16-pixel stage (A side)
+  constexpr int ARP = 256 / APG;           // dY rows covered by one pass of the block
+  constexpr int NEA = (BM + ARP - 1) / ARP, NEB = BN / 16;  // loads per thread per stage
+  typedef float avec __attribute__((ext_vector_type(AV == 1 ? 2 : AV)));  // AV == 1 uses .x only
   __shared__ __attribute__((aligned(16))) float smem[2 * kNG * (PLA + PLB)];
   float *sA = smem;
   float *sB = smem + 2 * kNG * PLA;
@@ -572,10 +595,11 @@ conv_wgrad_kernel(const WgradArgs a) {
   // rsub + 16*j: a wave-wide load instruction then reads 4 runs of 16 consecutive pixels
   // (64 contiguous bytes each for stride 1) instead of 64 scattered addresses.
   const int px = t & 15, rsub = t >> 4;
+  const int apg = t % APG, arow = t / APG;  // A side: pixel group / first row of this thread
   unsigned arow4[NEA];  // dY byte offset of channel row j (rows >= M clamped: never stored)
 #pragma unroll
   for (int j = 0; j < NEA; ++j) {
-    int gm = min(bm * BM + rsub + 16 * j, a.M - 1);
+    int gm = min(bm * BM + arow + ARP * j, a.M - 1);
     arow4[j] = (unsigned)(gm * a.dyChanStride) * 4u;
   }
   int tpo[NEB], tpy[NEB], tpz[NEB];  // the thread's taps: byte offset, du, dv (fixed all kernel)
@@ -587,7 +611,7 @@ conv_wgrad_kernel(const WgradArgs a) {
     tpz[j] = tp.z;
   }
   // LDS: [stage][g = px/4][row][px%4]
-  float *sAw = sA + (px >> 2) * PLA + rsub * 4 + (px & 3);
+  float *sAw = sA + ((apg * AV) >> 2) * PLA + arow * 4 + ((apg * AV) & 3);
   float *sBw = sB + (px >> 2) * PLB + rsub * 4 + (px & 3);
   const int half = lane >> 5, l31 = lane & 31;
   const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
@@ -595,7 +619,8 @@ conv_wgrad_kernel(const WgradArgs a) {
 
   // two register sets, loads issued two stages ahead (see conv_gemm_kernel): the small-tile /
   // huge-reduction layers (conv1: 1.2 M pixels into a 96 x 49 filter gradient) are latency-bound
-  float ra0[NEA], rb0[NEB], ra1[NEA], rb1[NEB];
+  avec ra0[NEA], ra1[NEA];
+  float rb0[NEB], rb1[NEB];
 
 #define XM_WLOAD_TILE(KT, RA, RB)                                              \
   {                                                                            \
@@ -605,11 +630,22 @@ conv_wgrad_kernel(const WgradArgs a) {
     uint32_t wo_ = xm_div(q_, a.divHo);                                        \
     uint32_t ho_ = q_ - wo_ * a.divHo.d;                                       \
     const unsigned pm_ = (int)p_ < a.NP ? 0u : 0xFFFFFFFFu; /* past the last pixel -> 0 */ \
-    const unsigned dyo_ = ((q_ + n_ * (unsigned)a.dySampleStride) * 4u) | pm_; \
     const int hb_ = (int)ho_ * a.sy - a.pt, wb_ = (int)wo_ * a.sx - a.pl_;     \
     const unsigned xo_ = (unsigned)(hb_ + a.H * wb_ + (int)n_ * a.xSampleStride) * 4u; \
-    _Pragma("unroll") for (int j = 0; j < NEA; ++j)                            \
-      RA[j] = buf_load(dyrsrc, (arow4[j] + dyo_) | pm_);                       \
+    if (AV == 1) {                                                             \
+      const unsigned dyo_ = ((q_ + n_ * (unsigned)a.dySampleStride) * 4u) | pm_; \
+      _Pragma("unroll") for (int j = 0; j < NEA; ++j)                          \
+        RA[j].x = buf_load(dyrsrc, (arow4[j] + dyo_) | pm_);                   \
+    } else {                                                                   \
+      /* the thread's pixel group (AV consecutive pixels of one sample: Ho*Wo % AV == 0) */ \
+      uint32_t pa_ = (uint32_t)((KT) * kBK + apg * AV);                        \
+      uint32_t na_ = xm_div(pa_, a.divHW);                                     \
+      uint32_t qa_ = pa_ - na_ * a.divHW.d;                                    \
+      const unsigned pma_ = (int)pa_ < a.NP ? 0u : 0xFFFFFFF0u;                \
+      const unsigned dya_ = (qa_ + na_ * (unsigned)a.dySampleStride) * 4u;     \
+      _Pragma("unroll") for (int j = 0; j < NEA; ++j)                          \
+        RA[j] = buf_load_v<AV>(dyrsrc, (arow4[j] + dya_) | pma_);              \
+    }                                                                          \
     _Pragma("unroll") for (int j = 0; j < NEB; ++j) {                          \
       bool ok_ = ((unsigned)(hb_ + tpy[j]) < (unsigned)a.H) &                  \
                  ((unsigned)(wb_ + tpz[j]) < (unsigned)a.W);                   \
@@ -620,7 +656,12 @@ conv_wgrad_kernel(const WgradArgs a) {
 
 #define XM_WSTORE_TILE(BUF, RA, RB)                                            \
   _Pragma("unroll") for (int j = 0; j < NEA; ++j)                              \
-    sAw[(BUF) * kNG * PLA + j * 64] = RA[j];                                   \
+    if (BM % ARP == 0 || arow + ARP * j < BM) {                                \
+      if (AV == 1)                                                             \
+        sAw[(BUF) * kNG * PLA + j * ARP * 4] = RA[j].x;                        \
+      else                                                                     \
+        *reinterpret_cast<avec *>(sAw + (BUF) * kNG * PLA + j * ARP * 4) = RA[j]; \
+    }                                                                          \
   _Pragma("unroll") for (int j = 0; j < NEB; ++j)                              \
     sBw[(BUF) * kNG * PLB + j * 64] = RB[j];
 
