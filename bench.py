@@ -272,12 +272,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for it in range(args.warmup):
+    # Bounded run-ahead: the host enqueues a step in ~1.5-3 ms, the GPU needs 9-13 ms.  Left alone the
+    # host fills the HIP queues; the runtime's queue-full path then stalls launches for milliseconds
+    # while the GPU drains and idles (measured: student step 13.1 -> 15.2 ms in most processes).  Keeping
+    # at most two steps in flight costs nothing and makes the step time reproducible.
+    inflight = []
+
+    def throttled_step(it):
         step(it)
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+        if len(inflight) > 2:
+            inflight.pop(0).synchronize()
+
+    for it in range(args.warmup):
+        throttled_step(it)
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        step(args.warmup + it)
+        throttled_step(args.warmup + it)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -299,7 +313,7 @@ def main():
         torch.cuda.synchronize()
         L.xm_prof_enable(1)
         for it in range(args.steps):
-            step(args.warmup + args.steps + 1 + it)
+            throttled_step(args.warmup + args.steps + 1 + it)
         torch.cuda.synchronize()
         L.xm_prof_enable(0)
         set_serial(was_serial)

@@ -1,6 +1,7 @@
 // Process-wide context of libxmodal_hip.so: last-error text, stream-ordered scratch buffer and a
 // content-addressed cache of small read-only device tables (convolution tap tables).
 // Mirrors MatConvNet's persistent per-process context (workspace + handles), SURVEY.md 8b.
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -31,6 +32,8 @@ int ws_get(size_t bytes, void **ptr, hipStream_t stream) {
   if (bytes > w.cap) {
     // grow geometrically; a grow happens only while shapes are first seen (warm-up)
     size_t want = bytes + bytes / 4 + (1u << 20);
+    static const bool verbose = getenv("XM_WS_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[xm ws] stream %p grow %zu -> %zu\n", (void *)stream, w.cap, want);
     if (w.ptr) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) return fail(XM_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(e));
@@ -56,6 +59,8 @@ const void *cached_device_table(const void *host, size_t bytes) {
   auto it = g_tables.find(key);
   if (it != g_tables.end()) return it->second;
   void *d = nullptr;
+  static const bool verbose = getenv("XM_WS_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "[xm ws] new device table %zu bytes (#%zu)\n", bytes, g_tables.size());
   if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
   if (hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(d);

@@ -298,6 +298,45 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   return XM_OK;
 }
 
+static void launch_gemm_multi_cfg(int ci, const ConvGemmMulti &m, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  switch (ci) {
+    case 0: hipLaunchKernelGGL((conv_gemm_multi_kernel<2, 2, 2, 2>), grid, block, 0, st, m); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_multi_kernel<2, 2, 1, 4>), grid, block, 0, st, m); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_multi_kernel<3, 1, 1, 4>), grid, block, 0, st, m); break;
+    case 3: hipLaunchKernelGGL((conv_gemm_multi_kernel<1, 2, 2, 2>), grid, block, 0, st, m); break;
+    case 4: hipLaunchKernelGGL((conv_gemm_multi_kernel<1, 1, 2, 2>), grid, block, 0, st, m); break;
+    case 5: hipLaunchKernelGGL((conv_gemm_multi_kernel<1, 1, 4, 1>), grid, block, 0, st, m); break;
+    default: hipLaunchKernelGGL((conv_gemm_multi_kernel<1, 1, 1, 4>), grid, block, 0, st, m); break;
+  }
+}
+
+// up to 4 masked (MODE 1) implicit GEMMs without split-K in one launch, same tile configuration
+static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipStream_t st) {
+  const Cfg &c = kCfgs[ci];
+  ConvGemmMulti m{};
+  int maxTiles = 0;
+  double flops = 0;
+  for (size_t i = 0; i < args.size(); ++i) {
+    ConvGemmArgs a = args[i];
+    a.nbm = (a.M + c.bm() - 1) / c.bm();
+    a.nbn = (a.NP + c.bn() - 1) / c.bn();
+    a.nkt = a.Rp / kBK;
+    a.tilesPerSplit = a.nkt;
+    a.NPs = (a.NP + 3) & ~3;
+    a.slab = nullptr;
+    maxTiles = std::max(maxTiles, a.nbm * a.nbn);
+    flops += a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue;
+    m.c[i] = a;
+  }
+  {
+    ProfScope ps(2 * 100 + ci * 2, flops, st);
+    launch_gemm_multi_cfg(ci, m, dim3(maxTiles, 1, (unsigned)args.size()), st);
+  }
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int choose_cfg(long long M, long long NP, int nkt) {
   return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP, nkt);
 }
@@ -330,6 +369,7 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fallback;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
+  static const bool verbose = getenv("XM_TUNE_VERBOSE") != nullptr;
   float best = 1e30f;
   int bi = fallback;
   for (int ci = 0; ci < kNumCfg; ++ci) {
@@ -345,6 +385,7 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) tmin = std::min(tmin, ms);
     }
+    if (verbose) fprintf(stderr, " cfg%d %.3f", ci, tmin);
     if (tmin < best) {
       best = tmin;
       bi = ci;
@@ -353,6 +394,9 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   g_tuned[key] = bi;
+  if (verbose)
+    fprintf(stderr, "  -> [xm tune] kind %d M %d NP %d Rp %d (%d %d %d %d %d): cfg%d %.3f ms\n", key.kind, key.M,
+            key.NP, key.Rp, key.mode, key.a, key.b, key.c, key.d, bi, best);
   return bi;
 }
 
@@ -625,6 +669,16 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
   double pair_total = 0;
   for (const Cls &c : cls) pair_total += (double)(foldH ? 1 : c.PI) * c.PJ * g.N * c.Rc;
+  // merged launch: 2-4 classes, no filter groups, and enough tiles per class that none would be split
+  bool merge = g.G == 1 && !foldH && cls.size() >= 2 && cls.size() <= 4 && g_force_splits == 0 &&
+               getenv("XM_DGRAD_MERGE") == nullptr;
+  {
+    // the merged launch never splits K: it needs enough tiles in total to fill the chip by itself
+    long long tiles = 0;
+    for (const Cls &c : cls) tiles += (long long)((g.FC + 127) / 128) * (((long long)c.PI * c.PJ * g.N + 255) / 256);
+    if (tiles < 512) merge = false;
+  }
+  std::vector<ConvGemmArgs> merged;
   for (size_t ic = 0; ic < cls.size(); ++ic) {
     const Cls &c = cls[ic];
     if (c.nU * c.nV > 63)
@@ -707,6 +761,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       // algorithmic work of dgrad == forward MACs (2*Ho*Wo*N*K*R), apportioned over the classes by
       // their share of (pixel, tap) pairs; masked-out pairs are not work
       a.algoFlops = 2.0 * g.Ho * g.Wo * (double)g.N * g.Kg * g.R * ((double)a.NP * c.Rc) / pair_total;
+      if (merge) {
+        merged.push_back(a);
+        continue;
+      }
       auto run = [&](int ci) {
         int sp;
         gemm_slab_floats(a, ci, &sp);
@@ -718,6 +776,21 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       rc = run(ci);
       if (rc) return rc;
     }
+  }
+  if (merge) {
+    // all stride-parity classes in one launch (each alone is a fraction more than one round of the chip)
+    auto run = [&](int ci) { return launch_gemm_multi(merged, ci, st); };
+    long long npSum = 0;
+    int rpMax = 0;
+    for (const ConvGemmArgs &a : merged) {
+      npSum += a.NP;
+      rpMax = std::max(rpMax, a.Rp);
+    }
+    TuneKey key{2, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
+                g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    int ci = tune_cfg(key, pick_cfg(merged[0].M, npSum, rpMax / kBK), st, run);
+    rc = run(ci);
+    if (rc) return rc;
   }
   return XM_OK;
 }
@@ -890,6 +963,8 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   const Cfg &c = kCfgs[ci];
   if (kind == 0)
     snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, key % 2);
+  else if (kind == 2)
+    snprintf(buf, len, "conv_gemm_multi_kernel<%d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn);
   else
     snprintf(buf, len, "conv_wgrad_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, 1 << (key % 4));
   return XM_OK;

@@ -161,8 +161,7 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
 
 // MODE 0: every tap is inside the image (pad == 0, Rp == R);  MODE 1: (u,v) validity mask.
 template <int TM, int TN, int WGM, int WGN, int MODE>
-__global__ void __launch_bounds__(256, 2)
-conv_gemm_kernel(const ConvGemmArgs a) {
+__device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(BN == 32 || BN == 64 || BN == 128 || BN == 256, "BN must divide 256");
@@ -507,6 +506,26 @@ conv_gemm_kernel(const ConvGemmArgs a) {
       }
     }
   }
+}
+
+template <int TM, int TN, int WGM, int WGN, int MODE>
+__global__ void __launch_bounds__(256, 2)
+conv_gemm_kernel(const ConvGemmArgs a) {
+  conv_gemm_body<TM, TN, WGM, WGN, MODE>(a);
+}
+
+// Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity
+// classes of a strided dgrad.  Each class alone is ~1.1 rounds of the chip (a 14 % full second round);
+// together they pack into whole rounds, and the larger 96-row tile becomes the best choice.
+struct ConvGemmMulti {
+  ConvGemmArgs c[4];
+};
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(256, 2)
+conv_gemm_multi_kernel(const ConvGemmMulti m) {
+  const ConvGemmArgs &a = m.c[blockIdx.z];
+  if ((int)blockIdx.x >= a.nbm * a.nbn) return;
+  conv_gemm_body<TM, TN, WGM, WGN, 1>(a);
 }
 
 // combine split-K slabs in split order and apply the fused epilogue; one thread per (m, p)

@@ -218,6 +218,7 @@ def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, 
     subset = list(subset)
     t0 = time.perf_counter()
     num = 0
+    inflight = []
     for t in range(0, len(subset), opts.batchSize):
         batch = subset[t:t + opts.batchSize]
         shard = shard_batch(batch, rank, world)
@@ -230,6 +231,12 @@ def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, 
             net.mode = "test"
             net.eval(inputs)
         num += len(batch)
+        # bounded run-ahead (two minibatches): a full HIP queue stalls launches for milliseconds
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+        if len(inflight) > 2:
+            inflight.pop(0).synchronize()
     stats = extractStatsFn({}, net)   # the only host synchronisation of the pass
     stats["num"] = num
     stats["time"] = time.perf_counter() - t0

@@ -13,16 +13,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcncrossmodalemotions_amd import dagnn, vl, zoo  # noqa: E402
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, tag=None):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    prof = os.environ.get("LB_PROF") and tag
+    if prof:
+        import ctypes as C
+        from mcncrossmodalemotions_amd import _lib
+        L = _lib.load()
+        L.xm_prof_enable(1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
         fn()
     e.record()
     torch.cuda.synchronize()
+    if prof:
+        L.xm_prof_enable(0)
+        cap = 64
+        keys = (C.c_int * cap)(); ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); cnt = (C.c_longlong * cap)()
+        n = L.xm_prof_collect(cap, keys, ms, fl, cnt)
+        out = []
+        for i in range(n):
+            buf = C.create_string_buffer(128); L.xm_prof_kernel_name(keys[i], buf, 128)
+            out.append("%s x%d avg %.3f ms" % (buf.value.decode(), cnt[i], ms[i] / cnt[i]))
+        print("[prof] %s: wall %.3f ms/call | %s | ws %d MB" % (tag, s.elapsed_time(e) / reps, "; ".join(out),
+                                                          L.xm_workspace_bytes() >> 20), file=sys.stderr)
     return s.elapsed_time(e) / reps
 
 
@@ -34,6 +51,9 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if os.environ.get("LB_RESERVE"):
+        from mcncrossmodalemotions_amd import _lib
+        _lib.check(_lib.load().xm_workspace_reserve(int(os.environ["LB_RESERVE"]) << 20))
     rng = np.random.default_rng(0)
     if args.net == "vggvox":
         net = zoo.emoVoxZoo("emovoxceleb-student", numSeconds=3, seed=200)
@@ -60,7 +80,7 @@ def main():
             continue
         blk = rec.block
         f = net.params[rec.params[0]].value
-        b = net.params[rec.params[1]].value if blk.hasBias else None
+        b = net.params[rec.params[1]].value if (blk.hasBias and not os.environ.get("LB_NOBIAS")) else None
         H, W, C, N = (int(s) for s in xin.shape)
         FH, FW, FC, K = blk.size
         y = vl.vl_nnconv(xin, f, b, stride=blk.stride, pad=blk.pad)
@@ -73,7 +93,7 @@ def main():
             row.append(timeit(lambda: vl.vl_nnconv(xin, f, None, dz, stride=blk.stride, pad=blk.pad,
                                                    no_der_filters=True), args.reps))
             row.append(timeit(lambda: vl.vl_nnconv(xin, f, None, dz, stride=blk.stride, pad=blk.pad,
-                                                   no_der_data=True), args.reps))
+                                                   no_der_data=True), args.reps, rec.name + " wgrad"))
         rows.append(row)
     tot = sum(r[5] for r in rows)
     print("%-22s %-14s %-7s %5s %8s %8s %7s %6s" % ("layer", "in", "filt", "K", "GFLOP", "us", "TF", "%"))
