@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$R
 mkdir -p $O
-python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
 python bench.py                                   | tail -1 > $O/bench_distill_n1.json
 python bench.py --serial --no-cpu-baseline        | tail -1 > $O/bench_distill_serial_n1.json
 python bench.py --workload student --no-cpu-baseline | tail -1 > $O/bench_student_n1.json
