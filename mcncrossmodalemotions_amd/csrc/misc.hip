@@ -290,24 +290,34 @@ __global__ void average_kernel(float *__restrict__ w, const float *__restrict__ 
   if (i < n) w[i] = (1.f - lr) * w[i] + lr * (der[i] * inv_workers);
 }
 
-// per-frequency-row normalisation: thread per (h, n); lanes along h are contiguous in memory
+// per-frequency-row normalisation: a block owns 64 consecutive rows h of one clip; its 4 waves split
+// the time axis (w = wave, wave + 4, ...), lanes along h are contiguous in memory.  Partial sums meet
+// in LDS in wave order (fixed -> deterministic); two passes (mean, then centred squares) as the
+// reference's mean() / std() do.
 __global__ void __launch_bounds__(256)
 spec_rownorm_kernel(const float *__restrict__ s, float *__restrict__ o, int H, int W, int N) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= H * N) return;
-  int h = idx % H, n = idx / H;
-  const float *p = s + h + (size_t)H * W * n;
-  float *q = o + h + (size_t)H * W * n;
+  __shared__ float red[4][64];
+  const int hl = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const int h = blockIdx.x * 64 + hl, n = blockIdx.y;
+  const bool ok = h < H;
+  const float *p = s + (ok ? h : 0) + (size_t)H * W * n;
+  float *q = o + (ok ? h : 0) + (size_t)H * W * n;
   float sum = 0.f;
-  for (int w = 0; w < W; ++w) sum += p[(size_t)H * w];
-  float mu = sum / (float)W;
+  for (int w = wl; w < W; w += 4) sum += p[(size_t)H * w];
+  red[wl][hl] = sum;
+  __syncthreads();
+  const float mu = ((red[0][hl] + red[1][hl]) + (red[2][hl] + red[3][hl])) / (float)W;
+  __syncthreads();
   float ss = 0.f;
-  for (int w = 0; w < W; ++w) {
+  for (int w = wl; w < W; w += 4) {
     float d = p[(size_t)H * w] - mu;
     ss += d * d;
   }
-  float inv = 1.f / sqrtf(ss / (float)(W - 1));
-  for (int w = 0; w < W; ++w) q[(size_t)H * w] = (p[(size_t)H * w] - mu) * inv;
+  red[wl][hl] = ss;
+  __syncthreads();
+  const float inv = 1.f / sqrtf(((red[0][hl] + red[1][hl]) + (red[2][hl] + red[3][hl])) / (float)(W - 1));
+  if (!ok) return;
+  for (int w = wl; w < W; w += 4) q[(size_t)H * w] = (p[(size_t)H * w] - mu) * inv;
 }
 
 __global__ void aggregate_logits_kernel(const float *__restrict__ lg, int F, int E,
@@ -564,8 +574,8 @@ int xm_spec_magnitude(const float *reim, int Wo, int B, int N, float *out, void 
 int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream) {
   if (H <= 0 || W <= 1 || N <= 0) return fail(XM_EINVAL, "spec_rownorm: need H>0, W>1, N>0");
   if (!spec || !out) return fail(XM_EINVAL, "spec_rownorm: NULL tensor");
-  int rows = H * N;
-  hipLaunchKernelGGL(spec_rownorm_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  if (N > 65535) return fail(XM_ETOOBIG, "spec_rownorm: more than 65535 clips per call");
+  hipLaunchKernelGGL(spec_rownorm_kernel, dim3((H + 63) / 64, N), dim3(256), 0, (hipStream_t)stream,
                      spec, out, H, W, N);
   XM_LAUNCH_CHECK();
   return XM_OK;
