@@ -393,7 +393,13 @@ def main():
         torch.cuda.synchronize()
         parserv.stop()
         dist.destroy_process_group()
+    try:
+        C.CDLL(None).fflush(None)        # anything RCCL / HIP still hold in C stdio buffers goes out first
+    except OSError:
+        pass
     if rank == 0:
+        if world > 1:
+            time.sleep(1.0)              # let the other ranks finish their teardown output
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
