@@ -786,7 +786,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       npSum += a.NP;
       rpMax = std::max(rpMax, a.Rp);
     }
-    TuneKey key{2, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
+    TuneKey key{3, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
                 g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(merged[0].M, npSum, rpMax / kBK), st, run);
     rc = run(ci);

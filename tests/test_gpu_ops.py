@@ -62,6 +62,54 @@ def test_conv_forward_backward(gpu, case):
     close(vl.to_numpy(db).ravel(), db_ref, what="conv db")
 
 
+# enough pixels per stride-parity class for the merged single-launch dgrad (conv_gemm_multi_kernel)
+MERGED_DGRAD_CASES = [
+    (200, 200, 8, 4, 3, 3, 8, 8, (2, 2), (1, 1, 1, 1), (1, 1)),     # 4 classes, 3x3
+    (182, 150, 6, 5, 5, 5, 6, 12, (2, 2), (1, 1, 1, 1), (1, 1)),    # the student's conv2 pattern (5x5 / 2)
+    (260, 140, 4, 4, 3, 3, 4, 6, (2, 1), (1, 0, 1, 1), (1, 1)),     # 2 classes (stride 2 x 1)
+    (150, 150, 5, 3, 4, 4, 5, 7, (3, 3), (1, 2, 0, 1), (1, 1)),     # 9 classes -> per-class launches
+]
+
+
+@pytest.mark.parametrize("case", MERGED_DGRAD_CASES)
+def test_conv_strided_dgrad_large(gpu, case):
+    test_conv_forward_backward(gpu, case)
+
+
+def test_conv_random_geometries(gpu):
+    """seeded fuzz over filter size / stride / padding / dilation / groups / odd sizes: forward, dX, dF, dB
+    against the fp64-accumulate oracle."""
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(20260928)
+    done = 0
+    while done < 28:
+        FH, FW = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        sy, sx = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        dy, dx = (int(rng.integers(1, 3)), int(rng.integers(1, 3))) if rng.random() < 0.25 else (1, 1)
+        pad = tuple(int(v) for v in rng.integers(0, 3, 4))
+        G = int(rng.choice([1, 1, 1, 2]))
+        FC = int(rng.integers(1, 9))
+        C, K = FC * G, int(rng.integers(1, 6)) * G
+        H, W, N = int(rng.integers(6, 40)), int(rng.integers(6, 40)), int(rng.integers(1, 4))
+        if H + pad[0] + pad[1] < (FH - 1) * dy + 1 or W + pad[2] + pad[3] < (FW - 1) * dx + 1:
+            continue
+        if FH * FW > 63:
+            continue
+        case = (H, W, C, N, FH, FW, FC, K, (sy, sx), pad, (dy, dx))
+        x, f, b = rnd(rng, H, W, C, N), rnd(rng, FH, FW, FC, K), rnd(rng, K)
+        y_ref = O.vl_nnconv(x, f, b, stride=(sy, sx), pad=pad, dilate=(dy, dx), acc64=True)
+        dzdy = rnd(rng, *y_ref.shape)
+        dx_ref, df_ref, db_ref = O.vl_nnconv(x, f, b, dzdy, stride=(sy, sx), pad=pad, dilate=(dy, dx), acc64=True)
+        xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+        close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, stride=(sy, sx), pad=pad, dilate=(dy, dx))), y_ref,
+              what="fuzz fwd %s" % (case,))
+        gx, gf, gb = vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), stride=(sy, sx), pad=pad, dilate=(dy, dx))
+        close(vl.to_numpy(gx), dx_ref, what="fuzz dx %s" % (case,))
+        close(vl.to_numpy(gf), df_ref, what="fuzz df %s" % (case,))
+        close(vl.to_numpy(gb).ravel(), db_ref, what="fuzz db %s" % (case,))
+        done += 1
+
+
 def test_conv_all_tile_configs(gpu):
     """every templated tile configuration must give the same answer."""
     from mcncrossmodalemotions_amd import vl, _lib
