@@ -304,6 +304,9 @@ def test_compute_audio_feats_variable_width(gpu):
     got_b = external.compute_audio_feats(net, dspecs, batch_by_bucket=True)
     close(got_b, ref, 1e-4, "bucket-batched")
     close(got_b, got, 1e-5, "batched vs single")
+    got_g = external.compute_audio_feats(net, dspecs, use_graphs=True)
+    close(got_g, ref, 1e-4, "HIP-graph replay")
+    close(external.compute_audio_feats(net, dspecs, use_graphs=True), got_g, 0, "graph replay is repeatable")
     with pytest.raises(ValueError):
         external.compute_audio_feats(net, [vl.from_numpy(O.F(np.ones((512, 60))))])
 

@@ -16,13 +16,16 @@ net = zoo.emoVoxZoo(numSeconds=4, seed=200)
 g = torch.Generator(device=dev); g.manual_seed(0)
 widths = rng.integers(100, 1100, args.clips)
 specs = [torch.randn((int(T), 512), generator=g, device=dev).abs_().t() for T in widths]   # 512 x T mats
-for mode in (False, True):
-    external.compute_audio_feats(net, specs[:32], batch_by_bucket=mode)   # warm-up: tile tuning per shape
-    external.compute_audio_feats(net, specs, batch_by_bucket=mode)
+ref = None
+for mode, graphs in ((False, False), (False, True), (True, False)):
+    external.compute_audio_feats(net, specs[:32], batch_by_bucket=mode, use_graphs=graphs)   # warm-up
+    external.compute_audio_feats(net, specs, batch_by_bucket=mode, use_graphs=graphs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = external.compute_audio_feats(net, specs, batch_by_bucket=mode)
+    out = external.compute_audio_feats(net, specs, batch_by_bucket=mode, use_graphs=graphs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("%-28s %8.1f clips/s  (%d clips, widths 100..1099, %.1f ms total)" % (
-        "bucket-batched" if mode else "one clip per eval (reference)", args.clips / dt, args.clips, dt * 1e3))
+    ref = out if ref is None else ref
+    name = ("bucket-batched" if mode else "one clip per eval (reference)") + (" + HIP graphs" if graphs else "")
+    print("%-44s %8.1f clips/s  (%d clips, widths 100..1099, %.1f ms total, max|diff| vs first %.2e)" % (
+        name, args.clips / dt, args.clips, dt * 1e3, float(np.abs(out - ref).max())))
