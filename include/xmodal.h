@@ -44,7 +44,7 @@ enum { XM_LOSS_SOFTMAXLOG = 0, XM_LOSS_CLASSERROR = 1 };
 enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 
 /* fused-epilogue flags for xm_nnconv_forward_fused / xm_nnbnorm_forward_fused */
-enum { XM_FUSE_RELU = 1 };
+enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2 };
 
 int xm_version(void);
 const char *xm_last_error(void);
@@ -109,7 +109,9 @@ int xm_nnbnorm_backward(const float *x, int H, int W, int C, int N, const float 
                         const float *dzdy, float epsilon, const float *moments_in, float *dx_out,
                         float *dg_out, float *db_out, float *moments_out, void *stream);
 /* Extension: backward through relu(bnorm(x)): `y` is the fused forward output; dzdy is masked
- * by (y > 0) before the vl_nnbnorm backward formulas. */
+ * by (y > 0) before the vl_nnbnorm backward formulas (flags & XM_FUSE_RELU).
+ * flags & XM_BN_BATCH_MOMENTS: moments_in holds the BATCH moments the forward call returned for this
+ * very X (train mode): they are not recomputed (one pass over X less), the train-mode formulas apply. */
 int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int C, int N,
                               const float *g, const float *b, const float *dzdy, float epsilon,
                               const float *moments_in, float *dx_out, float *dg_out, float *db_out,

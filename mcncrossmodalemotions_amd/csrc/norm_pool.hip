@@ -276,10 +276,11 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
 static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C, int N,
                           const float *g, const float *dzdy, float eps, const float *moments_in,
                           float *dx_out, float *dg_out, float *db_out, float *moments_out,
-                          hipStream_t st) {
+                          hipStream_t st, bool batch_moments = false) {
   int rc = bn_check(H, W, C, N);
   if (rc) return rc;
   if (!x || !g || !dzdy) return fail(XM_EINVAL, "vl_nnbnorm: NULL tensor");
+  if (batch_moments && !moments_in) return fail(XM_EINVAL, "vl_nnbnorm: XM_BN_BATCH_MOMENTS needs moments");
   const int HW = H * W;
   const int S = bn_splits(C, N);
   WsCarver ws;
@@ -309,7 +310,7 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
     size_t total = (size_t)HW * C * N;
     FastDiv d = make_fastdiv((uint32_t)HW);
     float m = (float)((double)HW * N);
-    int train = moments_in ? 0 : 1;
+    int train = (moments_in && !batch_moments) ? 0 : 1;
     bool al = ((((uintptr_t)x | (uintptr_t)dzdy | (uintptr_t)dx_out | (uintptr_t)yfwd) & 15) == 0);
     if ((HW & 3) == 0 && al)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(total / 4)), dim3(256), 0, st, x,
@@ -871,7 +872,8 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
   (void)b;
   if ((flags & XM_FUSE_RELU) && !y) return fail(XM_EINVAL, "vl_nnbnorm(fused bwd): y is NULL");
   return bnorm_backward(x, (flags & XM_FUSE_RELU) ? y : nullptr, H, W, C, N, g, dzdy, epsilon,
-                        moments_in, dx_out, dg_out, db_out, moments_out, (hipStream_t)stream);
+                        moments_in, dx_out, dg_out, db_out, moments_out, (hipStream_t)stream,
+                        (flags & XM_BN_BATCH_MOMENTS) != 0);
 }
 
 int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,

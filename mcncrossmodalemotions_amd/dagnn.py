@@ -120,9 +120,14 @@ class BatchNorm(Layer):
     def backward(self, inputs, params, derOutputs, relu=False, y=None, der_out=None):
         test = self.net is not None and self.net.mode == "test"
         do = der_out or [None, None, None]
+        # train mode: the forward pass of this eval left the batch moments of this very input in
+        # self.moments -- hand them back instead of re-reading X to recompute them
+        saved = None if test else self.moments
         dx, dg, db, mom = vl.vl_nnbnorm(inputs[0], params[0], params[1], derOutputs[0],
-                                        epsilon=self.epsilon, moments=params[2] if test else None,
-                                        relu=relu, y=y, dg_out=do[0], db_out=do[1], moments_out=do[2])
+                                        epsilon=self.epsilon,
+                                        moments=params[2] if test else saved,
+                                        relu=relu, y=y, dg_out=do[0], db_out=do[1], moments_out=do[2],
+                                        batch_moments=(not test) and saved is not None)
         # dagnn.BatchNorm: derParams{3} = the batch moments (consumed by trainMethod 'average')
         return [dx], [dg, db, mom]
 

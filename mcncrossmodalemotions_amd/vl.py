@@ -224,11 +224,13 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, wa
 
 
 def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None, dg_out=None,
-               db_out=None, moments_out=None):
+               db_out=None, moments_out=None, batch_moments=False):
     """forward:  Y, MOMENTS = VL_NNBNORM(X, G, B);  backward: DX, DG, DB, MOMENTS = (..., DZDY).
 
     MOMENTS is C x 2 = [mean, sqrt(var + epsilon)].  `relu=True` fuses vl_nnrelu (forward) /
-    its mask (backward; pass the fused forward output as `y`)."""
+    its mask (backward; pass the fused forward output as `y`).  `batch_moments=True` (backward,
+    extension): `moments` are the batch moments the forward call returned for this X -- train-mode
+    derivative without recomputing them."""
     x, g, b = _chk(x, "X"), _chk(g, "G"), _chk(b, "B")
     H, W, Cc, N = _shape4(x)
     if g.numel() != Cc or b.numel() != Cc:
@@ -252,13 +254,15 @@ def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=Non
     dxo = mat_empty(H, W, Cc, N, device=x.device)
     dg = dg_out if dg_out is not None else mat_empty(Cc, 1, device=x.device)
     db = db_out if db_out is not None else mat_empty(Cc, 1, device=x.device)
-    if relu:
-        if y is None:
+    if batch_moments and mi is None:
+        raise ValueError("vl_nnbnorm: batch_moments needs the moments of the forward call")
+    if relu or batch_moments:
+        if relu and y is None:
             raise ValueError("vl_nnbnorm: fused backward needs the forward output y")
-        _lib.check(L.xm_nnbnorm_backward_fused(_ptr(x), _ptr(_chk(y, "Y")), H, W, Cc, N, _ptr(g),
-                                               _ptr(b), _ptr(dzdy), float(epsilon), _ptr(mi),
-                                               _ptr(dxo), _ptr(dg), _ptr(db), _ptr(mo), 1,
-                                               _stream()))
+        _lib.check(L.xm_nnbnorm_backward_fused(_ptr(x), _ptr(_chk(y, "Y")) if relu else None, H, W, Cc, N,
+                                               _ptr(g), _ptr(b), _ptr(dzdy), float(epsilon), _ptr(mi),
+                                               _ptr(dxo), _ptr(dg), _ptr(db), _ptr(mo),
+                                               (1 if relu else 0) | (2 if batch_moments else 0), _stream()))
     else:
         _lib.check(L.xm_nnbnorm_backward(_ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), _ptr(dzdy),
                                          float(epsilon), _ptr(mi), _ptr(dxo), _ptr(dg), _ptr(db),

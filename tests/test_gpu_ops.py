@@ -221,6 +221,13 @@ def test_bnorm(gpu, shape, relu):
     close(vl.to_numpy(dx), dx_ref, what="bn dx")
     close(vl.to_numpy(dg).ravel(), dg_ref, what="bn dg")
     close(vl.to_numpy(db).ravel(), db_ref, what="bn db")
+    # train-mode backward handed the forward's batch moments (XM_BN_BATCH_MOMENTS): same bits, one pass less
+    dx2, dg2, db2, m2 = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), relu=relu, y=y if relu else None,
+                                      moments=m, batch_moments=True)
+    close(vl.to_numpy(dx2), vl.to_numpy(dx), 0, "bn dx with forward moments")
+    close(vl.to_numpy(dg2), vl.to_numpy(dg), 0, "bn dg with forward moments")
+    close(vl.to_numpy(db2), vl.to_numpy(db), 0, "bn db with forward moments")
+    close(vl.to_numpy(m2), vl.to_numpy(m), 0, "moments passed through")
     # test mode with stored moments
     mom = O.F(np.stack([rng.standard_normal(C), rng.uniform(0.5, 1.5, C)], 1))
     yt_ref, _ = O.vl_nnbnorm(x, g, b, moments=mom, acc64=True)
