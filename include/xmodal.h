@@ -73,6 +73,13 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
                        int FC, int K, const float *dzdy, float *dx_out, float *df_out,
                        float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
                        int dx, void *stream);
+/* Extension: DX = dgrad + dx_accum.  dagnn sums the derivatives that reach a variable from several
+ * consumers (a ResNet block input: shortcut + branch2a); the sum rides in the dgrad epilogue instead of a
+ * separate pass.  dx_accum has the size of X, must not alias dx_out, NULL = plain backward. */
+int xm_nnconv_backward_accum(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                             int FC, int K, const float *dzdy, float *dx_out, float *df_out,
+                             float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
+                             int dx, const float *dx_accum, void *stream);
 
 /* ---- vl_nnpool  (matlab/vl_nnpool.m; pool6 resized at emoVoxZoo.m:256-269) ------------------
  * Y = vl_nnpool(X, [ph pw], 'stride', .., 'pad', .., 'method', 'max'|'avg') */

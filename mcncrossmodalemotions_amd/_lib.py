@@ -25,6 +25,8 @@ SIGNATURES = {
                                [c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnconv_backward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +
                           [_i] * 8 + [_vp],
+    "xm_nnconv_backward_accum": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +
+                                [_i] * 8 + [c_fp, _vp],
     "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
     "xm_nnpool_forward_argmax": [c_fp] + [_i] * 12 + [c_fp, c_fp, _vp],

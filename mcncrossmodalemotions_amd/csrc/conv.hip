@@ -592,7 +592,10 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
 }
 
 // dX: one implicit GEMM per stride-parity class (a, b) of the input pixels.
-static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st) {
+// accum != NULL: dX = dgrad + accum (the derivative another branch of a fork already produced), added in
+// the GEMM epilogue instead of by a separate pass
+static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st,
+                      const float *accum = nullptr) {
   struct Cls {
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
@@ -646,8 +649,13 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       cls.push_back(c);
     }
   // pixels whose class has no tap (e.g. 1x1 stride 2) receive no gradient
-  if (!covers_all || cls.empty())
-    XM_HIP(hipMemsetAsync(dxo, 0, sizeof(float) * (size_t)g.H * g.W * g.C * g.N, st));
+  if (!covers_all || cls.empty()) {
+    const size_t bytes = sizeof(float) * (size_t)g.H * g.W * g.C * g.N;
+    if (accum)
+      XM_HIP(hipMemcpyAsync(dxo, accum, bytes, hipMemcpyDeviceToDevice, st));
+    else
+      XM_HIP(hipMemsetAsync(dxo, 0, bytes, st));
+  }
   if (cls.empty()) return XM_OK;
   // scratch for the split-K slab of the largest class under any tile configuration
   size_t slab_max = 0;
@@ -720,6 +728,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.X = dzdy + xoff;
       a.xBytes = (unsigned)((dyTotal - xoff) * 4);
       a.Y = dxo + (size_t)grp * g.FC * g.H * g.W;
+      a.resid = accum ? accum + (size_t)grp * g.FC * g.H * g.W : nullptr;
       a.taps = taps;
       a.M = foldH ? g.FC * g.FH : g.FC;
       a.Rp = c.Rp;
@@ -752,7 +761,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       a.divMU = make_fastdiv(foldH ? (uint32_t)g.FH : 1u);
       a.oUStride = foldH ? 1 : 0;
       a.vecStore = (!foldH && g.sy == 1 && g.sx == 1 && (c.PI * c.PJ) % 4 == 0 && c.PI == g.H &&
-                    c.PJ == g.W && ((uintptr_t)a.Y & 15) == 0) ? 1 : 0;
+                    c.PJ == g.W && (((uintptr_t)a.Y | (uintptr_t)a.resid) & 15) == 0) ? 1 : 0;
       if (foldH) {
         a.gh0 = 0;  // the single dY row; destination row comes from the GEMM row (m % FH)
         a.oh0 = 0;
@@ -995,6 +1004,14 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
                        int FC, int K, const float *dzdy, float *dx_out, float *df_out,
                        float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
                        int dx, void *stream) {
+  return xm_nnconv_backward_accum(x, H, W, C, N, f, FH, FW, FC, K, dzdy, dx_out, df_out, db_out, sy, sx, pt,
+                                  pb, pl, pr, dy, dx, nullptr, stream);
+}
+
+int xm_nnconv_backward_accum(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                             int FC, int K, const float *dzdy, float *dx_out, float *df_out,
+                             float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
+                             int dx, const float *dx_accum, void *stream) {
   Geo g;
   int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
   if (rc) return rc;
@@ -1021,7 +1038,8 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
   }
   if (dx_out) {
     if (!f) return fail(XM_EINVAL, "vl_nnconv: F is NULL but DZDX requested");
-    rc = conv_dgrad(f, dzdy, dx_out, g, st);
+    if (dx_accum == dx_out) return fail(XM_EINVAL, "vl_nnconv: dx_accum must not alias dx_out");
+    rc = conv_dgrad(f, dzdy, dx_out, g, st, dx_accum);
     if (rc) return rc;
   }
   return XM_OK;

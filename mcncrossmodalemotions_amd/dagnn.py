@@ -83,14 +83,15 @@ class Conv(Layer):
                              dilate=self.dilate)]
 
     def backward(self, inputs, params, derOutputs, need_dx=True, der_out=None, skip_db=False,
-                 need_df=True):
+                 need_df=True, dx_accum=None):
         b = params[1] if self.hasBias else None
         dfo = der_out[0] if der_out else None
         dbo = der_out[1] if (der_out and self.hasBias) else None
         dx, df, db = vl.vl_nnconv(inputs[0], params[0], b, derOutputs[0], stride=self.stride,
                                   pad=self.pad, dilate=self.dilate, no_der_data=not need_dx,
                                   no_der_filters=not need_df, no_der_biases=skip_db or not need_df,
-                                  df_out=dfo if need_df else None, db_out=dbo if need_df else None)
+                                  df_out=dfo if need_df else None, db_out=dbo if need_df else None,
+                                  dx_accum=dx_accum)
         return [dx], ([df, db] if self.hasBias else [df])
 
     def initParams(self, rng):
@@ -744,9 +745,15 @@ class _Step:
             side = net.wgradStream if need_dx else None
             if side is not None and net._flat is not None and net._direct_der(r) is None:
                 side = None  # the derivative would need a copy on this stream
+            # fork: another consumer of the input already left its derivative -> add it in the dgrad
+            # epilogue (dx = dgrad + existing) instead of a separate sum2 pass
+            xin = net.vars[r.inputs[0]]
+            accum = xin.der if need_dx else None
+            if accum is not None:
+                xin.der = None   # replaced by the accumulated result below
             if side is None:
                 dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
-                                              der_out=net._direct_der(r), skip_db=skip_db)
+                                              der_out=net._direct_der(r), skip_db=skip_db, dx_accum=accum)
                 if net.gradHook is not None:
                     net.gradHook(r.name)
             else:
@@ -761,7 +768,8 @@ class _Step:
                         net.gradHook(r.name)
                 douts[0].record_stream(side)
                 net._side_pending = True
-                dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False)
+                dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False,
+                                           dx_accum=accum)
             if skip_db:
                 dpar = [dpar[0], net.params[r.params[1]].der]
         elif isinstance(r.block, BatchNorm):

@@ -127,10 +127,11 @@ def out_size(n, pa, pb, f, d, s):
 
 def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
               no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
-              relu=False, df_out=None, db_out=None):
+              relu=False, df_out=None, db_out=None, dx_accum=None):
     """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
 
-    `scale/shift/residual/relu` select the fused forward epilogue (extension; see xmodal.h)."""
+    `scale/shift/residual/relu` select the fused forward epilogue (extension; see xmodal.h);
+    `dx_accum` (backward, extension): DX = dgrad + dx_accum in the dgrad epilogue."""
     x, f = _chk(x, "X"), _chk(f, "F")
     H, W, Cc, N = _shape4(x)
     FH, FW, FC, K = _shape4(f)
@@ -168,9 +169,14 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     # df_out / db_out: caller-owned destinations (e.g. views of the flat gradient buffer)
     dfo = None if no_der_filters else (df_out if df_out is not None else mat_empty(FH, FW, FC, K, device=x.device))
     dbo = None if (no_der_biases or bb is None) else (db_out if db_out is not None else mat_empty(K, 1, device=x.device))
-    _lib.check(L.xm_nnconv_backward(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(dzdy),
-                                    _ptr(dxo), _ptr(dfo), _ptr(dbo), sy, sx, pt, pb, pl, pr, dy, dx,
-                                    _stream()))
+    acc = None
+    if dx_accum is not None and dxo is not None:
+        acc = _chk(dx_accum, "DX_ACCUM")
+        if _shape4(acc) != [H, W, Cc, N]:
+            raise ValueError("vl_nnconv: dx_accum must have the size of X")
+    _lib.check(L.xm_nnconv_backward_accum(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(dzdy),
+                                          _ptr(dxo), _ptr(dfo), _ptr(dbo), sy, sx, pt, pb, pl, pr, dy, dx,
+                                          _ptr(acc), _stream()))
     return dxo, dfo, dbo
 
 

@@ -60,6 +60,11 @@ def test_conv_forward_backward(gpu, case):
     close(vl.to_numpy(dx), dx_ref, what="conv dx")
     close(vl.to_numpy(df), df_ref, what="conv df")
     close(vl.to_numpy(db).ravel(), db_ref, what="conv db")
+    # dX accumulated onto an existing derivative in the dgrad epilogue (xm_nnconv_backward_accum)
+    acc = rnd(rng, H, W, C, N)
+    dx2, _, _ = vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), stride=stride, pad=pad, dilate=dil,
+                             no_der_filters=True, dx_accum=vl.from_numpy(acc))
+    close(vl.to_numpy(dx2), dx_ref + acc, what="conv dx + accum")
 
 
 # enough pixels per stride-parity class for the merged single-launch dgrad (conv_gemm_multi_kernel)
