@@ -7,6 +7,13 @@ imported from here.)
 import ctypes as C
 import os
 
+# torch FIRST: its wheel bundles its own ROCm runtime (libamdhip64 / libhsa-runtime64 / librccl under
+# torch/lib).  libxmodal_hip.so is linked against the same sonames; once torch's copies are mapped the
+# loader reuses them and the process has ONE HIP runtime.  Loaded the other way round, the library pulls in
+# /opt/rocm/lib's copies, torch then maps its own next to them, and the process aborts in the runtimes'
+# static destructors at exit ("double free or corruption").
+import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so and friends)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libxmodal_hip.so")
 
