@@ -2,6 +2,9 @@ import os
 import sys
 
 import pytest
+# torch first: its wheel bundles its own ROCm and OpenMP runtimes; the oracle (libgomp) and the HIP library
+# are dlopen'ed later and then share them instead of mapping second copies (see mcncrossmodalemotions_amd/_lib.py)
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
