@@ -95,9 +95,10 @@ class Conv(Layer):
         return [dx], ([df, db] if self.hasBias else [df])
 
     def initParams(self, rng):
-        # dagnn.Conv.initParams: He-style sc = sqrt(2 / (h*w*out)); filters randn*sc, biases 0
+        # dagnn.Conv.initParams [EXT]: "Xavier improved", FAN-IN: sc = sqrt(2 / prod(size(1:3)));
+        # filters randn * sc, biases 0 (the fan-out variant is the commented-out line upstream)
         FH, FW, FC, K = self.size
-        sc = np.sqrt(2.0 / (FH * FW * K))
+        sc = np.sqrt(2.0 / (FH * FW * FC))
         p = [np.asfortranarray(rng.standard_normal(self.size).astype(np.float32) * np.float32(sc))]
         if self.hasBias:
             p.append(np.zeros((K, 1), np.float32))

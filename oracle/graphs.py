@@ -1,0 +1,357 @@
+"""The oracle's OWN layer tables and graph executor (TEST INFRASTRUCTURE ONLY, see xm_oracle.c).
+
+oracle_net.py walks the product's dagnn.DagNN objects, so a wrong layer table in the product's zoo.py would
+be invisible to every net-level test.  This module restates the three architectures of the hot path from
+SURVEY.md Appendix B (the public VGGVox / ResNet-50 / SE-ResNet-50 layer tables) WITHOUT importing anything
+from mcncrossmodalemotions_amd, executes them with the CPU oracle's operators, and generates the seeded
+synthetic parameters / inputs of SURVEY 8d.  tests/test_graph_tables.py asserts that the product's zoo.py
+builds exactly these graphs; tests/golden/make_golden_nets.py runs them once (fp64 accumulate) at the
+reference's real sizes and commits the results as tests/golden/nets_full.npz.
+
+Reference anchors:
+    student graph + surgery   emoVoxCeleb/emoVoxZoo.m:50-62,137-177,187-269   (pool6 table :258-259)
+    teacher graphs            teacher/ferPlusZoo.m:93-133 (downloaded .mat; Caffe-import layer names)
+    teacher inference         emoVoxCeleb/fetch_emovoxceleb_imdb.m:98-131     (test mode, last variable)
+    student step              emoVoxCeleb/run_distillation.m:125-131,170-182
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from oracle import oracle as O
+
+Layer = namedtuple("Layer", "name type inputs outputs params attrs")
+
+EMOTIONS = ["neutral", "happiness", "surprise", "sadness", "anger", "disgust", "fear", "contempt"]
+# emoVoxZoo.m:258-259
+POOL6_WIDTH = {100: 2, 200: 5, 300: 8, 400: 11, 500: 14, 600: 17, 700: 20, 800: 23, 900: 27, 1000: 30}
+
+
+def _conv(name, x, y, size, bias, stride=1, pad=0, pnames=None):
+    p = pnames or ([name + "f", name + "b"] if bias else [name + "f"])
+    return Layer(name, "conv", [x], [y], p, dict(size=tuple(size), hasBias=bool(bias), stride=(stride, stride),
+                                                  pad=(pad, pad, pad, pad)))
+
+
+def _bn(name, x, y, C, eps, pnames):
+    return Layer(name, "bnorm", [x], [y], list(pnames), dict(numChannels=C, epsilon=eps))
+
+
+def vggvox_student(width=300, num_outputs=8, loss="hot-cross-ent"):
+    """Appendix B.1 after the surgery of emoVoxZoo.m:187-253 (Loss/SoftMax stripped, 8-way fc8 ->
+    'prediction', input 'data'), configureForRegression (:137-177) and updatePooling (:256-269)."""
+    Ls = []
+    x = "data"
+    for nm, fh, ci, co, s, p in (("1", 7, 1, 96, 2, 1), ("2", 5, 96, 256, 2, 1), ("3", 3, 256, 384, 1, 1),
+                                 ("4", 3, 384, 256, 1, 1), ("5", 3, 256, 256, 1, 1)):
+        Ls.append(_conv("conv" + nm, x, "x_conv" + nm, (fh, fh, ci, co), True, s, p))
+        Ls.append(_bn("bn" + nm, "x_conv" + nm, "x_bn" + nm, co, 1e-4, ["bn%sm" % nm, "bn%sb" % nm, "bn%sx" % nm]))
+        Ls.append(Layer("relu" + nm, "relu", ["x_bn" + nm], ["x_relu" + nm], [], {}))
+        x = "x_relu" + nm
+        if nm in ("1", "2"):
+            Ls.append(Layer("mpool" + nm, "pool", [x], ["x_mpool" + nm], [],
+                            dict(poolSize=[3, 3], stride=(2, 2), pad=(0, 0, 0, 0), method="max")))
+            x = "x_mpool" + nm
+        if nm == "5":
+            Ls.append(Layer("mpool5", "pool", [x], ["x_mpool5"], [],
+                            dict(poolSize=[5, 3], stride=(3, 2), pad=(0, 0, 0, 0), method="max")))
+            x = "x_mpool5"
+    Ls.append(_conv("fc6", x, "x_fc6", (9, 1, 256, 4096), True))
+    Ls.append(_bn("bn6", "x_fc6", "x_bn6", 4096, 1e-4, ["bn6m", "bn6b", "bn6x"]))
+    Ls.append(Layer("relu6", "relu", ["x_bn6"], ["x_relu6"], [], {}))
+    Ls.append(Layer("pool6", "pool", ["x_relu6"], ["x_pool6"], [],
+                    dict(poolSize=[1, POOL6_WIDTH[width]], stride=(1, 1), pad=(0, 0, 0, 0), method="avg")))
+    Ls.append(_conv("fc7", "x_pool6", "x_fc7", (1, 1, 4096, 1024), True))
+    Ls.append(_bn("bn7", "x_fc7", "x_bn7", 1024, 1e-4, ["bn7m", "bn7b", "bn7x"]))
+    Ls.append(Layer("relu7", "relu", ["x_bn7"], ["x_relu7"], [], {}))
+    Ls.append(_conv("fc8", "x_relu7", "prediction", (1, 1, 1024, num_outputs), True))
+    if loss == "hot-cross-ent":      # emoVoxZoo.m:152: temperature hard-coded to 2, logit targets
+        Ls.append(Layer("loss", "softmaxceloss", ["prediction", "logitTarget"], ["objective"], [],
+                        dict(temperature=2, logitTargets=True)))
+    elif loss == "softmaxlog":
+        Ls.append(Layer("loss", "loss", ["prediction", "maxLabel"], ["objective"], [], dict(loss="softmaxlog")))
+    elif loss is not None:
+        raise ValueError(loss)
+    if loss is not None:             # emoVoxZoo.m:160-169
+        Ls.append(Layer("classerror", "loss", ["prediction", "maxLabel"], ["classerror"], [], dict(loss="classerror")))
+        Ls.append(Layer("classAccs", "errorstats", ["prediction", "maxLabel"], ["classAccs"], [],
+                        dict(numClasses=num_outputs)))
+    return Ls
+
+
+def resnet50_teacher(se=False, num_classes=8, heads=False):
+    """Appendix B.2 / B.3: Caffe-style (SE-)ResNet-50, stride on the first 1x1 of a stage, 224x224x3.
+    heads=True keeps the softmaxlog + classerror layers of the FER+ models (ferPlusZoo.m:240-252),
+    heads=False is the network after fetch_emovoxceleb_imdb.m:101-106 removed them."""
+    Ls = [_conv("conv1", "data", "conv1", (7, 7, 3, 64), True, 2, 3, ["conv1_filter", "conv1_bias"]),
+          _bn("bn_conv1", "conv1", "conv1_bn", 64, 1e-5, ["bn_conv1_mult", "bn_conv1_bias", "bn_conv1_moments"]),
+          Layer("conv1_relu", "relu", ["conv1_bn"], ["conv1x"], [], {}),
+          Layer("pool1", "pool", ["conv1x"], ["pool1"], [],
+                dict(poolSize=[3, 3], stride=(2, 2), pad=(0, 1, 0, 1), method="max"))]
+    x, cin = "pool1", 64
+    for si, nb in enumerate((3, 4, 6, 3)):
+        mid, cout = 64 << si, 256 << si
+        for bi in range(nb):
+            tag = "res%d%s" % (si + 2, "abcdef"[bi])
+            stride = 2 if (bi == 0 and si > 0) else 1
+            sc = x
+            if bi == 0:
+                Ls.append(_conv(tag + "_branch1", x, tag + "_branch1", (1, 1, cin, cout), False, stride, 0,
+                                [tag + "_branch1_filter"]))
+                Ls.append(_bn("bn" + tag[3:] + "_branch1", tag + "_branch1", tag + "_branch1_bn", cout, 1e-5,
+                              [tag + "_b1_mult", tag + "_b1_bias", tag + "_b1_moments"]))
+                sc = tag + "_branch1_bn"
+            y = x
+            for li, (fh, ci, co, s, p) in enumerate(((1, cin, mid, stride, 0), (3, mid, mid, 1, 1), (1, mid, cout, 1, 0))):
+                nm = tag + "_branch2" + "abc"[li]
+                Ls.append(_conv(nm, y, nm, (fh, fh, ci, co), False, s, p, [nm + "_filter"]))
+                Ls.append(_bn("bn" + nm[3:], nm, nm + "_bn", co, 1e-5, [nm + "_mult", nm + "_bias", nm + "_moments"]))
+                y = nm + "_bn"
+                if li < 2:
+                    Ls.append(Layer(nm + "_relu", "relu", [y], [nm + "x"], [], {}))
+                    y = nm + "x"
+            if se:
+                r = cout // 16
+                Ls.append(Layer(tag + "_global_pool", "gpool", [y], [tag + "_gp"], [], dict(method="avg")))
+                Ls.append(_conv(tag + "_fc1", tag + "_gp", tag + "_fc1", (1, 1, cout, r), True, 1, 0,
+                                [tag + "_fc1_filter", tag + "_fc1_bias"]))
+                Ls.append(Layer(tag + "_fc1_relu", "relu", [tag + "_fc1"], [tag + "_fc1x"], [], {}))
+                Ls.append(_conv(tag + "_fc2", tag + "_fc1x", tag + "_fc2", (1, 1, r, cout), True, 1, 0,
+                                [tag + "_fc2_filter", tag + "_fc2_bias"]))
+                Ls.append(Layer(tag + "_prob", "sigmoid", [tag + "_fc2"], [tag + "_prob"], [], {}))
+                Ls.append(Layer(tag, "axpy", [tag + "_prob", y, sc], [tag], [], {}))
+            else:
+                Ls.append(Layer(tag, "sum", [sc, y], [tag], [], {}))
+            Ls.append(Layer(tag + "_relu", "relu", [tag], [tag + "x"], [], {}))
+            x, cin = tag + "x", cout
+    Ls.append(Layer("pool5", "pool", [x], ["pool5"], [], dict(poolSize=[7, 7], stride=(1, 1), pad=(0, 0, 0, 0),
+                                                                method="avg")))
+    Ls.append(_conv("classifier", "pool5", "prediction", (1, 1, cin, num_classes), True, 1, 0,
+                    ["classifier_filter", "classifier_bias"]))
+    if heads:
+        Ls.append(Layer("loss", "loss", ["prediction", "label"], ["objective"], [], dict(loss="softmaxlog")))
+        Ls.append(Layer("top1error", "loss", ["prediction", "label"], ["top1error"], [], dict(loss="classerror")))
+    return Ls
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded synthetic parameters / inputs
+# ---------------------------------------------------------------------------------------------------
+def make_params(graph, seed):
+    """He-normal filters with FAN-IN scaling (MatConvNet dagnn.Conv.initParams [EXT]: sc = sqrt(2 / (h*w*in))),
+    zero biases, BN g = 1, b = 0, moments [0, 1].  One generator, consumed in layer order."""
+    rng = np.random.default_rng(seed)
+    P = {}
+    for l in graph:
+        if l.type == "conv":
+            FH, FW, FC, K = l.attrs["size"]
+            sc = np.float32(np.sqrt(2.0 / (FH * FW * FC)))
+            P[l.params[0]] = np.asfortranarray(rng.standard_normal((FH, FW, FC, K)).astype(np.float32) * sc)
+            if l.attrs["hasBias"]:
+                P[l.params[1]] = np.zeros((K, 1), np.float32)
+        elif l.type == "bnorm":
+            C = l.attrs["numChannels"]
+            mom = np.zeros((C, 2), np.float32, order="F")
+            mom[:, 1] = 1.0
+            P[l.params[0]] = np.ones((C, 1), np.float32)
+            P[l.params[1]] = np.zeros((C, 1), np.float32)
+            P[l.params[2]] = mom
+    return P
+
+
+def perturb_bn(P, graph, seed):
+    """non-trivial BN multipliers / biases (g ~ U(.5, 1.5), b ~ N(0, .1)) so that a swapped g/b or a wrong
+    broadcast cannot cancel out."""
+    rng = np.random.default_rng(seed)
+    for l in graph:
+        if l.type == "bnorm":
+            C = l.attrs["numChannels"]
+            P[l.params[0]] = rng.uniform(0.5, 1.5, (C, 1)).astype(np.float32)
+            P[l.params[1]] = (rng.standard_normal((C, 1)) * 0.1).astype(np.float32)
+    return P
+
+
+def face_batch(n, seed, avg=(131.0912, 103.8827, 91.4953)):
+    """U{0..255} grey replicated x3 minus the channel means (what getImageBatch /
+    normalizeFace produce, fetch_emovoxceleb_imdb.m:176-193)."""
+    rng = np.random.default_rng(seed)
+    grey = rng.integers(0, 256, (224, 224, 1, n)).astype(np.float32)
+    out = np.repeat(grey, 3, axis=2) - np.asarray(avg, np.float32).reshape(1, 1, 3, 1)
+    return np.asfortranarray(out.astype(np.float32))
+
+
+def spectrogram_batch(n, width, seed):
+    """|N(0,1)| 512 x W 'magnitudes', row-normalised as getBatchEmoVoxCeleb.m:164-169; teacher-logit stand-ins
+    ~ N(0, 3); maxLabel = argmax (getBatchEmoVoxCeleb.m:32)."""
+    rng = np.random.default_rng(seed)
+    spec = np.abs(rng.standard_normal((512, width, 1, n))).astype(np.float32)
+    data = O.spec_rownorm(O.F(spec))
+    lgo = O.F(rng.standard_normal((1, 1, 8, n)) * 3)
+    lab = O.F(lgo.reshape(8, n).argmax(0).reshape(1, 1, 1, n) + 1)
+    return data, lgo, lab
+
+
+# ---------------------------------------------------------------------------------------------------
+# executor
+# ---------------------------------------------------------------------------------------------------
+def forward(graph, inputs, P, mode="normal", acc64=True, keep=None):
+    """values of all variables (dict).  mode 'test' uses the stored BN moments.  `keep`: iterable of variable
+    names to retain; None keeps everything (needed for backward)."""
+    V = dict(inputs)
+    aux = {}
+    fan = {}
+    for l in graph:
+        for v in l.inputs:
+            fan[v] = fan.get(v, 0) + 1
+    for l in graph:
+        ins = [V.get(v) for v in l.inputs]
+        a = l.attrs
+        if any(i is None for i in ins):
+            continue     # head whose inputs were not supplied (MatConvNet would error; tests omit them on purpose)
+        if l.type == "conv":
+            y = O.vl_nnconv(ins[0], P[l.params[0]], P[l.params[1]] if a["hasBias"] else None, stride=a["stride"],
+                            pad=a["pad"], acc64=acc64)
+        elif l.type == "bnorm":
+            y, mom = O.vl_nnbnorm(ins[0], P[l.params[0]], P[l.params[1]], epsilon=a["epsilon"],
+                                  moments=P[l.params[2]] if mode == "test" else None, acc64=acc64)
+            aux[l.name] = mom
+        elif l.type == "relu":
+            y = O.vl_nnrelu(ins[0])
+        elif l.type == "sigmoid":
+            y = O.vl_nnsigmoid(ins[0])
+        elif l.type == "gpool":
+            y = O.vl_nnpool(ins[0], ins[0].shape[:2], method=a["method"])
+        elif l.type == "pool":
+            y = O.vl_nnpool(ins[0], a["poolSize"], stride=a["stride"], pad=a["pad"], method=a["method"])
+        elif l.type == "sum":
+            y = O.sum2(ins[0], ins[1])
+        elif l.type == "axpy":
+            y = O.scale_axpy(ins[1], ins[0], ins[2])
+        elif l.type == "softmaxceloss":
+            y = np.float32(O.vl_nnsoftmaxceloss(ins[0], ins[1], temperature=a["temperature"],
+                                                logit_targets=a["logitTargets"]))
+        elif l.type == "loss":
+            y = np.float32(O.vl_nnloss(ins[0], ins[1], loss=a["loss"]))
+        elif l.type == "errorstats":
+            y = np.float32(O.vl_nnloss(ins[0], ins[1], loss="classerror"))
+        else:
+            raise NotImplementedError(l.type)
+        V[l.outputs[0]] = y
+        if keep is not None:
+            for v in l.inputs:
+                fan[v] -= 1
+                if fan[v] == 0 and v not in keep and v not in inputs:
+                    V.pop(v, None)
+    V["__aux__"] = aux
+    return V
+
+
+def backward(graph, V, der_outputs, P, mode="normal", acc64=True):
+    """(variable derivatives, parameter derivatives) -- dagnn semantics: derivatives add at forks; a BatchNorm's
+    third parameter derivative is the batch moments."""
+    D = dict(der_outputs)
+    DP = {}
+
+    def add(name, d):
+        if d is not None:
+            D[name] = d if name not in D else D[name] + d
+
+    for l in reversed(graph):
+        dz = D.get(l.outputs[0])
+        if dz is None:
+            continue
+        ins = [V.get(v) for v in l.inputs]
+        a = l.attrs
+        if l.type == "conv":
+            first = l.inputs[0] == "data"
+            dx, df, db = O.vl_nnconv(ins[0], P[l.params[0]], P[l.params[1]] if a["hasBias"] else None, dz,
+                                     stride=a["stride"], pad=a["pad"], acc64=acc64, no_der_data=first)
+            add(l.inputs[0], dx)
+            DP[l.params[0]] = df
+            if a["hasBias"]:
+                DP[l.params[1]] = db
+        elif l.type == "bnorm":
+            dx, dg, db, mom = O.vl_nnbnorm(ins[0], P[l.params[0]], P[l.params[1]], dz, epsilon=a["epsilon"],
+                                           moments=P[l.params[2]] if mode == "test" else None, acc64=acc64)
+            add(l.inputs[0], dx)
+            DP[l.params[0]], DP[l.params[1]], DP[l.params[2]] = dg, db, mom
+        elif l.type == "relu":
+            add(l.inputs[0], O.vl_nnrelu(ins[0], dz))
+        elif l.type == "sigmoid":
+            add(l.inputs[0], O.vl_nnsigmoid(ins[0], dz))
+        elif l.type == "gpool":
+            add(l.inputs[0], O.vl_nnpool(ins[0], ins[0].shape[:2], dz, method=a["method"]))
+        elif l.type == "pool":
+            add(l.inputs[0], O.vl_nnpool(ins[0], a["poolSize"], dz, stride=a["stride"], pad=a["pad"],
+                                         method=a["method"]))
+        elif l.type == "sum":
+            add(l.inputs[0], dz)
+            add(l.inputs[1], dz)
+        elif l.type == "axpy":
+            dx, da = O.scale_backward(ins[1], ins[0], dz)
+            add(l.inputs[0], da)
+            add(l.inputs[1], dx)
+            add(l.inputs[2], dz)
+        elif l.type == "softmaxceloss":
+            add(l.inputs[0], O.vl_nnsoftmaxceloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(),
+                                                  temperature=a["temperature"], logit_targets=a["logitTargets"]))
+        elif l.type == "loss":
+            add(l.inputs[0], O.vl_nnloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(), loss=a["loss"]))
+        elif l.type == "errorstats":
+            pass
+        else:
+            raise NotImplementedError(l.type)
+    return D, DP
+
+
+def calibrate_moments(graph, P, x):
+    """one train-mode forward over x; every BatchNorm's batch moments become its stored `moments` (what
+    trainMethod 'average' converges to on a stationary input distribution)."""
+    V = forward(graph, {"data": x}, P, mode="normal", acc64=True, keep=())
+    for l in graph:
+        if l.type == "bnorm":
+            P[l.params[2]] = np.asfortranarray(V["__aux__"][l.name].astype(np.float32))
+    return P
+
+
+# ---------------------------------------------------------------------------------------------------
+# arithmetic of the tables (known answers used by tests/test_graph_tables.py)
+# ---------------------------------------------------------------------------------------------------
+def shapes(graph, in_shape):
+    """output H x W x C of every variable for one sample."""
+    S = {"data": tuple(in_shape)}
+    for l in graph:
+        a = l.attrs
+        if l.inputs[0] not in S:
+            continue
+        H, W, C = S[l.inputs[0]]
+        if l.type == "conv":
+            FH, FW, FC, K = a["size"]
+            assert FC == C, (l.name, FC, C)
+            pt, pb, pl, pr = a["pad"]
+            S[l.outputs[0]] = (O.conv_out_size(H, pt, pb, FH, 1, a["stride"][0]),
+                               O.conv_out_size(W, pl, pr, FW, 1, a["stride"][1]), K)
+        elif l.type == "pool":
+            pt, pb, pl, pr = a["pad"]
+            S[l.outputs[0]] = (O.conv_out_size(H, pt, pb, a["poolSize"][0], 1, a["stride"][0]),
+                               O.conv_out_size(W, pl, pr, a["poolSize"][1], 1, a["stride"][1]), C)
+        elif l.type == "gpool":
+            S[l.outputs[0]] = (1, 1, C)
+        elif l.type == "axpy":
+            S[l.outputs[0]] = S[l.inputs[1]]
+        elif l.type in ("softmaxceloss", "loss", "errorstats"):
+            S[l.outputs[0]] = (1, 1, 1)
+        else:
+            S[l.outputs[0]] = (H, W, C)
+    return S
+
+
+def macs(graph, in_shape):
+    S = shapes(graph, in_shape)
+    total = 0
+    for l in graph:
+        if l.type == "conv":
+            Ho, Wo, K = S[l.outputs[0]]
+            FH, FW, FC, _ = l.attrs["size"]
+            total += Ho * Wo * K * FH * FW * FC
+    return total
