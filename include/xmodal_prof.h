@@ -20,6 +20,10 @@ int xm_debug_force_conv_cfg(int cfg);
 int xm_debug_num_conv_cfgs(void);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);
+/* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,
+   XCC_ID}; out[4 * nblocks] receives the records of the most recent launch (synchronise first).
+   tools/conv_bench.py --cycles */
+int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks);
 #ifdef __cplusplus
 }
 #endif

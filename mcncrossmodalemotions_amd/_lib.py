@@ -76,6 +76,7 @@ _RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
 # test hooks (not part of include/xmodal.h)
 _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           "xm_debug_force_conv_splits": [_i],
+          "xm_debug_conv_cycles": [_i, C.POINTER(C.c_ulonglong), _i],
           # include/xmodal_prof.h
           "xm_prof_enable": [_i],
           "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),

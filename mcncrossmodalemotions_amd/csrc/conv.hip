@@ -119,10 +119,10 @@ static void launch_reduce_splits(const float *part, float *out, size_t total, in
 // dzdb(k) = sum over pixels and samples of dzdy(:,:,k,:): grid (K, S) partial sums, then a
 // fixed-order finalize (deterministic)
 __global__ void __launch_bounds__(256)
-bias_grad_partial_kernel(const float *__restrict__ dy, float *__restrict__ part, int HW, int K, int N,
+bias_grad_partial_kernel(const float *__restrict__ dy, double *__restrict__ part, int HW, int K, int N,
                          int S) {
   int k = blockIdx.x, sp = blockIdx.y;
-  float s = 0.f;
+  double s = 0.0;
   const bool vec = (HW & 3) == 0;
   for (int n = sp; n < N; n += S) {
     const float *p = dy + (size_t)HW * (k + (size_t)K * n);
@@ -130,26 +130,26 @@ bias_grad_partial_kernel(const float *__restrict__ dy, float *__restrict__ part,
       const float4 *p4 = reinterpret_cast<const float4 *>(p);
       for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
         float4 v = p4[i];
-        s += (v.x + v.y) + (v.z + v.w);
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
       }
     } else {
-      for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+      for (int i = threadIdx.x; i < HW; i += 256) s += (double)p[i];
     }
   }
-  __shared__ float red[4];
-  s = xm_wave_sum(s);
+  __shared__ double red[4];
+  s = xm_wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[(size_t)k * S + sp] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void bias_grad_finalize_kernel(const float *__restrict__ part, float *__restrict__ db, int K,
+__global__ void bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ db, int K,
                                           int S) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  float s = 0.f;
+  double s = 0.0;
   for (int i = 0; i < S; ++i) s += part[(size_t)k * S + i];
-  db[k] = s;
+  db[k] = (float)s;
 }
 
 // ---- tile configuration ---------------------------------------------------------------------
@@ -223,6 +223,7 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 }
 
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
+static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
 // ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) --------
 struct ProfRec {
@@ -280,6 +281,7 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   splits = (a.nkt + a.tilesPerSplit - 1) / a.tilesPerSplit;
   a.NPs = (a.NP + 3) & ~3;
   a.slab = splits > 1 ? slab : nullptr;
+  a.dbgCycles = g_dbg_cycles;
   dim3 grid(a.nbm * a.nbn, splits);
   {
     ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st);
@@ -914,6 +916,23 @@ int xm_debug_force_conv_cfg(int cfg) {
   return old;
 }
 int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
+// on = 1: every block (< 4096) of every later conv_gemm launch records {first clock, last clock, HW_ID, XCC_ID};
+// out (4 * nblocks words) receives the records of the most recent launch (caller synchronises first).
+// Debugging / tools only.
+int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks) {
+  const size_t bytes = 4096 * 4 * sizeof(unsigned long long);
+  if (on && !g_dbg_cycles) {
+    if (hipMalloc((void **)&g_dbg_cycles, bytes) != hipSuccess) return XM_ENOMEM;
+    (void)hipMemset(g_dbg_cycles, 0, bytes);
+  }
+  if (out && g_dbg_cycles)
+    (void)hipMemcpy(out, g_dbg_cycles, (size_t)std::min(nblocks, 4096) * 32, hipMemcpyDeviceToHost);
+  if (!on && g_dbg_cycles) {
+    (void)hipFree(g_dbg_cycles);
+    g_dbg_cycles = nullptr;
+  }
+  return XM_OK;
+}
 int xm_debug_force_conv_splits(int splits) {
   int old = g_force_splits;
   g_force_splits = splits > 0 ? splits : 0;
@@ -1021,9 +1040,9 @@ int xm_nnconv_backward_accum(const float *x, int H, int W, int C, int N, const f
     int S = std::max(1, std::min(N, 2048 / K));
     if ((long long)g.Ho * g.Wo < 1024) S = 1;
     WsCarver ws;
-    rc = ws.init(WsCarver::need((size_t)K * S, 4), st);
+    rc = ws.init(WsCarver::need((size_t)K * S, 8), st);
     if (rc) return rc;
-    float *part = ws.take<float>((size_t)K * S);
+    double *part = ws.take<double>((size_t)K * S);
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(K, S), dim3(256), 0, st, dzdy, part, g.Ho * g.Wo,
                        K, N, S);
     XM_LAUNCH_CHECK();

@@ -59,6 +59,7 @@ struct ConvGemmArgs {
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
+  unsigned long long *dbgCycles;  // debug (xm_debug_conv_cycles): per-block {first clock, last clock, HW_ID, XCC_ID}
 };
 
 // XCD-aware, bijective block remap: consecutive logical tiles (which share the same pixel tile)
@@ -511,7 +512,18 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 template <int TM, int TN, int WGM, int WGN, int MODE>
 __global__ void __launch_bounds__(256, 2)
 conv_gemm_kernel(const ConvGemmArgs a) {
+  unsigned long long c0 = 0;
+  if (a.dbgCycles) c0 = __builtin_readcyclecounter();
   conv_gemm_body<TM, TN, WGM, WGN, MODE>(a);
+  if (a.dbgCycles && threadIdx.x == 0) {
+    const unsigned b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (b < 4096) {
+      a.dbgCycles[4 * b + 0] = c0;
+      a.dbgCycles[4 * b + 1] = __builtin_readcyclecounter();
+      a.dbgCycles[4 * b + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+      a.dbgCycles[4 * b + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+  }
 }
 
 // Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity

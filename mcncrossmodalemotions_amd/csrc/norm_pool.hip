@@ -9,12 +9,12 @@
 namespace xm {
 
 // ============================== batch normalisation =========================================
-// Per-channel moments over H*W*N.  One pass, shifted sums (shift = first element of the channel)
-// so that var = E[(x-s)^2] - E[x-s]^2 does not cancel catastrophically in fp32.
+// Per-channel moments over H*W*N.  One pass, shifted sums (shift = first element of the channel), fp64
+// accumulators: the student's first layer reduces 1.2 M values per channel at 32 samples.
 // grid = (C, S): block (c, s) reduces samples s, s+S, ... of channel c.
-__device__ __forceinline__ void block_reduce2(float &a, float &b, float *red /*8 floats*/) {
-  a = xm_wave_sum(a);
-  b = xm_wave_sum(b);
+__device__ __forceinline__ void block_reduce2(double &a, double &b, double *red /*8 doubles*/) {
+  a = xm_wave_sum_d(a);
+  b = xm_wave_sum_d(b);
   int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     red[w] = a;
@@ -27,11 +27,11 @@ __device__ __forceinline__ void block_reduce2(float &a, float &b, float *red /*8
 }
 
 __global__ void __launch_bounds__(256)
-bn_stats_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int HW, int C, int N,
+bn_stats_partial_kernel(const float *__restrict__ x, double *__restrict__ part, int HW, int C, int N,
                         int S) {
   const int c = blockIdx.x, s = blockIdx.y;
   const float shift = x[(size_t)HW * c];
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   const bool vec = (HW & 3) == 0;
   for (int n = s; n < N; n += S) {
     const float *p = x + (size_t)HW * (c + (size_t)C * n);
@@ -39,19 +39,19 @@ bn_stats_partial_kernel(const float *__restrict__ x, float *__restrict__ part, i
       const float4 *p4 = reinterpret_cast<const float4 *>(p);
       for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
         float4 v = p4[i];
-        float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+        double d0 = (double)v.x - shift, d1 = (double)v.y - shift, d2 = (double)v.z - shift, d3 = (double)v.w - shift;
         a += (d0 + d1) + (d2 + d3);
         b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     } else {
       for (int i = threadIdx.x; i < HW; i += 256) {
-        float d = p[i] - shift;
+        double d = (double)p[i] - shift;
         a += d;
         b += d * d;
       }
     }
   }
-  __shared__ float red[8];
+  __shared__ double red[8];
   block_reduce2(a, b, red);
   if (threadIdx.x == 0) {
     part[2 * ((size_t)c * S + s)] = a;
@@ -60,22 +60,22 @@ bn_stats_partial_kernel(const float *__restrict__ x, float *__restrict__ part, i
 }
 
 // moments(c) = [mean, sqrt(var + eps)]
-__global__ void bn_finalize_kernel(const float *__restrict__ x, const float *__restrict__ part,
-                                   float *__restrict__ mom, int HW, int C, int S, float m,
+__global__ void bn_finalize_kernel(const float *__restrict__ x, const double *__restrict__ part,
+                                   float *__restrict__ mom, int HW, int C, int S, double m,
                                    float eps) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   for (int s = 0; s < S; ++s) {
     a += part[2 * ((size_t)c * S + s)];
     b += part[2 * ((size_t)c * S + s) + 1];
   }
-  float shift = x[(size_t)HW * c];
-  float d = a / m;
-  float var = b / m - d * d;
-  var = var < 0.f ? 0.f : var;
-  mom[c] = shift + d;
-  mom[C + c] = sqrtf(var + eps);
+  double shift = x[(size_t)HW * c];
+  double d = a / m;
+  double var = b / m - d * d;
+  var = var < 0.0 ? 0.0 : var;
+  mom[c] = (float)(shift + d);
+  mom[C + c] = (float)sqrt(var + (double)eps);
 }
 
 // y = g/sigma * (x - mu) + b   [relu]
@@ -119,10 +119,10 @@ bn_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const float 
 __global__ void __launch_bounds__(256)
 bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                       const float *__restrict__ yfwd, const float *__restrict__ mom,
-                      float *__restrict__ part, int HW, int C, int N, int S) {
+                      double *__restrict__ part, int HW, int C, int N, int S) {
   const int c = blockIdx.x, s = blockIdx.y;
-  const float mu = mom[c];
-  float a = 0.f, b = 0.f;
+  const double mu = mom[c];
+  double a = 0.0, b = 0.0;
   const bool vec = (HW & 3) == 0;
   for (int n = s; n < N; n += S) {
     size_t off = (size_t)HW * (c + (size_t)C * n);
@@ -139,19 +139,20 @@ bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
           dv.z = yv.z > 0.f ? dv.z : 0.f;
           dv.w = yv.w > 0.f ? dv.w : 0.f;
         }
-        a += (dv.x + dv.y) + (dv.z + dv.w);
-        b += (dv.x * (xv.x - mu) + dv.y * (xv.y - mu)) + (dv.z * (xv.z - mu) + dv.w * (xv.w - mu));
+        a += ((double)dv.x + (double)dv.y) + ((double)dv.z + (double)dv.w);
+        b += ((double)dv.x * ((double)xv.x - mu) + (double)dv.y * ((double)xv.y - mu)) +
+             ((double)dv.z * ((double)xv.z - mu) + (double)dv.w * ((double)xv.w - mu));
       }
     } else {
       for (int i = threadIdx.x; i < HW; i += 256) {
         float d = dy[off + i];
         if (yfwd && !(yfwd[off + i] > 0.f)) d = 0.f;
-        a += d;
-        b += d * (x[off + i] - mu);
+        a += (double)d;
+        b += (double)d * ((double)x[off + i] - mu);
       }
     }
   }
-  __shared__ float red[8];
+  __shared__ double red[8];
   block_reduce2(a, b, red);
   if (threadIdx.x == 0) {
     part[2 * ((size_t)c * S + s)] = a;
@@ -160,20 +161,20 @@ bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
 }
 
 // sums(c) = [sum dy, sum dy*(x-mu)];  dg = sums1 / sigma, db = sums0
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, const float *__restrict__ mom,
-                                       float *__restrict__ sums, float *__restrict__ dg,
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ part, const float *__restrict__ mom,
+                                       double *__restrict__ sums, float *__restrict__ dg,
                                        float *__restrict__ db, int C, int S) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   for (int s = 0; s < S; ++s) {
     a += part[2 * ((size_t)c * S + s)];
     b += part[2 * ((size_t)c * S + s) + 1];
   }
   sums[c] = a;
   sums[C + c] = b;
-  if (dg) dg[c] = b / mom[C + c];
-  if (db) db[c] = a;
+  if (dg) dg[c] = (float)(b / (double)mom[C + c]);
+  if (db) db[c] = (float)a;
 }
 
 // train: dx = g/sigma * (dy - sum_dy/m - (x-mu) * sum_dyx / (m sigma^2));  test: dx = g/sigma * dy
@@ -182,17 +183,19 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                     const float *__restrict__ yfwd, float *__restrict__ dx,
                     const float *__restrict__ g, const float *__restrict__ mom,
-                    const float *__restrict__ sums, FastDiv divHW, int C, size_t total, float m,
+                    const double *__restrict__ sums, FastDiv divHW, int C, size_t total, double m,
                     int train) {
   size_t stride = (size_t)gridDim.x * 256;
   const size_t cnt = VEC ? (total >> 2) : total;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < cnt; i += stride) {
     uint32_t plane = xm_div((uint32_t)(VEC ? (i << 2) : i), divHW);
     int c = plane % C;
-    float sg = mom[C + c], mu = mom[c];
-    float gs = g[c] / sg;
-    float c1 = train ? sums[c] / m : 0.f;
-    float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
+    // coefficients and the per-element expression in fp64, ONE rounding per output: the means c1 / c2 are
+    // then exact to ~1e-16 and sum(dx) over a channel stays at the sqrt(m) * ulp(dx) level
+    const double sg = mom[C + c], mu = mom[c];
+    const double gs = (double)g[c] / sg;
+    const double c1 = train ? sums[c] / m : 0.0;
+    const double c2 = train ? sums[C + c] / (m * sg * sg) : 0.0;
     if (VEC) {
       float4 xv = reinterpret_cast<const float4 *>(x)[i];
       float4 dv = reinterpret_cast<const float4 *>(dy)[i];
@@ -204,15 +207,15 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         dv.w = yv.w > 0.f ? dv.w : 0.f;
       }
       float4 o;
-      o.x = gs * (dv.x - c1 - (xv.x - mu) * c2);
-      o.y = gs * (dv.y - c1 - (xv.y - mu) * c2);
-      o.z = gs * (dv.z - c1 - (xv.z - mu) * c2);
-      o.w = gs * (dv.w - c1 - (xv.w - mu) * c2);
+      o.x = (float)(gs * ((double)dv.x - c1 - ((double)xv.x - mu) * c2));
+      o.y = (float)(gs * ((double)dv.y - c1 - ((double)xv.y - mu) * c2));
+      o.z = (float)(gs * ((double)dv.z - c1 - ((double)xv.z - mu) * c2));
+      o.w = (float)(gs * ((double)dv.w - c1 - ((double)xv.w - mu) * c2));
       reinterpret_cast<float4 *>(dx)[i] = o;
     } else {
       float d = dy[i];
       if (yfwd && !(yfwd[i] > 0.f)) d = 0.f;
-      dx[i] = gs * (d - c1 - (x[i] - mu) * c2);
+      dx[i] = (float)(gs * ((double)d - c1 - ((double)x[i] - mu) * c2));
     }
   }
 }
@@ -248,14 +251,14 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
   const float *mom = moments_in;
   WsCarver ws;
   if (!moments_in) {
-    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + WsCarver::need((size_t)2 * C, 4), st);
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 8) + WsCarver::need((size_t)2 * C, 4), st);
     if (rc) return rc;
-    float *part = ws.take<float>((size_t)2 * C * S);
+    double *part = ws.take<double>((size_t)2 * C * S);
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
     XM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
-                       C, S, (float)((double)HW * N), eps);
+                       C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
   } else if (moments_out) {
@@ -284,17 +287,18 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
   const int HW = H * W;
   const int S = bn_splits(C, N);
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * S, 4) + 2 * WsCarver::need((size_t)2 * C, 4), st);
+  rc = ws.init(WsCarver::need((size_t)2 * C * S, 8) + WsCarver::need((size_t)2 * C, 8) +
+                   WsCarver::need((size_t)2 * C, 4), st);
   if (rc) return rc;
-  float *part = ws.take<float>((size_t)2 * C * S);
-  float *sums = ws.take<float>((size_t)2 * C);
+  double *part = ws.take<double>((size_t)2 * C * S);
+  double *sums = ws.take<double>((size_t)2 * C);
   const float *mom = moments_in;
   if (!moments_in) {
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
     XM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
-                       C, S, (float)((double)HW * N), eps);
+                       C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
   } else if (moments_out) {
@@ -309,7 +313,7 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
   if (dx_out) {
     size_t total = (size_t)HW * C * N;
     FastDiv d = make_fastdiv((uint32_t)HW);
-    float m = (float)((double)HW * N);
+    double m = (double)HW * N;
     int train = (moments_in && !batch_moments) ? 0 : 1;
     bool al = ((((uintptr_t)x | (uintptr_t)dzdy | (uintptr_t)dx_out | (uintptr_t)yfwd) & 15) == 0);
     if ((HW & 3) == 0 && al)
@@ -638,13 +642,13 @@ __global__ void __launch_bounds__(256)
 bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ gg,
                           const float *__restrict__ bb, const float *__restrict__ mom,
                           const unsigned char *__restrict__ amax, const float *__restrict__ dp,
-                          float *__restrict__ part, PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N,
+                          double *__restrict__ part, PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N,
                           int S, int gz) {
   const int c = blockIdx.y;
   const int zz = blockIdx.z / S, sp = blockIdx.z % S;
   const int h = zz * blockDim.x + threadIdx.x;
   const int w = blockIdx.x * blockDim.y + threadIdx.y;
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   if (h < g.H && w < g.W) {
     const Route4 r = make_route(g, h, w, divSy, divSx);
     const float mu = mom[c], sc = gg[c] / mom[C + c], bc = bb[c];
@@ -653,16 +657,16 @@ bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__
       float xv = x[plane * g.H * g.W + h + (size_t)g.H * w];
       float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
       d = (sc * (xv - mu) + bc > 0.f) ? d : 0.f;
-      a += d;
-      b += d * (xv - mu);
+      a += (double)d;
+      b += (double)d * ((double)xv - (double)mu);
     }
   }
-  __shared__ float red[8];
+  __shared__ double red[8];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-  if (tid < 8) red[tid] = 0.f;  // blocks may hold fewer than 4 waves (small planes)
+  if (tid < 8) red[tid] = 0.0;  // blocks may hold fewer than 4 waves (small planes)
   __syncthreads();
-  a = xm_wave_sum(a);
-  b = xm_wave_sum(b);
+  a = xm_wave_sum_d(a);
+  b = xm_wave_sum_d(b);
   if ((tid & 63) == 0) {
     red[tid >> 6] = a;
     red[4 + (tid >> 6)] = b;
@@ -683,38 +687,39 @@ bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__
 __global__ void __launch_bounds__(256)
 bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gg,
                         const float *__restrict__ bb, const float *__restrict__ mom,
-                        const float *__restrict__ sums, const unsigned char *__restrict__ amax,
-                        const float *__restrict__ dp, float *__restrict__ dx, float *__restrict__ part2,
-                        PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N, int S, float m,
+                        const double *__restrict__ sums, const unsigned char *__restrict__ amax,
+                        const float *__restrict__ dp, float *__restrict__ dx, double *__restrict__ part2,
+                        PoolGeo g, FastDiv divSy, FastDiv divSx, int C, int N, int S, double m,
                         int train) {
   const int c = blockIdx.y;
   const int zz = blockIdx.z / S, sp = blockIdx.z % S;
   const int h = zz * blockDim.x + threadIdx.x;
   const int w = blockIdx.x * blockDim.y + threadIdx.y;
-  float acc = 0.f;
+  double acc = 0.0;
   if (h < g.H && w < g.W) {
     const Route4 r = make_route(g, h, w, divSy, divSx);
     const float mu = mom[c], sg = mom[C + c];
     const float gs = gg[c] / sg, bc = bb[c];
-    const float c1 = train ? sums[c] / m : 0.f;
-    const float c2 = train ? sums[C + c] / (m * sg * sg) : 0.f;
+    const double gsd = (double)gg[c] / (double)sg;
+    const double c1 = train ? sums[c] / m : 0.0;
+    const double c2 = train ? sums[C + c] / (m * (double)sg * (double)sg) : 0.0;
     for (int n = sp; n < N; n += S) {
       const size_t plane = (size_t)c + (size_t)C * n;
       const size_t xi = plane * g.H * g.W + h + (size_t)g.H * w;
       float xv = x[xi];
       float d = routed(amax, dp, plane * g.Ho * g.Wo, r);
       d = (gs * (xv - mu) + bc > 0.f) ? d : 0.f;
-      float o = gs * (d - c1 - (xv - mu) * c2);
+      float o = (float)(gsd * ((double)d - c1 - ((double)xv - (double)mu) * c2));
       dx[xi] = o;
-      acc += o;
+      acc += (double)o;
     }
   }
   if (part2) {
-    __shared__ float red[4];
+    __shared__ double red[4];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    if (tid < 4) red[tid] = 0.f;
+    if (tid < 4) red[tid] = 0.0;
     __syncthreads();
-    acc = xm_wave_sum(acc);
+    acc = xm_wave_sum_d(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) {
@@ -724,12 +729,12 @@ bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g
   }
 }
 
-__global__ void sum_partials_kernel(const float *__restrict__ part, float *__restrict__ out, int C, int S) {
+__global__ void sum_partials_kernel(const double *__restrict__ part, float *__restrict__ out, int C, int S) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
+  double s = 0.0;
   for (int i = 0; i < S; ++i) s += part[(size_t)c * S + i];
-  out[c] = s;
+  out[c] = (float)s;
 }
 
 static int pool_backward(const float *x, const unsigned char *amax, int H, int W, int C, int N, int ph,
@@ -775,13 +780,13 @@ static int bnrelupool_forward(const float *x, int H, int W, int C, int N, const 
   if (!moments_in) {
     const int S = bn_splits(C, N);
     WsCarver ws;
-    rc = ws.init(WsCarver::need((size_t)2 * C * S, 4), st);
+    rc = ws.init(WsCarver::need((size_t)2 * C * S, 8), st);
     if (rc) return rc;
-    float *part = ws.take<float>((size_t)2 * C * S);
+    double *part = ws.take<double>((size_t)2 * C * S);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
     XM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, moments_out,
-                       HW, C, S, (float)((double)HW * N), eps);
+                       HW, C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
   } else if (moments_out != moments_in) {
     XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
@@ -809,12 +814,12 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   int S = std::max(1, std::min(N, 4096 / std::max(1, C * gx * gz)));
   size_t nb = (size_t)gx * gz * S;
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 4) + WsCarver::need((size_t)2 * C, 4) +
-                   WsCarver::need((size_t)C * nb, 4), st);
+  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 8) + WsCarver::need((size_t)2 * C, 8) +
+                   WsCarver::need((size_t)C * nb, 8), st);
   if (rc) return rc;
-  float *part = ws.take<float>((size_t)2 * C * nb);
-  float *sums = ws.take<float>((size_t)2 * C);
-  float *part2 = dxsum_out ? ws.take<float>((size_t)C * nb) : nullptr;
+  double *part = ws.take<double>((size_t)2 * C * nb);
+  double *sums = ws.take<double>((size_t)2 * C);
+  double *part2 = dxsum_out ? ws.take<double>((size_t)C * nb) : nullptr;
   if (dxsum_out && !dx_out) return fail(XM_EINVAL, "bnorm+relu+pool backward: dxsum needs dx");
   dim3 grid(gx, C, gz * S), block(bx, by);
   FastDiv dsy = make_fastdiv((uint32_t)sy), dsx = make_fastdiv((uint32_t)sx);
@@ -826,7 +831,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   XM_LAUNCH_CHECK();
   if (dx_out) {
     hipLaunchKernelGGL(bnpool_bwd_apply_kernel, grid, block, 0, st, x, g, b, moments, sums, amax,
-                       dzdy_pool, dx_out, part2, pg, dsy, dsx, C, N, S, (float)((double)H * W * N), train);
+                       dzdy_pool, dx_out, part2, pg, dsy, dsx, C, N, S, (double)H * W * N, train);
     XM_LAUNCH_CHECK();
     if (part2) {
       hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dxsum_out, C,

@@ -96,6 +96,15 @@ __device__ __forceinline__ float xm_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Reductions that decide a mean (bnorm moments, the two sums of its backward pass, bias derivatives) are
+// accumulated in fp64: these kernels are HBM-bound, so the fp64 adds are free, and the derivative sums of
+// a train-mode vl_nnbnorm cancel almost completely (sum of dx over a channel is exactly 0 in exact
+// arithmetic) -- an fp32 mean that is off by one ulp leaves a bias that the layers below amplify.
+__device__ __forceinline__ double xm_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __device__ __forceinline__ float xm_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

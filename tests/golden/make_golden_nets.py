@@ -15,7 +15,7 @@ regenerated from seeds by oracle.graphs (numpy Generator streams); the teachers'
 because they come out of an oracle forward pass.  The reference itself cannot produce vectors (MATLAB +
 un-vendored MatConvNet), so parity with the true binaries stays "unpinned" (oracle/xm_oracle.c header).
 
-    python tests/golden/make_golden_nets.py       # ~2 minutes on 8 cores
+    python tests/golden/make_golden_nets.py       # ~1.5 minutes on 8 cores
 """
 import os
 import sys
@@ -44,6 +44,21 @@ def sample_idx(n):
 def summarize(d):
     flat = np.asarray(d, np.float32).ravel(order="F")
     return np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum())), flat[sample_idx(flat.size)]
+
+
+def fp32_deviation(out, tag, g, inputs, P):
+    """How far the reference's OWN arithmetic type is from exact: the same pass through the oracle's fp32 path
+    (MatConvNet's CPU algorithm shape: im2row + SGEMM, fp32 accumulation) against the fp64-accumulate values stored
+    above, per parameter derivative, on the stored samples.  Several derivatives are sums with massive cancellation
+    (the filter derivative of conv1 sums 150 k products whose BN-centred factors sum to zero; a conv bias in front
+    of a train-mode BatchNorm has an exactly-zero derivative), so "5e-4 of the largest entry" is below fp32
+    round-off for them whatever the summation order; the GPU tests allow 5e-4 * max|ref| + 4 * dev32."""
+    V = G.forward(g, inputs, P, mode="normal", acc64=False)
+    _, DP = G.backward(g, V, {"objective": np.float32(1)}, P, mode="normal", acc64=False)
+    out[tag + "_prediction_dev32"] = np.float32(np.abs(V["prediction"] - out[tag + "_prediction"]).max())
+    for k, d in DP.items():
+        _, s = summarize(d)
+        out["%s_der_%s_dev32" % (tag, k)] = np.float32(np.abs(s.astype(np.float64) - out["%s_der_%s_samp" % (tag, k)]).max())
 
 
 def teacher_params(se, seed):
@@ -91,6 +106,7 @@ def main():
     out["stu_classerror"] = np.float32(V["classerror"])
     for k, d in DP.items():
         out["stu_der_%s_norm" % k], out["stu_der_%s_samp" % k] = summarize(d)
+    fp32_deviation(out, "stu", g, {"data": data, "logitTarget": lgo, "maxLabel": lab}, P)
     print("student: objective %.6f (%.1f s)" % (V["objective"], time.time() - t0), flush=True)
 
     t0 = time.time()
@@ -104,6 +120,7 @@ def main():
     out["jnt_objective"] = np.float32(V["objective"])
     for k, d in DP.items():
         out["jnt_der_%s_norm" % k], out["jnt_der_%s_samp" % k] = summarize(d)
+    fp32_deviation(out, "jnt", g, {"data": x, "label": lab}, P)
     print("joint: objective %.6f (%.1f s)" % (V["objective"], time.time() - t0), flush=True)
 
     path = os.path.join(HERE, "nets_full.npz")

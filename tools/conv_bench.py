@@ -30,6 +30,10 @@ CASES = {
     "t_res4_1x1c": (14, 14, 256, 1, 1, 1024, 1, 0),
     "t_res5_3x3": (7, 7, 512, 3, 3, 512, 1, 1),
     "t_res5_1x1c": (7, 7, 512, 1, 1, 2048, 1, 0),
+    # synthetic ceiling probes (9th entry = fixed N): 512 tiles of 128x128 = exactly two per CU, long reductions
+    "x_fill3x3": (64, 64, 512, 3, 3, 512, 1, 1, 4),
+    "x_fill1x1": (64, 64, 1024, 1, 1, 512, 1, 0, 4),
+    "x_fill3x3_1": (64, 32, 512, 3, 3, 512, 1, 1, 4),     # 256 tiles: one per CU
 }
 
 
@@ -52,12 +56,14 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dirs", default="fwd,dgrad,wgrad")
     ap.add_argument("--scan", action="store_true", help="time every tile configuration (forced)")
+    ap.add_argument("--cycles", action="store_true",
+                    help="fwd only: shader clocks spent by block 0 (cycles per 16-k stage, effective clock)")
     args = ap.parse_args()
     names = args.cases or list(CASES)
     print("%-12s %-6s %9s %9s" % ("case", "dir", "ms", "TFLOP/s"))
     for nm in names:
-        H, W, C, FH, FW, K, s, p = CASES[nm]
-        N = args.n
+        H, W, C, FH, FW, K, s, p = CASES[nm][:8]
+        N = CASES[nm][8] if len(CASES[nm]) > 8 else args.n
         x = vl.from_numpy(np.random.default_rng(0).standard_normal((H, W, C, N)).astype(np.float32))
         f = vl.from_numpy(np.random.default_rng(1).standard_normal((FH, FW, C, K)).astype(np.float32))
         b = vl.from_numpy(np.zeros((K, 1), np.float32))
@@ -76,7 +82,30 @@ def main():
                 ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_filters=True), args.reps)
             else:
                 ms = timeit(lambda: vl.vl_nnconv(x, f, None, dz, stride=s, pad=p, no_der_data=True), args.reps)
-            print("%-12s %-6s %9.3f %9.1f %s" % (nm, d, ms, flops / ms / 1e9, "" if cfg < 0 else "cfg%d" % cfg), flush=True)
+            extra = ""
+            if args.cycles and d == "fwd":
+                import ctypes
+                nb = 4096
+                buf = (ctypes.c_ulonglong * (4 * nb))()
+                L.xm_debug_conv_cycles(1, buf, 0)
+                for _ in range(3):
+                    vl.vl_nnconv(x, f, b, stride=s, pad=p)
+                torch.cuda.synchronize()
+                L.xm_debug_conv_cycles(0, buf, nb)
+                rec = np.array(buf[:], dtype=np.uint64).reshape(nb, 4)
+                rec = rec[rec[:, 1] > 0]
+                dur = (rec[:, 1] - rec[:, 0]).astype(np.float64)
+                stages = (FH * FW * C + 15) // 16
+                xcc = rec[:, 3] & 0xF
+                extra = "  %d blocks: clk/block min %.0f med %.0f max %.0f (%.0f clk/stage med)" % (
+                    len(dur), dur.min(), np.median(dur), dur.max(), np.median(dur) / stages)
+                for xc in sorted(set(xcc.tolist())):
+                    m = xcc == xc
+                    t0, t1 = rec[m, 0].astype(np.float64), rec[m, 1].astype(np.float64)
+                    extra += "\n      xcc%d: %3d blocks, span %.0f clk (first start -> last end), starts within %.0f, ends within %.0f, dur med %.0f" % (
+                        xc, m.sum(), t1.max() - t0.min(), t0.max() - t0.min(), t1.max() - t1.min(), np.median(t1 - t0))
+            print("%-12s %-6s %9.3f %9.1f %s%s" % (nm, d, ms, flops / ms / 1e9, "" if cfg < 0 else "cfg%d" % cfg, extra),
+                  flush=True)
         L.xm_debug_force_conv_cfg(-1)
 
 

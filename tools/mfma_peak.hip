@@ -47,10 +47,12 @@ __global__ void __launch_bounds__(256, 2) probe(float *out, int iters) {
 
 // VARIANT B: NV independent VALU ops after every MFMA (+ NL buffer loads per 16 MFMAs from a
 // 64 MB array), interleave enforced with sched_group_barrier like the convolution kernels.
+__device__ unsigned long long g_cyc[2];
 template <int NV, int NL, int NW>
 __global__ void __launch_bounds__(256, 4) probe_mix(float *out, const float *src, unsigned srcBytes, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
   const int t = threadIdx.x;
+  const unsigned long long c0 = __builtin_readcyclecounter();
   for (int i = t; i < 8192; i += 256) lds[i] = (float)(i & 7) * 0.001f;
   __syncthreads();
   f32x16 acc[4];
@@ -100,6 +102,10 @@ __global__ void __launch_bounds__(256, 4) probe_mix(float *out, const float *src
     __builtin_amdgcn_sched_barrier(0);
     if (it & 1) __syncthreads();
   }
+  if (blockIdx.x == 0 && t == 0) {
+    g_cyc[0] = c0;
+    g_cyc[1] = __builtin_readcyclecounter();
+  }
   float s = lsum;
   for (int k = 0; k < 8; ++k) s += (float)x[k];
   for (int i = 0; i < 4; ++i)
@@ -126,7 +132,12 @@ void run_mix(const char *name, int blocks, int iters) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   double fl = (double)blocks * 4 * iters * 16 * 4096.0;
-  printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, fl / ms / 1e9);
+  unsigned long long cyc[2];
+  hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof(cyc));
+  double c = (double)(cyc[1] - cyc[0]);
+  // s_memtime ticks at a fixed 100 MHz on this part when read through readcyclecounter?  print both views
+  printf("%-44s %8.3f ms  %7.1f TFLOP/s   block0: %.0f ticks = %.1f ticks/us, %.1f ticks per 16 mfma\n", name, ms,
+         fl / ms / 1e9, c, c / (ms * 1e3), c / iters);
   hipFree(out);
   hipFree(src);
 }
