@@ -166,13 +166,16 @@ def main():
             lab = vl.max_label(lgo)
 
     F = args.frames if wl == "distill" else 1
-    tstream = torch.cuda.Stream(device=dev) if (wl == "distill" and args.overlap_teacher and F == 1) else None
+    _tp = os.environ.get("XM_TEACHER_PRIO")
+    tstream = (torch.cuda.Stream(device=dev, priority=int(_tp)) if _tp is not None else torch.cuda.Stream(device=dev)) \
+        if (wl == "distill" and args.overlap_teacher and F == 1) else None
     frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if (wl == "teacher" or F > 1) else None
     if F > 1:
         first = torch.arange(0, nb, device=dev, dtype=torch.int32) * F + 1   # 1-based, inclusive
         last = first + (F - 1)
     if args.wgrad_stream:
-        side = torch.cuda.Stream(device=dev)
+        _sp = os.environ.get("XM_SIDE_PRIO")
+        side = torch.cuda.Stream(device=dev, priority=int(_sp)) if _sp is not None else torch.cuda.Stream(device=dev)
         if student is not None:
             student.wgradStream = side
         if wl == "joint":
@@ -286,6 +289,9 @@ def main():
         if len(inflight) > 2:
             inflight.pop(0).synchronize()
 
+    _mp = os.environ.get("XM_MAIN_PRIO")
+    if _mp is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(_mp)))
     for it in range(args.warmup):
         throttled_step(it)
     barrier()

@@ -920,6 +920,9 @@ int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
 // out (4 * nblocks words) receives the records of the most recent launch (caller synchronises first).
 // Debugging / tools only.
 int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks) {
+#ifndef XM_DEBUG_CYCLES
+  if (on) return fail(XM_ENOTSUP, "xm_debug_conv_cycles: library built without -DXM_DEBUG_CYCLES");
+#endif
   const size_t bytes = 4096 * 4 * sizeof(unsigned long long);
   if (on && !g_dbg_cycles) {
     if (hipMalloc((void **)&g_dbg_cycles, bytes) != hipSuccess) return XM_ENOMEM;

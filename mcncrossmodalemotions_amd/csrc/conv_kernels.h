@@ -512,9 +512,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 template <int TM, int TN, int WGM, int WGN, int MODE>
 __global__ void __launch_bounds__(256, 2)
 conv_gemm_kernel(const ConvGemmArgs a) {
-  unsigned long long c0 = 0;
-  if (a.dbgCycles) c0 = __builtin_readcyclecounter();
+#ifdef XM_DEBUG_CYCLES
+  // per-block shader-clock trace (tools/conv_bench.py --cycles).  Compile-time only: even as a never-taken
+  // branch it cost the whole step 4 % (the start-clock value stays live across the main loop).
+  const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
   conv_gemm_body<TM, TN, WGM, WGN, MODE>(a);
+#ifdef XM_DEBUG_CYCLES
   if (a.dbgCycles && threadIdx.x == 0) {
     const unsigned b = blockIdx.x + gridDim.x * blockIdx.y;
     if (b < 4096) {
@@ -524,6 +528,7 @@ conv_gemm_kernel(const ConvGemmArgs a) {
       a.dbgCycles[4 * b + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
     }
   }
+#endif
 }
 
 // Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity
