@@ -186,15 +186,31 @@ int xm_nnloss(const float *x, const float *labels, int C, int N, int loss, const
  * trainMethod 'gradient':  m <- momentum*m - (wd*w + der/batch);  w <- w + lr*m */
 int xm_sgd_update(float *w, float *m, const float *der, size_t n, float lr, float momentum,
                   float weight_decay, float batch, void *stream);
-/* trainMethod 'average' (BN moments):  w <- (1-lr)*w + lr*der/nworkers */
-int xm_average_update(float *w, const float *der, size_t n, float lr, float nworkers,
+/* trainMethod 'average' (BN moments):  w <- (1-lr)*w + lr*der/denom.
+ * MatConvNet [EXT]: dagnn.BatchNorm hands back moments * (its worker's batch size), the workers' values are summed
+ * and accumulateGradients divides by the GLOBAL batch size -- workers with ragged shards are weighted by their
+ * sample counts.  Single worker: der = the batch moments, denom = 1. */
+int xm_average_update(float *w, const float *der, size_t n, float lr, float denom,
                       void *stream);
+/* x <- a * x (the worker-batch-size weighting of the moments before the exchange) */
+int xm_scale_f32(float *x, size_t n, float a, void *stream);
 /* ParameterServer.{start,push,sync,pull}: sum of `buf` over all workers, in place, via RCCL.
  * xm_comm_init takes the 128-byte ncclUniqueId produced by xm_comm_unique_id on rank 0 and
  * distributed by the host (MATLAB labBroadcast / torch.distributed broadcast). */
 int xm_comm_unique_id(void *id128);
 int xm_comm_init(const void *id128, int rank, int world);
-int xm_allreduce_sum_f32(float *buf, size_t n, void *stream);
+int xm_allreduce_sum_f32(float *buf, size_t n, void *stream);   /* blocking-in-stream-order form: runs on `stream` */
+/* Overlapped form (what cnn_train_dag's push-as-derivatives-become-ready / sync-before-update does with 'tmove'):
+ *   xm_parserv_push(buf, n, producer)  after the kernels that wrote buf[0..n) were enqueued on `producer`: the sum over
+ *                                      all workers starts when they finish and runs on the communicator's own HIP
+ *                                      stream -- the producer stream goes on with the rest of the backward pass;
+ *   xm_parserv_sync(consumer)          once per minibatch before accumulateGradients: `consumer` waits (on the
+ *                                      device, not the host) for every push since the previous sync.
+ * Every element must be pushed exactly once per minibatch.  world == 1: both are no-ops. */
+int xm_parserv_push(float *buf, size_t n, void *producer_stream);
+int xm_parserv_sync(void *consumer_stream);
+/* ncclCommCount of the communicator (1 when no communicator exists): proof of the worker count */
+int xm_comm_count(int *ranks);
 int xm_comm_destroy(void);
 
 /* ---- batch-provider arithmetic (device side of getBatchEmoVoxCeleb / getImageBatch) ---------

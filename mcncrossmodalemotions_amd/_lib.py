@@ -63,6 +63,10 @@ SIGNATURES = {
     "xm_comm_unique_id": [_vp],
     "xm_comm_init": [_vp, _i, _i],
     "xm_allreduce_sum_f32": [c_fp, _sz, _vp],
+    "xm_parserv_push": [c_fp, _sz, _vp],
+    "xm_parserv_sync": [_vp],
+    "xm_comm_count": [C.POINTER(C.c_int)],
+    "xm_scale_f32": [c_fp, _sz, _f, _vp],
     "xm_comm_destroy": [],
     "xm_spec_rownorm": [c_fp, _i, _i, _i, c_fp, _vp],
     "xm_spec_magnitude": [c_fp, _i, _i, _i, c_fp, _vp],
@@ -76,6 +80,7 @@ _RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
 # test hooks (not part of include/xmodal.h)
 _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           "xm_debug_force_conv_splits": [_i],
+          "xm_debug_comm_force_single": [_i],
           "xm_debug_conv_cycles": [_i, C.POINTER(C.c_ulonglong), _i],
           # include/xmodal_prof.h
           "xm_prof_enable": [_i],

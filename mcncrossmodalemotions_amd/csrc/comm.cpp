@@ -6,8 +6,26 @@
 
 #include "xm_common.h"
 
+#include <vector>
+
 static ncclComm_t g_comm = nullptr;
 static int g_world = 1;
+static int g_force_single = 0;             // debugging: a real 1-rank communicator (xm_debug_comm_force_single)
+// ParameterServer push/sync: the exchange runs on the communicator's OWN stream so that a bucket's all-reduce
+// overlaps whatever the producer stream does next (the rest of the backward pass)
+static hipStream_t g_ps_stream = nullptr;
+static std::vector<hipEvent_t> g_ps_events;
+static size_t g_ps_next = 0;
+static int g_ps_pending = 0;
+
+static hipEvent_t ps_event() {
+  if (g_ps_next == g_ps_events.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_ps_events.push_back(e);
+  }
+  return g_ps_events[g_ps_next++];
+}
 
 #define XM_NCCL(expr)                                                                   \
   do {                                                                                  \
@@ -31,7 +49,7 @@ int xm_comm_init(const void *id128, int rank, int world) {
   if (g_comm) return xm::fail(XM_EINVAL, "comm: already initialised");
   if (world < 1 || rank < 0 || rank >= world) return xm::fail(XM_EINVAL, "comm: bad rank/world");
   g_world = world;
-  if (world == 1) return XM_OK;  // single worker: ParameterServer is bypassed (numel(gpus) == 1)
+  if (world == 1 && !g_force_single) return XM_OK;  // single worker: ParameterServer is bypassed (numel(gpus) == 1)
   if (!id128) return xm::fail(XM_EINVAL, "comm: NULL id");
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
@@ -39,15 +57,66 @@ int xm_comm_init(const void *id128, int rank, int world) {
   return XM_OK;
 }
 
+int xm_debug_comm_force_single(int on) {
+  g_force_single = on != 0;
+  return XM_OK;
+}
+
+int xm_comm_count(int *ranks) {
+  if (!ranks) return xm::fail(XM_EINVAL, "comm: NULL output");
+  *ranks = 1;
+  if (g_comm) XM_NCCL(ncclCommCount(g_comm, ranks));
+  return XM_OK;
+}
+
+// ParameterServer.push: start the sum of `buf` over all workers as soon as everything already enqueued on
+// `producer_stream` has finished; returns at once (the exchange runs on the communicator's stream).
+int xm_parserv_push(float *buf, size_t n, void *producer_stream) {
+  if (!g_comm || n == 0) return XM_OK;
+  if (!buf) return xm::fail(XM_EINVAL, "parserv: NULL buffer");
+  if (!g_ps_stream) XM_HIP(hipStreamCreateWithFlags(&g_ps_stream, hipStreamNonBlocking));
+  hipEvent_t e = ps_event();
+  if (!e) return xm::fail(XM_EHIP, "parserv: event creation failed");
+  XM_HIP(hipEventRecord(e, (hipStream_t)producer_stream));
+  XM_HIP(hipStreamWaitEvent(g_ps_stream, e, 0));
+  XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, g_ps_stream));
+  ++g_ps_pending;
+  return XM_OK;
+}
+
+// ParameterServer.sync + pull: `consumer_stream` waits for every push issued since the last sync; the summed
+// values are then in place.  Does not block the host.
+int xm_parserv_sync(void *consumer_stream) {
+  if (!g_comm || !g_ps_pending) {
+    g_ps_next = 0;
+    return XM_OK;
+  }
+  hipEvent_t e = ps_event();
+  if (!e) return xm::fail(XM_EHIP, "parserv: event creation failed");
+  XM_HIP(hipEventRecord(e, g_ps_stream));
+  XM_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, e, 0));
+  g_ps_pending = 0;
+  g_ps_next = 0;   // events are re-recorded next step; stream order keeps earlier waits valid
+  return XM_OK;
+}
+
 int xm_allreduce_sum_f32(float *buf, size_t n, void *stream) {
-  if (g_world == 1 || n == 0) return XM_OK;
-  if (!g_comm) return xm::fail(XM_EINVAL, "comm: xm_comm_init has not been called");
+  if (!g_comm || n == 0) return XM_OK;
   if (!buf) return xm::fail(XM_EINVAL, "comm: NULL buffer");
   XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, (hipStream_t)stream));
   return XM_OK;
 }
 
 int xm_comm_destroy(void) {
+  if (g_ps_stream) {
+    (void)hipStreamSynchronize(g_ps_stream);
+    (void)hipStreamDestroy(g_ps_stream);
+    g_ps_stream = nullptr;
+  }
+  for (hipEvent_t e : g_ps_events) (void)hipEventDestroy(e);
+  g_ps_events.clear();
+  g_ps_next = 0;
+  g_ps_pending = 0;
   if (g_comm) {
     XM_NCCL(ncclCommDestroy(g_comm));
     g_comm = nullptr;

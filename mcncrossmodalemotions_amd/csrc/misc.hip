@@ -284,6 +284,11 @@ sgd_kernel(float *__restrict__ w, float *__restrict__ m, const float *__restrict
   }
 }
 
+__global__ void scale_kernel(float *__restrict__ x, size_t n, float a) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= a;
+}
+
 __global__ void average_kernel(float *__restrict__ w, const float *__restrict__ der, size_t n,
                                float lr, float inv_workers) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -522,6 +527,14 @@ int xm_sgd_update(float *w, float *m, const float *der, size_t n, float lr, floa
   int vec = ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)der) & 15) == 0) ? 1 : 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(vec ? n / 4 + 1 : n)), dim3(256), 0, (hipStream_t)stream,
                      w, m, der, n, lr, momentum, weight_decay, 1.0f / batch, vec);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_scale_f32(float *x, size_t n, float a, void *stream) {
+  if (n == 0) return XM_OK;
+  if (!x) return fail(XM_EINVAL, "scale: NULL tensor");
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, a);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

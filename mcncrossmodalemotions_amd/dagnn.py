@@ -454,6 +454,18 @@ class DagNN:
         self._side_pending = False
         self.device = None
         self._flat = None
+        # bumped whenever parameter VALUES change behind torch's back (raw-pointer HIP updates: xm_sgd_update /
+        # xm_average_update on the flat buffers, checkpoint loads, pack_params): cached derived quantities
+        # (folded test-mode bnorm scale / shift) are keyed on it.  Shared with replica()s (same parameters).
+        self._gen = [0]
+
+    @property
+    def paramGeneration(self):
+        return self._gen[0]
+
+    @paramGeneration.setter
+    def paramGeneration(self, v):
+        self._gen[0] = int(v)
 
     # ---- construction -------------------------------------------------------------------
     def addLayer(self, name, block, inputs, outputs, params=()):
@@ -521,6 +533,7 @@ class DagNN:
         for l in self.layers:
             r.layers.append(_LayerRec(l.name, copy.copy(l.block), l.inputs, l.outputs, l.params))
         r.params = self.params
+        r._gen = self._gen
         r.rebuild()
         for name, v in self.vars.items():
             r.vars[name].precious = v.precious
@@ -566,6 +579,7 @@ class DagNN:
                     self.params[pname].weightDecay = 0.0
                     self.params[pname].learningRate = 2.0
         self._flat = None
+        self.paramGeneration += 1
 
     def move(self, device="gpu"):
         """dag.move('gpu'): upload parameters (fetch_emovoxceleb_imdb.m:108)."""
@@ -605,6 +619,7 @@ class DagNN:
                 off += (n + 3) // 4 * 4
             segs.append((key, start, off))
         self._flat = FlatParams(val, der, mom, segs)
+        self.paramGeneration += 1
         return self._flat
 
     # ---- evaluation -----------------------------------------------------------------------
@@ -699,7 +714,10 @@ class DagNN:
             p.der = d if (p.der is None or seen == 0 and not self.accumulateParamDers) else vl.sum2(p.der, d)
 
     def _plan(self, training):
-        key = (training, self.mode, self.fuse, len(self.layers))
+        # the set of precious variables is part of the key: a fused step never materialises the intermediate
+        # variables it swallows, so marking one precious after a plan was built must rebuild the plan
+        key = (training, self.mode, self.fuse, len(self.layers),
+               tuple(n for n, v in self.vars.items() if v.precious))
         if getattr(self, "_plan_key", None) == key and getattr(self, "_plan_layers", None) == [
                 id(l) for l in self.layers]:
             return self._plan_cache
@@ -919,7 +937,8 @@ class _ConvFoldStep(_Step):
 
     def _fold(self, net):
         g, b, mom = [net.params[p].value for p in self.bn_rec.params]
-        key = (g.data_ptr(), b.data_ptr(), mom.data_ptr(), g._version, b._version, mom._version)
+        key = (g.data_ptr(), b.data_ptr(), mom.data_ptr(), g._version, b._version, mom._version,
+               net.paramGeneration)
         if self._folded is None or self._folded[0] != key:
             gn, bn_, mn = vl.to_numpy(g).ravel(), vl.to_numpy(b).ravel(), vl.to_numpy(mom)
             sc = (gn / mn[:, 1]).astype(np.float32)

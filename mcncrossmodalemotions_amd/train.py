@@ -29,106 +29,187 @@ class TrainOpts:
 
 
 class ParameterServer:
-    """ParameterServer.{start, push, pull, sync} collapsed to a sum-all-reduce.
+    """ParameterServer.{start, push, sync, pull, stop} of MatConvNet [EXT] (selected with
+    'parameterServer', struct('method','tmove') at run_distillation.m:88,181) as a sum-all-reduce over RCCL.
 
-    backend 'rccl-capi' : libxmodal_hip's own communicator (xm_comm_init + xm_allreduce_sum_f32),
-                          unique id distributed through torch.distributed's store;
-    backend 'torch'     : torch.distributed.all_reduce (nccl == RCCL on ROCm, gloo on CPU tests)."""
+        push(flat[a:b])   start summing that range over all workers as soon as the kernels already enqueued on the
+                          current stream have produced it; returns at once
+        sync()            the current stream waits (on the device) for every push since the last sync; the sums are
+                          then in place ("pull" is the identity: the reduction is in place)
+
+    backend 'rccl-capi' : the library's own communicator behind the C ABI (xm_comm_init + xm_parserv_push /
+                          xm_parserv_sync) -- what a MATLAB spmd host would bind; the 128-byte unique id travels
+                          through torch.distributed's store here (labBroadcast there);
+    backend 'torch'     : torch.distributed.all_reduce(async_op=True) (nccl == RCCL on ROCm, gloo on the CPU tests)."""
 
     def __init__(self, backend="torch"):
         self.backend = backend
         self.world = 1
         self.rank = 0
         self._started = False
+        self._handles = []
 
     def start(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        if self.world > 1 and self.backend == "rccl-capi":
+        if (self.world > 1 or self.force) and self.backend == "rccl-capi":
             L = _lib.load()
             buf = (C.c_char * 128)()
+            if self.world == 1:
+                _lib.check(L.xm_debug_comm_force_single(1))
             if self.rank == 0:
                 _lib.check(L.xm_comm_unique_id(buf))
-            t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
-                t = t.cuda()
-            dist.broadcast(t, 0)
-            raw = bytes(t.cpu().tolist())
+            raw = bytes(buf)
+            if self.world > 1:
+                t = torch.tensor(list(raw), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, 0)
+                raw = bytes(t.cpu().tolist())
             _lib.check(L.xm_comm_init(C.c_char_p(raw), self.rank, self.world))
         self._started = True
 
-    force = False  # debugging: run the collective even with a single worker
-    overlap = True  # 'torch' backend: bucketed exchange overlapped with the backward pass (GradBuckets)
+    force = False  # debugging: run the collectives even with a single worker
+    overlap = True  # bucketed exchange overlapped with the backward pass (GradBuckets); False: one exchange after it
 
-    def allreduce_(self, flat):
-        if self.world == 1 and not self.force:
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def push(self, part):
+        if not self.active or part.numel() == 0:
             return
         if self.backend == "rccl-capi":
-            _lib.check(_lib.load().xm_allreduce_sum_f32(C.c_void_p(flat.data_ptr()), flat.numel(),
-                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            _lib.check(_lib.load().xm_parserv_push(C.c_void_p(part.data_ptr()), part.numel(),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         else:
             import torch.distributed as dist
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._handles.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+
+    def sync(self):
+        if self.backend == "rccl-capi":
+            if self.active:
+                _lib.check(_lib.load().xm_parserv_sync(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        else:
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+
+    def allreduce_(self, flat):
+        """one exchange of a whole buffer (push + sync)"""
+        self.push(flat)
+        self.sync()
+
+    def comm_count(self):
+        """worker count as the communicator itself reports it (ncclCommCount / the process group)"""
+        if self.backend == "rccl-capi":
+            n = C.c_int(0)
+            _lib.check(_lib.load().xm_comm_count(C.byref(n)))
+            return int(n.value)
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_initialized() else 1
 
     def stop(self):
-        if self.backend == "rccl-capi" and self.world > 1:
+        self.sync()
+        if self.backend == "rccl-capi" and self.active:
             _lib.check(_lib.load().xm_comm_destroy())
 
 
 class GradBuckets:
-    """Overlapped gradient exchange: the filters of the last FC layers are 82 % of the
-    student's gradient bytes (fc6 37.7 MB + fc7 16.8 MB of 66.6 MB) and their derivatives are the FIRST
-    to be ready in the backward pass.  They form one contiguous range of the flat buffer (the tail of the
-    filter segment), which is all-reduced asynchronously as soon as the earliest of those layers has
-    enqueued its wgrad -- the rest of the backward pass (conv5 ... conv1, ~4 ms) hides it.  The
-    remainder (conv filters, biases, BN parameters and moments) goes out after the backward pass.
-    Same sums as one all-reduce over the whole buffer: every element is reduced exactly once."""
+    """Bucket plan of the overlapped gradient exchange.
 
-    def __init__(self, net, early_layers=("fc6", "fc7", "fc8")):
+    The derivatives of a network become ready from its LAST layer to its first.  The flat derivative buffer holds
+    the filters of one (trainMethod, lr, wd) group contiguously in layer order, so the tail of that segment is
+    complete first.  The plan cuts the filter segments, from the back, into buckets of >= `target_bytes` at
+    parameter boundaries; a bucket is pushed as soon as the earliest of its layers has enqueued its filter
+    derivative (dagnn calls gradHook(layer name) right there, on the stream the derivative was enqueued on), the
+    rest of the backward pass hides the exchange.  Whatever is not covered (biases, bnorm multipliers / biases /
+    moments -- small) goes out as one or two ranges after the pass.  Every element is pushed exactly once.
+
+    student (66.6 MB):  [fc6f fc7f fc8f] 54.5 MB on fc6  |  [conv1f..conv5f] 12 MB on conv1 ... | rest
+    SE-ResNet-50 (config 5, 104 MB): ~4 buckets of 24-32 MB along res5 / res4 / res3-2 | rest."""
+
+    def __init__(self, net, target_bytes=24 << 20):
+        from . import dagnn
         flat = net._flat
-        total = int(flat.der.numel())
-        recs = [net.getLayer(n) for n in early_layers]
-        recs = [r for r in recs if r is not None]
-        self.early = None
-        self.trigger = None
-        if recs:
-            ps = [net.params[r.params[0]] for r in recs]
-            a = min(p._flat_off for p in ps)
-            b = max(p._flat_off + (int(p.value.numel()) + 3) // 4 * 4 for p in ps)
-            inside = {id(q) for q in net.params.values() if a <= getattr(q, "_flat_off", -1) < b}
-            if inside == {id(p) for p in ps}:          # nothing else lives inside the range
-                self.early = (a, b)
-                order = {l.name: i for i, l in enumerate(net.layers)}
-                self.trigger = min((r.name for r in recs), key=lambda n: order[n])   # its backward runs last
-        self.rest = [(0, total)] if self.early is None else [(0, self.early[0]), (self.early[1], total)]
-        self.rest = [(a, b) for a, b in self.rest if b > a]
-        self.handles = []
         self.flat = flat
+        total = int(flat.der.numel())
+        order = {l.name: i for i, l in enumerate(net.layers)}
+        # filter parameters written by exactly one conv layer, with their flat ranges
+        items = []
+        for l in net.layers:
+            if isinstance(l.block, dagnn.Conv):
+                p = net.params[l.params[0]]
+                if p.fanout == 1 and hasattr(p, "_flat_off"):
+                    n = (int(p.value.numel()) + 3) // 4 * 4
+                    items.append((p._flat_off, p._flat_off + n, l.name))
+        items.sort()
+        # maximal runs of adjacent filters (one run per (trainMethod, lr, wd) segment in practice)
+        runs, cur = [], []
+        for it in items:
+            if cur and it[0] != cur[-1][1]:
+                runs.append(cur)
+                cur = []
+            cur.append(it)
+        if cur:
+            runs.append(cur)
+        self.buckets = []      # (a, b, trigger layer)
+        for run in runs:
+            acc = []
+            for it in reversed(run):           # from the back: those derivatives are ready first
+                acc.append(it)
+                if 4 * (acc[0][1] - acc[-1][0]) >= target_bytes:
+                    self.buckets.append((acc[-1][0], acc[0][1], min((x[2] for x in acc), key=lambda n: order[n])))
+                    acc = []
+            if acc:
+                self.buckets.append((acc[-1][0], acc[0][1], min((x[2] for x in acc), key=lambda n: order[n])))
+        # canonical push order = the order the backward pass reaches the trigger layers (last layer first); every
+        # worker -- also one whose shard is empty and that runs no backward pass -- issues its collectives in it
+        self.buckets.sort(key=lambda x: -order[x[2]])
+        self.by_trigger = {}
+        for a, b, t in self.buckets:
+            self.by_trigger.setdefault(t, []).append((a, b))
+        covered = sorted((a, b) for a, b, _ in self.buckets)
+        self.rest, pos = [], 0
+        for a, b in covered:
+            if a > pos:
+                self.rest.append((pos, a))
+            pos = b
+        if pos < total:
+            self.rest.append((pos, total))
+        self._sent = set()
+        self.log = None        # tests: list that receives every pushed (a, b)
 
     def ranges(self):
-        return ([self.early] if self.early else []) + self.rest
+        return [(a, b) for a, b, _ in self.buckets] + self.rest
 
     def begin(self):
-        self.handles = []
+        self._sent = set()
 
-    def on_layer(self, name):
-        if name == self.trigger:
-            import torch.distributed as dist
-            a, b = self.early
-            self.handles.append(dist.all_reduce(self.flat.der[a:b], op=dist.ReduceOp.SUM, async_op=True))
+    def _push(self, parserv, a, b):
+        if self.log is not None:
+            self.log.append((a, b))
+        parserv.push(self.flat.der[a:b])
 
-    def finish(self):
-        import torch.distributed as dist
-        if self.early is not None and not self.handles:       # trigger layer absent from this pass
-            self.rest_all = [self.early] + self.rest
-        else:
-            self.rest_all = self.rest
-        for a, b in self.rest_all:
-            dist.all_reduce(self.flat.der[a:b], op=dist.ReduceOp.SUM)
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+    def on_layer(self, parserv, name):
+        for a, b in self.by_trigger.get(name, ()):
+            self._sent.add((a, b))
+            self._push(parserv, a, b)
+
+    def finish(self, parserv):
+        for a, b, _ in self.buckets:           # trigger layer absent from this pass (frozen / idle worker)
+            if (a, b) not in self._sent:
+                self._push(parserv, a, b)
+        for a, b in self.rest:
+            self._push(parserv, a, b)
+        parserv.sync()
+
+
+def _in_buckets(buckets, a, b):
+    """does an early bucket overlap the flat range [a, b)?  (the moments segment is re-weighted after the backward
+    pass, so it must not have been pushed during it -- filters never share a bucket with it, this is a guard)"""
+    return any(x < b and a < y for x, y, _ in buckets.buckets)
 
 
 def shard_batch(batch, rank, world):
@@ -136,42 +217,63 @@ def shard_batch(batch, rank, world):
     return list(batch)[rank::world]
 
 
-def accumulate_gradients(net, opts, lr, global_batch, nworkers=1):
-    """accumulateGradients of cnn_train_dag (solver = []): per flat segment one fused launch."""
+def accumulate_gradients(net, opts, lr, global_batch, moments_denom=1.0):
+    """accumulateGradients of cnn_train_dag (solver = []): per flat segment one fused launch.
+    `moments_denom`: 1 for a single worker (der = the batch moments); the global batch size when the exchanged der
+    is sum_w moments_w * batch_w (train_step does that weighting)."""
     flat = net._flat
     for (method, lr_mult, wd_mult), a, b in flat.segments:
         if b == a:
             continue
         if method == "average":
-            vl.average_update(flat.val[a:b], flat.der[a:b], lr_mult, nworkers)
+            vl.average_update(flat.val[a:b], flat.der[a:b], lr_mult, moments_denom)
         else:
             vl.sgd_update(flat.val[a:b], flat.mom[a:b], flat.der[a:b], lr * lr_mult, opts.momentum,
                           opts.weightDecay * wd_mult, global_batch)
+    net.paramGeneration = getattr(net, "paramGeneration", 0) + 1   # folded / cached views of the parameters are stale
 
 
-def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, input_events=None):
-    """One minibatch of cnn_train_dag's processEpoch in training mode."""
+def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, input_events=None, local_batch=None):
+    """One minibatch of cnn_train_dag's processEpoch in training mode.
+
+    `inputs` None: this worker's interleaved shard of the minibatch is EMPTY (ragged tail smaller than the worker
+    count): it contributes zero derivatives / zero-weight moments but still joins the exchange -- every collective
+    is entered by every worker.  `local_batch`: samples of this worker's shard (default: global_batch / workers)."""
     if net._flat is None:
         net.pack_params()
     net.mode = "normal"
     world = parserv.world if parserv is not None else 1
-    exchange = parserv is not None and (world > 1 or parserv.force)
+    exchange = parserv is not None and parserv.active
+    global_batch = global_batch or opts.batchSize
+    if local_batch is None:
+        local_batch = 0 if inputs is None else global_batch / world
     buckets = None
-    if exchange and parserv.backend == "torch" and parserv.overlap:
+    if exchange and parserv.overlap:
         buckets = net.__dict__.get("_grad_buckets")
         if buckets is None or buckets.flat is not net._flat:
             buckets = net.__dict__["_grad_buckets"] = GradBuckets(net)
         buckets.begin()
-        net.gradHook = buckets.on_layer
+    net.gradHook = None
+    if buckets is not None and inputs is not None and not any(m == "average" for (m, _, _), a, b in net._flat.segments
+                                                              if b > a and _in_buckets(buckets, a, b)):
+        net.gradHook = lambda name: buckets.on_layer(parserv, name)
+    if inputs is None:
+        net._flat.der.zero_()
     else:
-        net.gradHook = None
-    net.eval(inputs, opts.derOutputs, input_events=input_events)
-    if buckets is not None:
-        buckets.finish()
-    elif exchange:
-        parserv.allreduce_(net._flat.der)
+        net.eval(inputs, opts.derOutputs, input_events=input_events)
+    if exchange:
+        # MatConvNet [EXT]: dagnn.BatchNorm returns moments * (worker batch size), accumulateGradients divides the
+        # workers' sum by the global batch size -- ragged shards are weighted by their sample counts
+        for (method, _, _), a, b in net._flat.segments:
+            if method == "average" and b > a:
+                vl.scale_(net._flat.der[a:b], float(local_batch))
+        if buckets is not None:
+            buckets.finish(parserv)
+        else:
+            parserv.allreduce_(net._flat.der)
+    net.gradHook = None
     lr = float(opts.learningRate[min(epoch, len(opts.learningRate) - 1)])
-    accumulate_gradients(net, opts, lr, global_batch or opts.batchSize, world)
+    accumulate_gradients(net, opts, lr, global_batch, float(global_batch) if exchange else 1.0)
 
 
 def extractStats(stats, net):
@@ -208,9 +310,74 @@ def _reset_losses(net):
             l.block.reset()
 
 
+class _RunAhead:
+    """bounded host run-ahead (two minibatches): a full HIP queue stalls launches for milliseconds"""
+
+    def __init__(self, device):
+        self.on = device is not None and device.type == "cuda"
+        self.inflight = []
+
+    def tick(self):
+        if not self.on:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append(ev)
+        if len(self.inflight) > 2:
+            self.inflight.pop(0).synchronize()
+
+
+def merge_loss_stats(net, parserv):
+    """validation / training statistics are per-worker running sums (dagnn.Loss.average, ErrorStats counters):
+    sum them over the workers before extractStats reads them, so that rank 0 reports -- and checkpoints -- the
+    statistics of the whole subset, not of its own shard."""
+    from . import dagnn
+    if parserv is None or not parserv.active:
+        return
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    dev = net.device if net.device is not None else torch.device("cpu")
+    blocks = [l.block for l in net.layers if isinstance(l.block, dagnn.LossBase)]
+    vals = []
+    for b in blocks:
+        if isinstance(b, dagnn.ErrorStats):
+            C_ = b.numClasses
+            vals.append(b._correct.reshape(-1).to(torch.float64) if b._correct is not None
+                        else torch.zeros(C_, dtype=torch.float64, device=dev))
+            vals.append(b._population.reshape(-1).to(torch.float64) if b._population is not None
+                        else torch.zeros(C_, dtype=torch.float64, device=dev))
+        else:
+            b._fold()
+            vals.append((b._sum.reshape(1).to(torch.float64) if b._sum is not None
+                         else torch.zeros(1, dtype=torch.float64, device=dev)))
+        vals.append(torch.tensor([float(b.numAveraged)], dtype=torch.float64, device=dev))
+    if not vals:
+        return
+    t = torch.cat([v.to(dev) for v in vals])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    pos = 0
+    for b in blocks:
+        if isinstance(b, dagnn.ErrorStats):
+            C_ = b.numClasses
+            if b._correct is None:
+                b._correct = vl.mat_zeros(C_, 1, device=dev) if dev.type == "cuda" else torch.zeros(C_, 1).t().contiguous().t()
+                b._population = b._correct.clone()
+            b._correct.reshape(-1).copy_(t[pos:pos + C_].to(torch.float32))
+            b._population.reshape(-1).copy_(t[pos + C_:pos + 2 * C_].to(torch.float32))
+            pos += 2 * C_
+        else:
+            b._sum = t[pos].to(torch.float32).reshape(())
+            pos += 1
+        b.numAveraged = int(round(float(t[pos].item())))
+        pos += 1
+
+
 def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, extractStatsFn=extractStats):
     """processEpoch of cnn_train_dag [EXT]: one pass over `subset` in minibatches of opts.batchSize;
-    each worker evaluates the interleaved shard batch(labindex:numlabs:end)."""
+    each worker evaluates the interleaved shard batch(labindex:numlabs:end).  A ragged tail batch with fewer
+    samples than workers leaves some shards empty: those workers still enter train_step (zero contribution) so
+    that every collective is matched."""
     import time
     world = parserv.world if parserv is not None else 1
     rank = parserv.rank if parserv is not None else 0
@@ -218,29 +385,63 @@ def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, 
     subset = list(subset)
     t0 = time.perf_counter()
     num = 0
-    inflight = []
+    ahead = _RunAhead(net.device)
     for t in range(0, len(subset), opts.batchSize):
         batch = subset[t:t + opts.batchSize]
         shard = shard_batch(batch, rank, world)
-        if not shard:
-            continue
-        inputs = getBatch(imdb, shard)
         if mode == "train":
-            train_step(net, inputs, opts, epoch, parserv, len(batch))
-        else:
+            inputs = getBatch(imdb, shard) if shard else None
+            train_step(net, inputs, opts, epoch, parserv, len(batch), local_batch=len(shard))
+        elif shard:
             net.mode = "test"
-            net.eval(inputs)
+            net.eval(getBatch(imdb, shard))
         num += len(batch)
-        # bounded run-ahead (two minibatches): a full HIP queue stalls launches for milliseconds
-        ev = torch.cuda.Event()
-        ev.record()
-        inflight.append(ev)
-        if len(inflight) > 2:
-            inflight.pop(0).synchronize()
+        ahead.tick()
+    merge_loss_stats(net, parserv)
     stats = extractStatsFn({}, net)   # the only host synchronisation of the pass
     stats["num"] = num
     stats["time"] = time.perf_counter() - t0
     return stats
+
+
+def save_checkpoint(net, path, info, epoch):
+    """net-epoch-<n>.pt: {parameter name: value / momentum} (self-describing: loadable into any net that has
+    parameters of those names and shapes, e.g. emoVoxZoo(scratch=0) for inference), written to a temporary file and
+    renamed into place so that a crash cannot leave a truncated file that `cont` would pick up."""
+    import os
+    vals, moms = {}, {}
+    for name, p in net.params.items():
+        n = int(p.value.numel())
+        off = p._flat_off
+        vals[name] = net._flat.val[off:off + n].reshape(tuple(reversed(p.value.shape))).clone()
+        moms[name] = net._flat.mom[off:off + n].reshape(tuple(reversed(p.value.shape))).clone()
+    tmp = path + ".tmp"
+    torch.save({"format": "xmodal-params-v2", "params": vals, "momentum": moms, "info": info, "epoch": epoch}, tmp)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(net, path, strict=True):
+    """inverse of save_checkpoint (values stored in the flat buffers' memory order: reversed MATLAB shape)"""
+    ck = torch.load(path, map_location=net.device, weights_only=True)
+    if ck.get("format") != "xmodal-params-v2":
+        raise ValueError("%s: not an xmodal checkpoint" % path)
+    if net._flat is None:
+        net.pack_params()
+    for name, p in net.params.items():
+        if name not in ck["params"]:
+            if strict:
+                raise KeyError("checkpoint has no parameter %r" % name)
+            continue
+        n = int(p.value.numel())
+        off = p._flat_off
+        src = ck["params"][name]
+        if int(src.numel()) != n:
+            raise ValueError("parameter %r: %d values in the checkpoint, %d in the net" % (name, src.numel(), n))
+        net._flat.val[off:off + n].copy_(src.reshape(-1))
+        if name in ck.get("momentum", {}):
+            net._flat.mom[off:off + n].copy_(ck["momentum"][name].reshape(-1))
+    net.paramGeneration = getattr(net, "paramGeneration", 0) + 1
+    return ck
 
 
 def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpochs=300, train=None, val=None,
@@ -271,13 +472,17 @@ def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpoch
     if expDir and parserv.rank == 0:
         os.makedirs(expDir, exist_ok=True)
     if cont and expDir:
-        done = [e for e in range(1, numEpochs + 1) if os.path.exists(path(e))]
-        if done:
-            start = max(done)
-            ck = torch.load(path(start), map_location=net.device, weights_only=False)
-            net._flat.val.copy_(ck["val"])
-            net._flat.mom.copy_(ck["mom"])
+        done = sorted(e for e in range(1, numEpochs + 1) if os.path.exists(path(e)))
+        while done:                      # newest readable checkpoint wins; unreadable ones are skipped
+            try:
+                ck = load_checkpoint(net, path(done[-1]))
+            except Exception as e:       # noqa: BLE001 -- a damaged file must not stop `cont`
+                print("cnn_train_dag: skipping unreadable checkpoint %s (%s)" % (path(done[-1]), e), flush=True)
+                done.pop()
+                continue
+            start = done[-1]
             info = ck["info"]
+            break
     for epoch in range(start, numEpochs):
         rng = np.random.default_rng(epoch + 1 + randomSeed)       # rng(epoch + opts.randomSeed)
         order = [train[i] for i in rng.permutation(len(train))]
@@ -288,6 +493,6 @@ def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpoch
         if verbose and parserv.rank == 0:
             print("epoch %d: train %s | val %s" % (epoch + 1, info["train"][-1], info["val"][-1]), flush=True)
         if path and parserv.rank == 0:
-            torch.save({"val": net._flat.val, "mom": net._flat.mom, "info": info, "epoch": epoch + 1}, path(epoch + 1))
+            save_checkpoint(net, path(epoch + 1), info, epoch + 1)
     parserv.stop()
     return net, info

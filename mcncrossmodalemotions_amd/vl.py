@@ -493,8 +493,14 @@ def sgd_update(w, m, der, lr, momentum=0.9, weight_decay=5e-4, batch=1.0):
                                   float(momentum), float(weight_decay), float(batch), _stream()))
 
 
+def scale_(x, a):
+    """x <- a * x in place (worker-batch weighting of the BN moments before the ParameterServer exchange)."""
+    _lib.check(_L().xm_scale_f32(_ptr(x), x.numel(), float(a), _stream()))
+
+
 def average_update(w, der, lr, nworkers=1.0):
-    """in-place trainMethod 'average' update (BN moments)."""
+    """in-place trainMethod 'average' update (BN moments): w <- (1-lr) w + lr der / nworkers (denominator: 1 for a
+    single worker, the GLOBAL batch size when der = sum over workers of moments * worker batch size)."""
     _lib.check(_L().xm_average_update(_ptr(w), _ptr(der), w.numel(), float(lr), float(nworkers),
                                       _stream()))
 

@@ -69,40 +69,94 @@ int orc_conv_out_size(int in, int pad_a, int pad_b, int f, int dilate, int strid
 /* small blocked SGEMM pieces (no system BLAS in the image)            */
 /* ------------------------------------------------------------------ */
 
-/* C[m + ldc*n] (+)= sum_k A[m + lda*k] * B[k*bks + n*bns]   (fp32 chain over k) */
-static void gemm_nn(int M, int N, int K, const float *A, int lda, const float *B, size_t bks,
-                    size_t bns, float *C, int ldc, int accumulate) {
-  enum { MB = 16, NB = 4 };
-  int nmb = (M + MB - 1) / MB, nnb = (N + NB - 1) / NB;
-#pragma omp parallel for collapse(2) schedule(static)
-  for (int ib = 0; ib < nmb; ++ib)
-    for (int jb = 0; jb < nnb; ++jb) {
-      int m0 = ib * MB, n0 = jb * NB;
-      int mb = M - m0 < MB ? M - m0 : MB, nb = N - n0 < NB ? N - n0 : NB;
-      float acc[NB][MB];
-      for (int j = 0; j < NB; ++j)
-        for (int i = 0; i < MB; ++i)
-          acc[j][i] = (accumulate && j < nb && i < mb) ? C[m0 + i + (size_t)ldc * (n0 + j)] : 0.f;
-      if (mb == MB && nb == NB) {
-        for (int k = 0; k < K; ++k) {
-          const float *a = A + m0 + (size_t)lda * k;
-          for (int j = 0; j < NB; ++j) {
-            float bj = B[k * bks + (n0 + j) * bns];
-            for (int i = 0; i < MB; ++i) acc[j][i] += a[i] * bj;
-          }
-        }
-      } else {
-        for (int k = 0; k < K; ++k) {
-          const float *a = A + m0 + (size_t)lda * k;
-          for (int j = 0; j < nb; ++j) {
-            float bj = B[k * bks + (n0 + j) * bns];
-            for (int i = 0; i < mb; ++i) acc[j][i] += a[i] * bj;
-          }
-        }
-      }
-      for (int j = 0; j < nb; ++j)
-        for (int i = 0; i < mb; ++i) C[m0 + i + (size_t)ldc * (n0 + j)] = acc[j][i];
+/* Threads: conv forward / dgrad first build the im2row matrices of a CHUNK of images (as many as fit 1 GiB), then
+ * run one flat parallel loop over (image, row block, column block) SGEMM work items -- MatConvNet's CPU path loops
+ * over images and hands each SGEMM to a multithreaded BLAS; this is the same arithmetic (per output element an fp32
+ * chain over k in the same order) with the cores kept busy for small images too.  No nested teams. */
+/* grow-only scratch for the im2row matrices: a fresh 50+ MB malloc per call is an mmap + page-fault storm that
+ * costs more than the SGEMM it feeds (not thread-safe across concurrent oracle calls; the callers are serial) */
+static float *g_scratch = NULL;
+static size_t g_scratch_floats = 0;
+static float *scratch_get(size_t floats) {
+  if (floats > g_scratch_floats) {
+    free(g_scratch);
+    g_scratch = (float *)aligned_alloc(4096, (sizeof(float) * floats + 4095) & ~(size_t)4095);
+    g_scratch_floats = g_scratch ? floats : 0;
+  }
+  return g_scratch;
+}
+
+static size_t chunk_images(size_t per_image_floats, int N) {
+  size_t cap = ((size_t)1 << 28) / (per_image_floats ? per_image_floats : 1); /* 2^28 floats = 1 GiB */
+  if (cap < 1) cap = 1;
+  return cap > (size_t)N ? (size_t)N : cap;
+}
+
+/* micro-kernel: acc[j][0..31] += A[0..31 + lda*k] * B[k*bks + j*bns], k = 0..K-1 (fp32 chain over k per element,
+ * whatever the vector width: the clones differ in speed, not in rounding) */
+enum { GMB = 32, GNB = 4 };
+__attribute__((target_clones("avx512f", "default")))
+static void gemm_nn_block(int K, const float *A, int lda, const float *B, size_t bks, size_t bns,
+                          float acc[GNB][GMB]) {
+  float c0[GMB], c1[GMB], c2[GMB], c3[GMB];
+  for (int i = 0; i < GMB; ++i) {
+    c0[i] = acc[0][i];
+    c1[i] = acc[1][i];
+    c2[i] = acc[2][i];
+    c3[i] = acc[3][i];
+  }
+  for (int k = 0; k < K; ++k) {
+    const float *a = A + (size_t)lda * k;
+    const float b0 = B[k * bks], b1 = B[k * bks + bns], b2 = B[k * bks + 2 * bns], b3 = B[k * bks + 3 * bns];
+    for (int i = 0; i < GMB; ++i) {
+      float av = a[i];
+      c0[i] += av * b0;
+      c1[i] += av * b1;
+      c2[i] += av * b2;
+      c3[i] += av * b3;
     }
+  }
+  for (int i = 0; i < GMB; ++i) {
+    acc[0][i] = c0[i];
+    acc[1][i] = c1[i];
+    acc[2][i] = c2[i];
+    acc[3][i] = c3[i];
+  }
+}
+
+/* C_i[m + ldc*n] (+)= sum_k A_i[m + lda*k] * B[k*bks + n*bns]   (fp32 chain over k) for `cnt` independent problems
+ * that share B: A_i = A + i*strideA, C_i = C + i*strideC; one flat
+ * parallel loop over (problem, row block, column block) */
+static void gemm_nn_batched(int cnt, int M, int N, int K, const float *A, size_t strideA, int lda, const float *B,
+                            size_t bks, size_t bns, float *C, size_t strideC, int ldc, int accumulate) {
+  enum { MB = GMB, NB = GNB };
+  int nmb = (M + MB - 1) / MB, nnb = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int q = 0; q < cnt; ++q)
+    for (int ib = 0; ib < nmb; ++ib)
+      for (int jb = 0; jb < nnb; ++jb) {
+        const float *Aq = A + strideA * q;
+        float *Cq = C + strideC * q;
+        int m0 = ib * MB, n0 = jb * NB;
+        int mb = M - m0 < MB ? M - m0 : MB, nb = N - n0 < NB ? N - n0 : NB;
+        float acc[NB][MB];
+        for (int j = 0; j < NB; ++j)
+          for (int i = 0; i < MB; ++i)
+            acc[j][i] = (accumulate && j < nb && i < mb) ? Cq[m0 + i + (size_t)ldc * (n0 + j)] : 0.f;
+        if (mb == MB && nb == NB) {
+          gemm_nn_block(K, Aq + m0, lda, B + (size_t)n0 * bns, bks, bns, acc);
+        } else {
+          for (int k = 0; k < K; ++k) {
+            const float *a = Aq + m0 + (size_t)lda * k;
+            for (int j = 0; j < nb; ++j) {
+              float bj = B[k * bks + (n0 + j) * bns];
+              for (int i = 0; i < mb; ++i) acc[j][i] += a[i] * bj;
+            }
+          }
+        }
+        for (int j = 0; j < nb; ++j)
+          for (int i = 0; i < mb; ++i) Cq[m0 + i + (size_t)ldc * (n0 + j)] = acc[j][i];
+      }
 }
 
 /* C[r + ldc*n] += sum_p A[p + lda*r] * B[p + ldb*n]   (A^T B, reduction over contiguous p) */
@@ -161,25 +215,51 @@ static void im2row(const float *x, int H, int W, int FC, int FH, int FW, int sy,
   }
 }
 
-/* row2im: scatter-add dcol back into dx (one image / one group) */
-static void row2im_add(const float *col, int H, int W, int FC, int FH, int FW, int sy, int sx,
-                       int pt, int pl, int dy, int dx, int Ho, int Wo, float *xg) {
+/* im2row of images [0, cnt) of one filter group: col_i = col + i*P*R, x_i = x + i*xstride */
+static void im2row_batched(int cnt, const float *x, size_t xstride, int H, int W, int FC, int FH, int FW, int sy,
+                           int sx, int pt, int pl, int dy, int dx, int Ho, int Wo, float *col) {
   size_t P = (size_t)Ho * Wo;
-#pragma omp parallel for schedule(static)
-  for (int c = 0; c < FC; ++c)
-    for (int v = 0; v < FW; ++v)
-      for (int u = 0; u < FH; ++u) {
-        const float *src = col + P * (u + FH * (v + FW * c));
-        for (int wo = 0; wo < Wo; ++wo) {
-          int wi = wo * sx - pl + v * dx;
-          if (wi < 0 || wi >= W) continue;
-          for (int ho = 0; ho < Ho; ++ho) {
-            int hi = ho * sy - pt + u * dy;
-            if (hi < 0 || hi >= H) continue;
-            xg[XI(hi, wi, c, 0, H, W, FC)] += src[ho + (size_t)Ho * wo];
-          }
+  int R = FH * FW * FC;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int q = 0; q < cnt; ++q)
+    for (int r = 0; r < R; ++r) {
+      const float *xq = x + xstride * q;
+      int u = r % FH, v = (r / FH) % FW, c = r / (FH * FW);
+      float *dst = col + P * ((size_t)R * q + r);
+      for (int wo = 0; wo < Wo; ++wo) {
+        int wi = wo * sx - pl + v * dx;
+        for (int ho = 0; ho < Ho; ++ho) {
+          int hi = ho * sy - pt + u * dy;
+          float val = 0.f;
+          if (hi >= 0 && hi < H && wi >= 0 && wi < W) val = xq[XI(hi, wi, c, 0, H, W, FC)];
+          dst[ho + (size_t)Ho * wo] = val;
         }
       }
+    }
+}
+
+/* row2im of images [0, cnt): scatter-add each dcol_i back into dx_i (taps of one channel stay in one thread) */
+static void row2im_add_batched(int cnt, const float *col, int H, int W, int FC, int FH, int FW, int sy, int sx,
+                               int pt, int pl, int dy, int dx, int Ho, int Wo, float *xg, size_t xstride) {
+  size_t P = (size_t)Ho * Wo;
+  int R = FH * FW * FC;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int q = 0; q < cnt; ++q)
+    for (int c = 0; c < FC; ++c)
+      for (int v = 0; v < FW; ++v)
+        for (int u = 0; u < FH; ++u) {
+          const float *src = col + P * ((size_t)R * q + (u + FH * (v + FW * c)));
+          float *xq = xg + xstride * q;
+          for (int wo = 0; wo < Wo; ++wo) {
+            int wi = wo * sx - pl + v * dx;
+            if (wi < 0 || wi >= W) continue;
+            for (int ho = 0; ho < Ho; ++ho) {
+              int hi = ho * sy - pt + u * dy;
+              if (hi < 0 || hi >= H) continue;
+              xq[XI(hi, wi, c, 0, H, W, FC)] += src[ho + (size_t)Ho * wo];
+            }
+          }
+        }
 }
 
 /*
@@ -222,22 +302,28 @@ int orc_nnconv_forward(const float *x, int H, int W, int C, int N, const float *
       }
     return 0;
   }
-  float *col = (float *)malloc(sizeof(float) * P * R);
+  size_t chunk = chunk_images(P * R, N);
+  float *col = scratch_get(P * R * chunk);
   if (!col) return -2;
-  for (int n = 0; n < N; ++n)
+  const size_t xs = (size_t)H * W * C, ys = P * K;
+  for (int n0 = 0; n0 < N; n0 += (int)chunk) {
+    int cnt = N - n0 < (int)chunk ? N - n0 : (int)chunk;
     for (int g = 0; g < G; ++g) {
-      im2row(x + XI(0, 0, g * FC, n, H, W, C), H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
-             col);
-      float *yg = y + XI(0, 0, g * Kg, n, Ho, Wo, K);
+      im2row_batched(cnt, x + XI(0, 0, g * FC, n0, H, W, C), xs, H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
+                     col);
+      float *yg = y + XI(0, 0, g * Kg, n0, Ho, Wo, K);
       /* bias first (MatConvNet: rank-1 GEMM with a ones vector), then accumulate */
-      for (int k = 0; k < Kg; ++k) {
-        float bv = b ? b[g * Kg + k] : 0.f;
-        float *yk = yg + P * k;
-        for (size_t p = 0; p < P; ++p) yk[p] = bv;
-      }
-      gemm_nn((int)P, Kg, R, col, (int)P, f + (size_t)R * g * Kg, 1, (size_t)R, yg, (int)P, 1);
+#pragma omp parallel for collapse(2) schedule(static)
+      for (int q = 0; q < cnt; ++q)
+        for (int k = 0; k < Kg; ++k) {
+          float bv = b ? b[g * Kg + k] : 0.f;
+          float *yk = yg + ys * q + P * k;
+          for (size_t p = 0; p < P; ++p) yk[p] = bv;
+        }
+      gemm_nn_batched(cnt, (int)P, Kg, R, col, P * R, (int)P, f + (size_t)R * g * Kg, 1, (size_t)R, yg, ys, (int)P,
+                      1);
     }
-  free(col);
+  }
   return 0;
 }
 
@@ -333,26 +419,37 @@ int orc_nnconv_backward(const float *x, int H, int W, int C, int N, const float 
     }
     return 0;
   }
-  float *col = (float *)malloc(sizeof(float) * P * R);
-  if (!col) return -2;
-  if (dfo) memset(dfo, 0, sizeof(float) * (size_t)R * K);
-  if (dxo) memset(dxo, 0, sizeof(float) * (size_t)H * W * C * N);
-  for (int n = 0; n < N; ++n)
-    for (int g = 0; g < G; ++g) {
-      const float *dyg = dzdy + XI(0, 0, g * Kg, n, Ho, Wo, K);
-      if (dfo) {
-        im2row(x + XI(0, 0, g * FC, n, H, W, C), H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
-               col);
+  if (dfo) {
+    /* dzdf accumulates over the images in image order (as MatConvNet does): images stay sequential, the threads
+       work inside each im2row / SGEMM */
+    float *col = scratch_get(P * R);
+    if (!col) return -2;
+    memset(dfo, 0, sizeof(float) * (size_t)R * K);
+    for (int n = 0; n < N; ++n)
+      for (int g = 0; g < G; ++g) {
+        const float *dyg = dzdy + XI(0, 0, g * Kg, n, Ho, Wo, K);
+        im2row(x + XI(0, 0, g * FC, n, H, W, C), H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo, col);
         gemm_tn_acc(R, Kg, (int)P, col, (int)P, dyg, (int)P, dfo + (size_t)R * g * Kg, R);
       }
-      if (dxo) {
+  }
+  if (dxo) {
+    memset(dxo, 0, sizeof(float) * (size_t)H * W * C * N);
+    size_t chunk = chunk_images(P * R, N);
+    float *col = scratch_get(P * R * chunk);
+    if (!col) return -2;
+    const size_t xs = (size_t)H * W * C, ys = P * K;
+    for (int n0 = 0; n0 < N; n0 += (int)chunk) {
+      int cnt = N - n0 < (int)chunk ? N - n0 : (int)chunk;
+      for (int g = 0; g < G; ++g) {
+        const float *dyg = dzdy + XI(0, 0, g * Kg, n0, Ho, Wo, K);
         /* dcol[p, r] = sum_k dy[p, k] * f[r, k] */
-        gemm_nn((int)P, R, Kg, dyg, (int)P, f + (size_t)R * g * Kg, (size_t)R, 1, col, (int)P, 0);
-        row2im_add(col, H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
-                   dxo + XI(0, 0, g * FC, n, H, W, C));
+        gemm_nn_batched(cnt, (int)P, R, Kg, dyg, ys, (int)P, f + (size_t)R * g * Kg, (size_t)R, 1, col, P * R,
+                        (int)P, 0);
+        row2im_add_batched(cnt, col, H, W, FC, FH, FW, sy, sx, pt, pl, dy, dx, Ho, Wo,
+                           dxo + XI(0, 0, g * FC, n0, H, W, C), xs);
       }
     }
-  free(col);
+  }
   return 0;
 }
 

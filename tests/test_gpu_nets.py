@@ -331,25 +331,40 @@ def test_compute_visual_feats_splits_tracks(gpu):
 
 
 def test_bucketed_gradient_exchange(gpu):
-    """train.GradBuckets: the early bucket is exactly the fc6-8 filter range, the ranges tile the
-    flat buffer once, and a step with the overlapped exchange (single-rank RCCL group: the collective is an
-    identity) leaves bit-identical parameters to a step with one exchange at the end / no exchange."""
+    """train.GradBuckets: buckets are cut from the back of the filter segment at parameter boundaries
+    (student: [fc6f fc7f fc8f] on fc6 = 82 % of the bytes, then the conv filters), the ranges tile the flat buffer
+    exactly once, and a step with the overlapped exchange -- through torch.distributed AND through the library's own
+    communicator behind the C ABI (xm_parserv_push / xm_parserv_sync), single-rank groups: the collective is an
+    identity -- leaves bit-identical parameters to a step with one exchange at the end / no exchange."""
     import torch
     import torch.distributed as dist
     from mcncrossmodalemotions_amd import train, vl, zoo
     net = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
     net.pack_params()
-    bk = train.GradBuckets(net)
+    bk = train.GradBuckets(net, target_bytes=64 << 10)
     total = int(net._flat.der.numel())
     rs = sorted(bk.ranges())
     assert rs[0][0] == 0 and rs[-1][1] == total and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
-    f6, f8 = net.params["fc6f"], net.params["fc8f"]
-    assert bk.early == (f6._flat_off, f8._flat_off + (int(f8.value.numel()) + 3) // 4 * 4)
-    assert bk.trigger == "fc6"
-    full = zoo.emoVoxZoo(numSeconds=3, seed=1)       # full width: the early bucket carries 82 % of the bytes
+    full = zoo.emoVoxZoo(numSeconds=3, seed=1)       # full width: the first bucket carries 82 % of the bytes
     full.pack_params()
     bf = train.GradBuckets(full)
-    assert 0.80 < (bf.early[1] - bf.early[0]) / float(full._flat.der.numel()) < 0.84
+    f6, f8 = full.params["fc6f"], full.params["fc8f"]
+    a, b, trig = bf.buckets[0]
+    assert (a, b) == (f6._flat_off, f8._flat_off + (int(f8.value.numel()) + 3) // 4 * 4) and trig == "fc6"
+    assert 0.80 < (b - a) / float(full._flat.der.numel()) < 0.84
+    rs = sorted(bf.ranges())
+    assert rs[0][0] == 0 and rs[-1][1] == int(full._flat.der.numel()) and all(x[1] == y[0] for x, y in zip(rs, rs[1:]))
+    # config 5: the SE-ResNet-50 teacher's 104 MB go out in several buckets along the backward pass
+    tnet = zoo.ferPlusZoo("senet50-ferplus")
+    tnet.removeLayer("top1error")
+    tnet.pack_params()
+    bt = train.GradBuckets(tnet)
+    assert 3 <= len(bt.buckets) <= 6 and all(4 * (b - a) >= (8 << 20) for a, b, _ in bt.buckets[:-1])
+    order = {l.name: i for i, l in enumerate(tnet.layers)}
+    trig = [order[t] for _, _, t in bt.buckets]
+    assert trig == sorted(trig, reverse=True)            # pushed in the order the backward pass reaches them
+    rs = sorted(bt.ranges())
+    assert rs[0][0] == 0 and rs[-1][1] == int(tnet._flat.der.numel()) and all(x[1] == y[0] for x, y in zip(rs, rs[1:]))
     own_group = not dist.is_initialized()
     if own_group:
         dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:29571",
@@ -359,23 +374,35 @@ def test_bucketed_gradient_exchange(gpu):
         x = O.F(rng.standard_normal((512, 100, 1, 4)))
         lg = O.F(rng.standard_normal((1, 1, 8, 4)) * 3)
         res = []
-        for mode in ("none", "end", "overlap", "overlap+side"):
+        for mode in ("none", "end", "overlap", "overlap+side", "capi-end", "capi-overlap+side"):
             n = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
             n.pack_params()
-            if mode == "overlap+side":
+            if mode.endswith("+side"):
                 n.wgradStream = torch.cuda.Stream()
             ps = None
             if mode != "none":
-                ps = train.ParameterServer("torch")
-                ps.start()
+                ps = train.ParameterServer("rccl-capi" if mode.startswith("capi") else "torch")
                 ps.force = True
-                ps.overlap = mode.startswith("overlap")
+                ps.start()
+                ps.overlap = "overlap" in mode
+                assert ps.comm_count() == 1
             opts = train.TrainOpts(batchSize=4)
             xd, lgd = vl.from_numpy(x), vl.from_numpy(lg)
+            pushed = []
             for it in range(3):
                 train.train_step(n, ["data", xd, "logitTarget", lgd, "maxLabel", vl.max_label(lgd)], opts, it, ps, 4)
+                if ps is not None and ps.overlap and it == 0:
+                    n._grad_buckets.log = pushed
             torch.cuda.synchronize()
+            if pushed:   # two logged steps: every element pushed exactly once per step
+                pr = sorted(pushed)
+                half = pr[::2]
+                assert pr[::2] == pr[1::2]
+                assert half[0][0] == 0 and half[-1][1] == int(n._flat.der.numel())
+                assert all(u[1] == v[0] for u, v in zip(half, half[1:]))
             res.append(n._flat.val.clone())
+            if ps is not None:
+                ps.stop()
         for r in res[1:]:
             assert torch.equal(res[0], r)
     finally:
