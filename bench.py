@@ -478,6 +478,8 @@ def main():
             "settle_steps": settle, "windows": windows, "rccl_ranks": rccl_ranks,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+    if os.environ.get("XM_TUNE_SAVE") and rank == 0:
+        vl.tune_save()          # persist the tile choices measured in this run (tools/collect_profiles.sh)
     # tear the process group down BEFORE printing: RCCL writes its banner / teardown lines to stdout
     # and the contract line must be the last thing rank 0 prints
     if dist.is_initialized():
@@ -516,7 +518,7 @@ def cpu_baseline(wl, pairs, W):
     only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv would be faster still (this
     SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an upper bound."""
     from oracle import oracle as O, graphs as G
-    cores = O.num_threads()
+    cores = O.set_num_threads()          # one thread per physical core this process may use
     if pairs <= 0:
         pairs = max(16, cores // 4)
     t_total, gflop = 0.0, 0.0
@@ -558,7 +560,9 @@ def cpu_teacher_line(args):
     """BASELINE config 1 as its own line (teacher/benchmark_ferplus_models.m:46-54): resnet50-ferplus forward with
     the loss / classerror heads attached, test mode, batch 32, on the host cores only -- no GPU is touched.  The
     arithmetic is the oracle's fp32 path (MatConvNet's CPU algorithm shape); median of the timed passes."""
+    import torch  # noqa: F401  (first, as everywhere: its OpenMP runtime is then the one the oracle shares)
     from oracle import oracle as O
+    O.set_num_threads()
     nb = args.per_gpu_batch or 32
     K, Wm = max(1, args.steps or 3), max(1, args.warmup or 1)
     for _ in range(Wm):

@@ -48,9 +48,32 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2 };
 
 int xm_version(void);
 const char *xm_last_error(void);
+/* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
+ * MI355X host the MEX layer keeps tensors in buffers obtained here and hands MATLAB an opaque handle -- mex/xm_mex.h,
+ * mex/matlab/xmArray.m).  Plain hipMalloc / hipFree / hipMemcpy underneath; upload / download are synchronous with
+ * respect to the host and ordered after everything enqueued on the null stream. */
+int xm_device_alloc(void **ptr, size_t bytes);
+int xm_device_free(void *ptr);
+int xm_device_upload(void *dst_device, const void *src_host, size_t bytes);
+int xm_device_download(void *dst_host, const void *src_device, size_t bytes);
+int xm_device_synchronize(void);
+/* Tile-configuration table of vl_nnconv ("find mode": the first time a (direction, geometry) is seen every tile
+ * configuration is timed on the caller's stream and the winner kept).  The table persists in a text file next to the
+ * library (tune_gfx950.txt; $XM_TUNE_FILE overrides, XM_TUNE_FILE="" disables): loaded before the first lookup,
+ * written by xm_tune_save.  With the shipped table the tile choice -- hence the summation order and the bits of every
+ * result -- is the same in every process, and known shapes cost no timed launches on first use
+ * (external/compute_audio_feats.m:116-136 walks ten width buckets).  XM_AUTOTUNE=0 uses the analytic model instead. */
+int xm_tune_load(const char *path);   /* NULL / "" = the default file; returns the number of entries read */
+int xm_tune_save(const char *path);   /* merges with the file on disk, writes atomically */
+int xm_tune_entries(int *total, int *unsaved);
 /* optional: pre-size the internal scratch (split-K partials, filter transposes, tap tables). */
 int xm_workspace_reserve(size_t bytes);
 size_t xm_workspace_bytes(void);
+/* Scratch is one grow-only buffer per stream; growing it frees the old buffer.  A HIP graph captured earlier still
+ * holds the old address: reserve the largest need of a stream BEFORE capturing on it, and re-capture when the
+ * generation counter (incremented by every growth, any stream) has moved since the capture. */
+int xm_workspace_reserve_stream(size_t bytes, void *stream);
+unsigned long long xm_workspace_generation(void);
 /* output extent of conv / pool along one axis: floor((in + pa + pb - ((f-1)*d+1)) / s) + 1 */
 int xm_out_size(int in, int pad_a, int pad_b, int f, int dilate, int stride);
 

@@ -24,8 +24,18 @@ _i, _f, _sz, _vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p
 SIGNATURES = {
     "xm_version": [],
     "xm_last_error": [],
+    "xm_tune_load": [C.c_char_p],
+    "xm_tune_save": [C.c_char_p],
+    "xm_tune_entries": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "xm_workspace_reserve": [_sz],
     "xm_workspace_bytes": [],
+    "xm_workspace_reserve_stream": [_sz, _vp],
+    "xm_workspace_generation": [],
+    "xm_device_alloc": [C.POINTER(C.c_void_p), _sz],
+    "xm_device_free": [_vp],
+    "xm_device_upload": [_vp, _vp, _sz],
+    "xm_device_download": [_vp, _vp, _sz],
+    "xm_device_synchronize": [],
     "xm_out_size": [_i] * 6,
     "xm_nnconv_forward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 + [_vp],
     "xm_nnconv_forward_fused": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 +
@@ -76,7 +86,8 @@ SIGNATURES = {
     "xm_normalize_face": [c_fp, _i, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
     "xm_crop_resize_face": [c_fp, _i, _i, _i, _f, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
 }
-_RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t}
+_RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t,
+             "xm_workspace_generation": C.c_ulonglong}
 # test hooks (not part of include/xmodal.h)
 _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           "xm_debug_force_conv_splits": [_i],

@@ -26,6 +26,7 @@ struct WsBuf {
   size_t cap = 0;
 };
 static std::map<hipStream_t, WsBuf> g_ws;
+static unsigned long long g_ws_generation = 0;  // bumped whenever a scratch buffer moves (see xm_workspace_generation)
 
 int ws_get(size_t bytes, void **ptr, hipStream_t stream) {
   WsBuf &w = g_ws[stream];
@@ -34,6 +35,7 @@ int ws_get(size_t bytes, void **ptr, hipStream_t stream) {
     size_t want = bytes + bytes / 4 + (1u << 20);
     static const bool verbose = getenv("XM_WS_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "[xm ws] stream %p grow %zu -> %zu\n", (void *)stream, w.cap, want);
+    ++g_ws_generation;
     if (w.ptr) {
       hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) return fail(XM_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(e));
@@ -80,6 +82,45 @@ const char *xm_last_error(void) { return xm::err_buf(); }
 int xm_workspace_reserve(size_t bytes) {
   void *p;
   return xm::ws_get(bytes, &p, nullptr);
+}
+int xm_workspace_reserve_stream(size_t bytes, void *stream) {
+  void *p;
+  return xm::ws_get(bytes, &p, (hipStream_t)stream);
+}
+unsigned long long xm_workspace_generation(void) { return xm::g_ws_generation; }
+
+int xm_device_alloc(void **ptr, size_t bytes) {
+  if (!ptr) return xm::fail(XM_EINVAL, "device_alloc: NULL output");
+  *ptr = nullptr;
+  if (bytes == 0) return XM_OK;
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e != hipSuccess) return xm::fail(XM_ENOMEM, "hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+  return XM_OK;
+}
+int xm_device_free(void *ptr) {
+  if (!ptr) return XM_OK;
+  hipError_t e = hipFree(ptr);
+  if (e != hipSuccess) return xm::fail(XM_EHIP, "hipFree -> %s", hipGetErrorString(e));
+  return XM_OK;
+}
+int xm_device_upload(void *dst_device, const void *src_host, size_t bytes) {
+  if (bytes == 0) return XM_OK;
+  if (!dst_device || !src_host) return xm::fail(XM_EINVAL, "device_upload: NULL pointer");
+  hipError_t e = hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return xm::fail(XM_EHIP, "hipMemcpy(H2D, %zu) -> %s", bytes, hipGetErrorString(e));
+  return XM_OK;
+}
+int xm_device_download(void *dst_host, const void *src_device, size_t bytes) {
+  if (bytes == 0) return XM_OK;
+  if (!dst_host || !src_device) return xm::fail(XM_EINVAL, "device_download: NULL pointer");
+  hipError_t e = hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return xm::fail(XM_EHIP, "hipMemcpy(D2H, %zu) -> %s", bytes, hipGetErrorString(e));
+  return XM_OK;
+}
+int xm_device_synchronize(void) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return xm::fail(XM_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(e));
+  return XM_OK;
 }
 size_t xm_workspace_bytes(void) {
   size_t t = 0;

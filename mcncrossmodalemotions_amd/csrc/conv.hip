@@ -1,9 +1,12 @@
 // vl_nnconv forward / backward on gfx950 -- host-side planning + C ABI.
 // Replaces MatConvNet's vl_nnconv MEX (matlab/src/vl_nnconv.cu, bits/nnconv.cu: im2row + SGEMM
 // per image) behind the same operator contract; see include/xmodal.h and conv_kernels.h.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "conv_kernels.h"
@@ -353,6 +356,53 @@ struct TuneKey {
   bool operator<(const TuneKey &o) const { return memcmp(this, &o, sizeof(TuneKey)) < 0; }
 };
 static std::map<TuneKey, int> g_tuned;
+
+// ---- persistent tuning table ------------------------------------------------------------------
+// The measured choices are kept in a text file next to the library (tune_gfx950.txt, or $XM_TUNE_FILE) and
+// loaded before the first lookup: tile choices -- and therefore the summation order of every convolution --
+// are then the same in every process, and shapes already in the table pay no timed launches on the caller's
+// stream.  Shapes that are not in the table are still measured once per process (and written back by
+// xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
+constexpr int XM_TUNE_REV = 2;
+static bool g_tune_loaded = false;
+static int g_tune_new = 0;  // entries measured in this process (not yet saved)
+
+static std::string tune_default_path() {
+  if (const char *e = getenv("XM_TUNE_FILE")) return e;
+  Dl_info info;
+  if (dladdr((const void *)&tune_default_path, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.find_last_of('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/tune_gfx950.txt";
+  }
+  return "tune_gfx950.txt";
+}
+static int tune_load_file(const char *path) {
+  FILE *fp = fopen(path, "r");
+  if (!fp) return 0;
+  int ver = 0, rev = 0, ncfg = 0, n = 0;
+  if (fscanf(fp, "xmodal-tune %d rev=%d cfgs=%d\n", &ver, &rev, &ncfg) == 3 && ver == 1 && rev == XM_TUNE_REV &&
+      ncfg == kNumCfg) {
+    TuneKey k;
+    int cfg;
+    while (fscanf(fp, "%d %d %d %d %d %d %d %d %d %d\n", &k.kind, &k.M, &k.NP, &k.Rp, &k.mode, &k.a, &k.b, &k.c, &k.d,
+                  &cfg) == 10)
+      if (cfg >= 0 && cfg < kNumCfg && !g_tuned.count(k)) {
+        g_tuned[k] = cfg;
+        ++n;
+      }
+  }
+  fclose(fp);
+  return n;
+}
+static void tune_load_once() {
+  if (g_tune_loaded) return;
+  g_tune_loaded = true;
+  const char *e = getenv("XM_TUNE_FILE");
+  if (e && !e[0]) return;  // XM_TUNE_FILE="" : no persistent table
+  int n = tune_load_file(tune_default_path().c_str());
+  if (getenv("XM_TUNE_VERBOSE")) fprintf(stderr, "[xm tune] %d entries from %s\n", n, tune_default_path().c_str());
+}
 static int autotune_enabled() {
   static int on = -1;
   if (on < 0) {
@@ -365,6 +415,7 @@ template <class F>
 static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (!autotune_enabled()) return fallback;
+  tune_load_once();
   auto it = g_tuned.find(key);
   if (it != g_tuned.end()) return it->second;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -396,6 +447,7 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   g_tuned[key] = bi;
+  ++g_tune_new;
   if (verbose)
     fprintf(stderr, "  -> [xm tune] kind %d M %d NP %d Rp %d (%d %d %d %d %d): cfg%d %.3f ms\n", key.kind, key.M,
             key.NP, key.Rp, key.mode, key.a, key.b, key.c, key.d, bi, best);
@@ -916,6 +968,34 @@ int xm_debug_force_conv_cfg(int cfg) {
   return old;
 }
 int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
+
+// ---- persistent tuning table (include/xmodal.h) ----------------------------------------------
+int xm_tune_load(const char *path) {
+  g_tune_loaded = true;
+  return tune_load_file(path && path[0] ? path : tune_default_path().c_str());
+}
+int xm_tune_save(const char *path) {
+  tune_load_once();   // merge with what is on disk
+  std::string p = path && path[0] ? std::string(path) : tune_default_path();
+  std::string tmp = p + ".tmp";
+  FILE *fp = fopen(tmp.c_str(), "w");
+  if (!fp) return fail(XM_EINVAL, "xm_tune_save: cannot write %s", tmp.c_str());
+  fprintf(fp, "xmodal-tune 1 rev=%d cfgs=%d\n", XM_TUNE_REV, kNumCfg);
+  for (auto &kv : g_tuned) {
+    const TuneKey &k = kv.first;
+    fprintf(fp, "%d %d %d %d %d %d %d %d %d %d\n", k.kind, k.M, k.NP, k.Rp, k.mode, k.a, k.b, k.c, k.d, kv.second);
+  }
+  fclose(fp);
+  if (rename(tmp.c_str(), p.c_str()) != 0) return fail(XM_EINVAL, "xm_tune_save: rename to %s failed", p.c_str());
+  g_tune_new = 0;
+  return XM_OK;
+}
+int xm_tune_entries(int *total, int *unsaved) {
+  tune_load_once();
+  if (total) *total = (int)g_tuned.size();
+  if (unsaved) *unsaved = g_tune_new;
+  return XM_OK;
+}
 // on = 1: every block (< 4096) of every later conv_gemm launch records {first clock, last clock, HW_ID, XCC_ID};
 // out (4 * nblocks words) receives the records of the most recent launch (caller synchronises first).
 // Debugging / tools only.

@@ -66,8 +66,18 @@ class _GraphedEval:
     def __init__(self, dag, inp, out_name):
         self.dag, self.inp, self.out_name = dag, inp, out_name
         self.graphs = {}
+        self.ws_generation = None
 
     def run(self, x, p1, ind1):
+        from . import _lib
+        L = _lib.load()
+        # The library's scratch is ONE grow-only buffer per stream and every graph is captured on the same side
+        # stream: warming up a larger shape may move that buffer (the old one is freed), and a graph captured
+        # earlier would then write its split-K slabs / padded filters / bnorm partial sums to freed memory.  The
+        # generation counter moves with every growth: all graphs captured before it are dropped and re-captured.
+        gen = int(L.xm_workspace_generation())
+        if self.ws_generation is not None and gen != self.ws_generation:
+            self.graphs.clear()
         key = (tuple(int(v) for v in x.shape), p1)
         ent = self.graphs.get(key)
         if ent is None:
@@ -87,7 +97,12 @@ class _GraphedEval:
             with torch.cuda.graph(g, stream=side):
                 self.dag.eval([self.inp, static_in])
                 static_out = self.dag.vars[self.out_name].value
+            if int(L.xm_workspace_generation()) != gen:
+                # the warm-up of THIS shape grew the scratch: every older graph points at the freed buffer
+                for k in [k for k in self.graphs if k != key]:
+                    del self.graphs[k]
             ent = self.graphs[key] = (g, static_in, static_out)
+            self.ws_generation = int(L.xm_workspace_generation())
         g, static_in, static_out = ent
         static_in.copy_(x)
         g.replay()

@@ -116,6 +116,14 @@ def _L():
     return _lib.load()
 
 
+def tune_save(path=None):
+    """write the measured tile-configuration table next to the library (or to `path`); returns (total, new)"""
+    tot, new = C.c_int(0), C.c_int(0)
+    _lib.check(_L().xm_tune_entries(C.byref(tot), C.byref(new)))
+    _lib.check(_L().xm_tune_save(path.encode() if path else None))
+    return int(tot.value), int(new.value)
+
+
 def out_size(n, pa, pb, f, d, s):
     return _L().xm_out_size(n, pa, pb, f, d, s)
 

@@ -338,3 +338,30 @@ def normalize_face(rgb, avg3):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def physical_cores():
+    """cores this process may run on, SMT siblings counted once (an OpenMP team on both hyper-threads of a core
+    runs the SGEMM slower than one thread per core)"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    seen, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur and int(cur["processor"]) in allowed:
+                    seen.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                cur = {}
+                continue
+            k, v = line.split(":", 1)
+            cur[k.strip()] = v.strip()
+    except OSError:
+        return len(allowed)
+    return len(seen) or len(allowed)
+
+
+def set_num_threads(n=None):
+    lib().orc_set_num_threads(int(n or physical_cores()))
+    return num_threads()

@@ -46,6 +46,14 @@
 #define XI(h, w, c, n, H, W, C) \
   ((size_t)(h) + (size_t)(H) * ((size_t)(w) + (size_t)(W) * ((size_t)(c) + (size_t)(C) * (size_t)(n))))
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

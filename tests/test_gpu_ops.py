@@ -444,3 +444,46 @@ def test_sgd_and_batch_math(gpu):
     rgb = O.F(rng.integers(0, 256, (12, 10, 3, 2)))
     avg = [131.1, 103.9, 91.5]
     close(vl.to_numpy(vl.normalize_face(vl.from_numpy(rgb), avg)), O.normalize_face(rgb, avg), 1e-6, "face")
+
+
+def test_device_memory_entry_points(gpu):
+    """xm_device_alloc / upload / download / free: the device-array substitute a MATLAB host uses,
+    round trip + one operator on the raw buffers."""
+    import ctypes as C
+    from mcncrossmodalemotions_amd import _lib
+    L = _lib.load()
+    x = np.random.default_rng(0).standard_normal(1000).astype(np.float32)
+    px, py = C.c_void_p(), C.c_void_p()
+    _lib.check(L.xm_device_alloc(C.byref(px), x.nbytes))
+    _lib.check(L.xm_device_alloc(C.byref(py), x.nbytes))
+    _lib.check(L.xm_device_upload(px, x.ctypes.data_as(C.c_void_p), x.nbytes))
+    _lib.check(L.xm_nnrelu(px, x.size, 0.0, None, py, None))
+    _lib.check(L.xm_device_synchronize())
+    y = np.empty_like(x)
+    _lib.check(L.xm_device_download(y.ctypes.data_as(C.c_void_p), py, x.nbytes))
+    assert np.array_equal(y, np.maximum(x, 0))
+    _lib.check(L.xm_device_free(px))
+    _lib.check(L.xm_device_free(py))
+    assert L.xm_device_alloc(None, 16) != 0 and b"NULL" in L.xm_last_error()
+
+
+def test_tuning_table_persists(gpu, tmp_path):
+    """xm_tune_save / xm_tune_load: a shape measured in this process lands in the file; loading the file in a fresh
+    table reproduces the choice (the shipped tune_gfx950.txt makes tile choices identical across processes)."""
+    import ctypes as C
+    from mcncrossmodalemotions_amd import _lib, vl
+    L = _lib.load()
+    rng = np.random.default_rng(1)
+    x = vl.from_numpy(rng.standard_normal((19, 23, 8, 3)).astype(np.float32))      # a geometry no table contains
+    f = vl.from_numpy(rng.standard_normal((3, 3, 8, 24)).astype(np.float32))
+    y0 = vl.to_numpy(vl.vl_nnconv(x, f, None, pad=1))
+    path = str(tmp_path / "tune.txt").encode()
+    _lib.check(L.xm_tune_save(path))
+    tot, new = C.c_int(), C.c_int()
+    _lib.check(L.xm_tune_entries(C.byref(tot), C.byref(new)))
+    assert tot.value >= 1 and new.value == 0
+    lines = open(path.decode()).read().splitlines()
+    assert lines[0].startswith("xmodal-tune 1 rev=") and len(lines) - 1 == tot.value
+    assert any(l.split()[:3] == ["0", "24", str(19 * 23 * 3)] for l in lines[1:])
+    assert L.xm_tune_load(path) == 0          # everything in the file is already in the table
+    assert np.array_equal(vl.to_numpy(vl.vl_nnconv(x, f, None, pad=1)), y0)
