@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream, no overlap anywhere (what the roofline leg and the rocprof profile use: "
                          "kernel durations are then those of isolated kernels)")
+    ap.add_argument("--teacher-batch", type=int, default=0,
+                    help="distill: faces per frozen-teacher pass (a multiple of the per-GPU batch; 0 = the per-GPU "
+                         "batch).  The reference decouples the two as well: buildImdb runs the teacher at batch 128 "
+                         "(fetch_emovoxceleb_imdb.m:63), the student trains at 64 (run_distillation.m:75).  One pass "
+                         "feeds teacher-batch / per-gpu-batch consecutive steps; every pair still gets its own face")
     ap.add_argument("--teacher-prefetch", type=int, default=1,
                     help="1: the teacher stream works one batch ahead of the student (needs --overlap-teacher 1)")
     ap.add_argument("--overlap-teacher", type=int, default=1,
@@ -169,9 +174,14 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------
     faces = spec = lgo = lab = flab = None
+    tmult = 1
     if teacher is not None:
         F = args.frames if wl == "distill" else 1
-        faces = xbatch.getImageBatch(nb * F, seed=seed, device=dev)
+        if wl == "distill" and F == 1 and args.teacher_batch:
+            if args.teacher_batch % nb:
+                raise SystemExit("--teacher-batch must be a multiple of the per-GPU batch")
+            tmult = args.teacher_batch // nb
+        faces = xbatch.getImageBatch(nb * F * tmult, seed=seed, device=dev)
         calib = xbatch.getImageBatch(min(nb, 16), seed=999, device=dev)
         zoo.calibrate_moments(teacher, ["data", calib])  # realistic stored moments
         teacher.mode = "test" if wl != "joint" else "normal"
@@ -242,7 +252,7 @@ def main():
                              parserv, nb * world)
             return
         if wl == "distill" and (tstream is None or mode["serial"]):
-            teacher.eval(["data", faces])
+            teacher.eval(["data", faces if tmult == 1 else faces[..., :nb]])
             tl = teacher.vars["prediction"].value      # 1 x 1 x 8 x nb teacher logits
             ml = vl.max_label(tl)                       # getBatchEmoVoxCeleb.m:32
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
@@ -275,12 +285,23 @@ def main():
                 return tl_, ml_, ev_
 
             if args.teacher_prefetch:
-                if "next" not in prefetched:
-                    prefetched["next"] = launch_teacher()
-                tl, ml, ev = prefetched["next"]
-                prefetched["next"] = launch_teacher()
+                # queue of per-step logit slices; one teacher pass (tmult * nb faces) refills it when a single
+                # step of slack is left, i.e. the teacher never runs more than one pass ahead
+                q = prefetched.setdefault("q", [])
+
+                def refill():
+                    tl_, ml_, ev_ = launch_teacher()
+                    for k in range(tmult):
+                        q.append((tl_[..., k * nb:(k + 1) * nb], ml_[..., k * nb:(k + 1) * nb], ev_))
+                if not q:
+                    refill()
+                tl, ml, ev = q.pop(0)
+                if len(q) == 0:
+                    refill()
             else:
                 tl, ml, ev = launch_teacher()
+                if tmult > 1:
+                    tl, ml = tl[..., :nb], ml[..., :nb]
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world, input_events={"logitTarget": ev, "maxLabel": ev})
             return
@@ -467,6 +488,7 @@ def main():
                                     "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",
                                     "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
                        "per_gpu_batch": nb, "global_batch": units, "face": "224x224x3",
+                       "teacher_batch": nb * (tmult if wl == "distill" else 1),
                        "spectrogram": "512x%dx1" % W, "parallelism": "dp%d" % world,
                        "weights": "random-init (seeded)", "parameter_server": args.parserv,
                        "streams": "serial" if args.serial else

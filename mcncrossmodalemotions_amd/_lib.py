@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so and friends)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libxmodal_hip.so")
+SO_PATH = os.environ.get("XM_LIB_PATH") or os.path.join(_HERE, "libxmodal_hip.so")   # XM_LIB_PATH: A/B experiments
 
 c_fp = C.c_void_p  # device pointers travel as raw addresses
 _i, _f, _sz, _vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p

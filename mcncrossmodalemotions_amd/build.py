@@ -6,12 +6,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libxmodal_hip.so")
+# experiments: XM_BUILD_TAG=v1 XM_DEFINES="-DXM_VARIANT=1" python -m mcncrossmodalemotions_amd.build  builds
+# libxmodal_hip_v1.so next to the product library; XM_LIB_PATH=<that file> makes _lib.py load it (A/B runs in one
+# gpurun call).  The product build uses neither.
+TAG = os.environ.get("XM_BUILD_TAG", "")
+OUT = os.path.join(HERE, "libxmodal_hip%s.so" % ("_" + TAG if TAG else ""))
 SOURCES = ["context.cpp", "conv.hip", "norm_pool.hip", "misc.hip", "comm.cpp"]
 HEADERS = ["xm_common.h", "conv_kernels.h", os.path.join("..", "..", "include", "xmodal.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("XM_DEBUG_CYCLES"):   # per-block clock trace in the conv kernels (tools/conv_bench.py --cycles)
     FLAGS.append("-DXM_DEBUG_CYCLES")
+FLAGS += os.environ.get("XM_DEFINES", "").split()
 
 
 def _stale(target, deps):
@@ -23,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "_obj")
+    objdir = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []

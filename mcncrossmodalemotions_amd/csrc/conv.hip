@@ -169,8 +169,17 @@ static const Cfg kCfgs[] = {
     {1, 1, 2, 2},  //  64 x  64
     {1, 1, 4, 1},  // 128 x  32
     {1, 1, 1, 4},  //  32 x 128
+    // LDS-DMA variants (conv_gemm_dma_kernel): forward / dgrad GEMMs of 1x1 unit-stride layers only
+    {2, 2, 2, 2},  //  7: 128 x 128, 3 LDS stages
+    {2, 2, 1, 4},  //  8:  64 x 256, 3 stages
+    {1, 2, 2, 2},  //  9:  64 x 128, 4 stages
+    {1, 1, 2, 2},  // 10:  64 x  64, 4 stages
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kNumBaseCfg = 7;                       // configurations every direction / geometry can run
+static const int kDmaBase[] = {0, 1, 3, 4};          // the register-staged configuration of the same tile shape
+static inline bool is_dma_cfg(int ci) { return ci >= kNumBaseCfg; }
+static inline int base_cfg(int ci) { return is_dma_cfg(ci) ? kDmaBase[ci - kNumBaseCfg] : ci; }
 
 static int g_force_splits = 0;  // test hook
 
@@ -192,7 +201,7 @@ static int pick_splits(int tiles, int nkt) {
 static int pick_cfg(long long M, long long NP, int nkt) {
   double best = 1e300;
   int bi = 0;
-  for (int i = 0; i < kNumCfg; ++i) {
+  for (int i = 0; i < kNumBaseCfg; ++i) {
     const Cfg &c = kCfgs[i];
     long long tiles = ((M + c.bm() - 1) / c.bm()) * ((NP + c.bn() - 1) / c.bn());
     int s = pick_splits((int)std::min<long long>(tiles, 1 << 20), nkt);
@@ -209,6 +218,16 @@ static int pick_cfg(long long M, long long NP, int nkt) {
     }
   }
   return bi;
+}
+
+static void launch_gemm_dma(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  switch (ci) {
+    case 7: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 2, 2, 3>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 1, 4, 3>), grid, block, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 2, 2, 2, 4>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 1, 2, 2, 4>), grid, block, 0, st, a); break;
+  }
 }
 
 template <int MODE>
@@ -276,6 +295,7 @@ static size_t gemm_slab_floats(const ConvGemmArgs &a, int ci, int *splits_out) {
 }
 
 static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *slab, hipStream_t st) {
+  if (is_dma_cfg(ci) && !a.dmaOk) ci = base_cfg(ci);   // forced configuration on a geometry it cannot run
   const Cfg &c = kCfgs[ci];
   a.nbm = (a.M + c.bm() - 1) / c.bm();
   a.nbn = (a.NP + c.bn() - 1) / c.bn();
@@ -288,7 +308,14 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   dim3 grid(a.nbm * a.nbn, splits);
   {
     ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st);
-    if (mode)
+    if (is_dma_cfg(ci)) {
+      // persistent: one round of co-resident blocks (a multiple of 8 so that every XCD gets the same share)
+      static const int per_cu_tab[] = {3, 2, 4, 4};          // co-resident blocks per CU (LDS-limited)
+      const int slots = std::max(8, 256 * per_cu_tab[ci - kNumBaseCfg] / std::max(1, splits));
+      const int ntl = a.nbm * a.nbn;
+      const int g = ntl <= slots ? ntl : slots - slots % 8;
+      launch_gemm_dma(ci, a, dim3(std::max(1, g), splits), st);
+    } else if (mode)
       launch_gemm_cfg<1>(ci, a, grid, st);
     else
       launch_gemm_cfg<0>(ci, a, grid, st);
@@ -318,6 +345,7 @@ static void launch_gemm_multi_cfg(int ci, const ConvGemmMulti &m, dim3 grid, hip
 
 // up to 4 masked (MODE 1) implicit GEMMs without split-K in one launch, same tile configuration
 static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipStream_t st) {
+  ci = base_cfg(ci);
   const Cfg &c = kCfgs[ci];
   ConvGemmMulti m{};
   int maxTiles = 0;
@@ -363,7 +391,7 @@ static std::map<TuneKey, int> g_tuned;
 // are then the same in every process, and shapes already in the table pay no timed launches on the caller's
 // stream.  Shapes that are not in the table are still measured once per process (and written back by
 // xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
-constexpr int XM_TUNE_REV = 2;
+constexpr int XM_TUNE_REV = 3;
 static bool g_tune_loaded = false;
 static int g_tune_new = 0;  // entries measured in this process (not yet saved)
 
@@ -412,8 +440,8 @@ static int autotune_enabled() {
   return on;
 }
 template <class F>
-static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch) {
-  if (g_force_cfg >= 0) return g_force_cfg;
+static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch, int ncfg = kNumBaseCfg) {
+  if (g_force_cfg >= 0) return g_force_cfg < ncfg ? g_force_cfg : base_cfg(g_force_cfg);
   if (!autotune_enabled()) return fallback;
   tune_load_once();
   auto it = g_tuned.find(key);
@@ -425,7 +453,7 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   static const bool verbose = getenv("XM_TUNE_VERBOSE") != nullptr;
   float best = 1e30f;
   int bi = fallback;
-  for (int ci = 0; ci < kNumCfg; ++ci) {
+  for (int ci = 0; ci < ncfg; ++ci) {
     float tmin = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {
       (void)hipEventRecord(e0, st);
@@ -566,6 +594,11 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     int sp;
     slabf = std::max(slabf, gemm_slab_floats(proto, c, &sp));
   }
+  // LDS-DMA eligibility: a plain GEMM in memory (1x1, unit stride, no padding), pixel quads inside one sample,
+  // 16-byte aligned operands
+  const bool dma_ok = !need_pad && mode == 0 && g.FH == 1 && g.FW == 1 && g.sy == 1 && g.sx == 1 && g.dy == 1 &&
+                      g.dx == 1 && (g.H * g.W) % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)f & 15) == 0 &&
+                      g.R % kBK == 0 && getenv("XM_NO_DMA") == nullptr;
   WsCarver ws;
   int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4), st);
   if (rc) return rc;
@@ -631,6 +664,9 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     // 4 consecutive output pixels are contiguous (same sample) and every tile starts on a multiple
     // of 32 pixels; 16-byte alignment of (y, residual) rows needs Ho*Wo % 4 == 0
     a.vecStore = ((g.Ho * g.Wo) % 4 == 0 && (((uintptr_t)a.Y | (uintptr_t)a.resid) & 15) == 0) ? 1 : 0;
+    a.dmaOk = dma_ok ? 1 : 0;
+    a.aBytes = (unsigned)((size_t)g.Kg * lda * 4);
+    a.tapStride = (unsigned)((size_t)g.H * g.W * 4);
     auto run = [&](int ci) {
       int sp;
       gemm_slab_floats(a, ci, &sp);
@@ -638,7 +674,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       return launch_gemm(aa, mode, ci, sp, slab, st);
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run);
+    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, dma_ok ? kNumCfg : kNumBaseCfg);
     rc = run(ci);
     if (rc) return rc;
   }
@@ -719,7 +755,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     proto.M = foldH ? g.FC * g.FH : g.FC;
     proto.NP = (foldH ? 1 : c.PI) * c.PJ * g.N;
     proto.Rp = c.Rp;
-    for (int ci = 0; ci < kNumCfg; ++ci) {
+    for (int ci = 0; ci < kNumBaseCfg; ++ci) {
       int sp;
       slab_max = std::max(slab_max, gemm_slab_floats(proto, ci, &sp));
     }
@@ -861,6 +897,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
 // one wgrad launch (+ split reduction) with tile configuration ci; `part` has room for 1024 slabs
 static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g, int ci, float *part,
                      hipStream_t st) {
+  ci = base_cfg(ci);
   const Cfg &c = kCfgs[ci];
   const int NP = g.Ho * g.Wo * g.N;
   const int nkt = (NP + kBK - 1) / kBK;
@@ -931,7 +968,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   int fb = 0;
   {
     double best = 1e300;
-    for (int i = 0; i < kNumCfg; ++i) {
+    for (int i = 0; i < kNumBaseCfg; ++i) {
       const Cfg &cc = kCfgs[i];
       double eff = (cc.tm * cc.tn >= 4) ? 1.0 : (cc.tm * cc.tn >= 2 ? 1.12 : 1.3);
       double cost = (double)((g.Kg + cc.bm() - 1) / cc.bm() * cc.bm()) *
@@ -1072,7 +1109,9 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;
   if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
   const Cfg &c = kCfgs[ci];
-  if (kind == 0)
+  if (kind == 0 && is_dma_cfg(ci))
+    snprintf(buf, len, "conv_gemm_dma_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, ci >= 9 ? 4 : 3);
+  else if (kind == 0)
     snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, key % 2);
   else if (kind == 2)
     snprintf(buf, len, "conv_gemm_multi_kernel<%d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn);

@@ -43,6 +43,9 @@ struct ConvGemmArgs {
   const float *bias, *scale, *shift, *resid;
   int relu;
   unsigned xBytes;    // size of the gather source in bytes (buffer bounds check)
+  unsigned aBytes;    // size of A in bytes (LDS-DMA variant: A is read through a buffer descriptor too)
+  unsigned tapStride; // LDS-DMA variant: byte distance between consecutive taps (1x1: H*W*4)
+  int dmaOk;          // 1: this launch may use conv_gemm_dma_kernel
   int lda, M, Rp, Rtrue;
   int PI, PJ, NP, NPs;  // pixel grid (i fastest), total pixel count PI*PJ*N, slab row pitch
   FastDiv divPIJ, divPI;
@@ -159,6 +162,155 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
     __builtin_amdgcn_sched_group_barrier(XM_SGB_VALU, NVALU, 0);              \
     __builtin_amdgcn_sched_group_barrier(XM_SGB_VMEM_RD, 1, 0);                \
   }
+
+// Epilogue shared by the implicit-GEMM kernels: split-K slab store, or y = act((acc + bias) * scale + shift +
+// residual) with scalar-cache row constants and 16-byte stores through an in-quad transpose.
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16 (&acc)[TM][TN], int bm, int bn,
+                                                   int split, int wm, int wn, int half, int l31) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+#if defined(XM_VARIANT) && XM_VARIANT == 2
+  {  // experiment: no stores (keeps the accumulators alive through an impossible condition)
+    float s_ = 0.f;
+    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j)
+        for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+    if (s_ == 123456.789f) a.Y[0] = s_;
+    return;
+  }
+#endif
+  // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (a.slab) {
+    // split-K: raw partial sums, [split][m][p] with p contiguous
+    float *out = a.slab + (size_t)split * a.M * a.NPs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int p = bn * BN + (wn * TN + j) * 32 + l31;
+      if (p >= a.NP) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < a.M) out[(size_t)m * a.NPs + p] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  // ---- epilogue: y = act((acc + bias) * scale + shift + residual) ----
+  // Per-row constants are wave-uniform up to lane>>5 (rows r and r+4 of an MFMA tile), so they are
+  // fetched through the scalar cache (two candidates per output, selected by the lane half) instead
+  // of three vector loads per output element.
+  const int wbase = __builtin_amdgcn_readfirstlane(bm * BM + wm * TM * 32);
+  int obase[TN];
+  bool pok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int p = bn * BN + (wn * TN + j) * 32 + l31;
+    pok[j] = p < a.NP;
+    uint32_t pc = pok[j] ? p : a.NP - 1;
+    uint32_t n = xm_div(pc, a.divPIJ);
+    uint32_t q = pc - n * a.divPIJ.d;
+    uint32_t jj = xm_div(q, a.divPI);
+    uint32_t ii = q - jj * a.divPI.d;
+    obase[j] = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride;
+  }
+  if (a.vecStore) {
+    // Wide path (dword stores are issue-bound at ~2.5 TB/s on this chip): each group of 4
+    // accumulator registers holds 4 consecutive channel rows of one pixel; a 4x4 transpose inside
+    // the lane quad turns that into 4 consecutive pixels of one row -> one 16-byte store per lane.
+    const int iq = l31 & 3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rb_lo = wbase + i * 32 + 8 * g4;  // wave-uniform; this lane half adds 4
+        float mul[4], add[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c_lo = min(rb_lo + k, a.M - 1), c_hi = min(rb_lo + k + 4, a.M - 1);
+          mul[k] = 1.f;
+          add[k] = 0.f;
+          if (a.scale) {
+            float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
+            float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
+            mul[k] = half ? s_hi : s_lo;
+            add[k] = half ? t_hi : t_lo;
+          }
+          if (a.bias) {
+            float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
+            add[k] += (half ? b_hi : b_lo) * mul[k];
+          }
+        }
+        const int row = rb_lo + 4 * half + iq;  // the row this lane stores after the transpose
+        const int rowc = min(row, a.M - 1);
+        uint32_t mc = xm_div((uint32_t)rowc, a.divMU);
+        const int moff = (int)mc * a.oChanStride + (rowc - (int)mc * (int)a.divMU.d) * a.oUStride;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k] * mul[k] + add[k];
+          quad_transpose4(v, iq);
+          if (row < a.M && pok[j]) {
+            const int off = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (a.resid) {
+              // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
+              // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
+              const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.resid + off);
+              o += rv;
+            }
+            if (a.relu) {
+              o.x = fmaxf(o.x, 0.f);
+              o.y = fmaxf(o.y, 0.f);
+              o.z = fmaxf(o.z, 0.f);
+              o.w = fmaxf(o.w, 0.f);
+            }
+#if defined(XM_VARIANT) && XM_VARIANT == 3
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(a.Y + off));
+#else
+            *reinterpret_cast<f32x4 *>(a.Y + off) = o;
+#endif
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_lo = wbase + i * 32 + (r & 3) + 8 * (r >> 2);  // wave-uniform
+      const int m = row_lo + 4 * half;
+      const int c_lo = min(row_lo, a.M - 1), c_hi = min(row_lo + 4, a.M - 1);
+      float mul = 1.f, add = 0.f;
+      if (a.scale) {
+        float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
+        float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
+        mul = half ? s_hi : s_lo;
+        add = half ? t_hi : t_lo;
+      }
+      if (a.bias) {
+        float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
+        add += (half ? b_hi : b_lo) * mul;  // (acc + b) * s + t == acc * s + (b * s + t)
+      }
+      uint32_t mc = xm_div((uint32_t)min(m, a.M - 1), a.divMU);
+      const int moff = (int)mc * a.oChanStride + (min(m, a.M - 1) - (int)mc * (int)a.divMU.d) * a.oUStride;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (m < a.M && pok[j]) {
+          int off = obase[j] + moff;
+          float v = acc[i][j][r] * mul + add;
+          if (a.resid) v += a.resid[off];
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.Y[off] = v;
+        }
+      }
+    }
+  }
+}
 
 // MODE 0: every tap is inside the image (pad == 0, Rp == R);  MODE 1: (u,v) validity mask.
 template <int TM, int TN, int WGM, int WGN, int MODE>
@@ -299,13 +451,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   //   read chunk 0 of CUR^1 -> (af0, bf0)      | MFMAs of chunk 1 from (af1, bf1)
   // LDS[CUR^1] was last read (its chunk 1) at the start of the previous stage, i.e. before the
   // previous mid-stage barrier, so overwriting it here is safe.
+#ifndef XM_VARIANT
+#define XM_VARIANT 0
+#endif
+#if XM_VARIANT == 1
+#define XM_FETCH_EARLY(KT)
+#define XM_FETCH_LATE(KT) XM_FETCH_TAPS(KT)
+#else
+#define XM_FETCH_EARLY(KT) XM_FETCH_TAPS(KT)
+#define XM_FETCH_LATE(KT)
+#endif
 #define XM_STAGE_LD(KT, CUR, LA, LB, SA, SB)                                   \
   XM_LOAD_TILE((KT) + 2, LA, LB)                                               \
-  XM_FETCH_TAPS((KT) + 3)                                                      \
+  XM_FETCH_EARLY((KT) + 3)                                                     \
   XM_READ_FRAGS(CUR, 1, af1, bf1)                                              \
   XM_MFMA_CHUNK(af0, bf0)                                                      \
   XM_INTERLEAVE(MODE == 1 ? 6 : 4)                                             \
   __builtin_amdgcn_sched_barrier(0);                                           \
+  XM_FETCH_LATE((KT) + 3)                                                      \
   XM_STORE_TILE((CUR) ^ 1, SA, SB)                                             \
   __syncthreads();                                                             \
   XM_READ_FRAGS((CUR) ^ 1, 0, af0, bf0)                                        \
@@ -368,6 +531,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
     }
   }
 #undef XM_FETCH_TAPS
+#undef XM_FETCH_EARLY
+#undef XM_FETCH_LATE
 #undef XM_LOAD_TILE
 #undef XM_STORE_TILE
 #undef XM_STAGE_LD
@@ -375,138 +540,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 #undef XM_STAGE_LAST
 
   if (TM * TN == 1) acc[0][0] += accx;
-  // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  if (a.slab) {
-    // split-K: raw partial sums, [split][m][p] with p contiguous
-    float *out = a.slab + (size_t)split * a.M * a.NPs;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int p = bn * BN + (wn * TN + j) * 32 + l31;
-      if (p >= a.NP) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m < a.M) out[(size_t)m * a.NPs + p] = acc[i][j][r];
-        }
-    }
-    return;
-  }
-  // ---- epilogue: y = act((acc + bias) * scale + shift + residual) ----
-  // Per-row constants are wave-uniform up to lane>>5 (rows r and r+4 of an MFMA tile), so they are
-  // fetched through the scalar cache (two candidates per output, selected by the lane half) instead
-  // of three vector loads per output element.
-  const int wbase = __builtin_amdgcn_readfirstlane(bm * BM + wm * TM * 32);
-  int obase[TN];
-  bool pok[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int p = bn * BN + (wn * TN + j) * 32 + l31;
-    pok[j] = p < a.NP;
-    uint32_t pc = pok[j] ? p : a.NP - 1;
-    uint32_t n = xm_div(pc, a.divPIJ);
-    uint32_t q = pc - n * a.divPIJ.d;
-    uint32_t jj = xm_div(q, a.divPI);
-    uint32_t ii = q - jj * a.divPI.d;
-    obase[j] = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride;
-  }
-  if (a.vecStore) {
-    // Wide path (dword stores are issue-bound at ~2.5 TB/s on this chip): each group of 4
-    // accumulator registers holds 4 consecutive channel rows of one pixel; a 4x4 transpose inside
-    // the lane quad turns that into 4 consecutive pixels of one row -> one 16-byte store per lane.
-    const int iq = l31 & 3;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int rb_lo = wbase + i * 32 + 8 * g4;  // wave-uniform; this lane half adds 4
-        float mul[4], add[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c_lo = min(rb_lo + k, a.M - 1), c_hi = min(rb_lo + k + 4, a.M - 1);
-          mul[k] = 1.f;
-          add[k] = 0.f;
-          if (a.scale) {
-            float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
-            float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
-            mul[k] = half ? s_hi : s_lo;
-            add[k] = half ? t_hi : t_lo;
-          }
-          if (a.bias) {
-            float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
-            add[k] += (half ? b_hi : b_lo) * mul[k];
-          }
-        }
-        const int row = rb_lo + 4 * half + iq;  // the row this lane stores after the transpose
-        const int rowc = min(row, a.M - 1);
-        uint32_t mc = xm_div((uint32_t)rowc, a.divMU);
-        const int moff = (int)mc * a.oChanStride + (rowc - (int)mc * (int)a.divMU.d) * a.oUStride;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k] * mul[k] + add[k];
-          quad_transpose4(v, iq);
-          if (row < a.M && pok[j]) {
-            const int off = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            if (a.resid) {
-              const float *rp = a.resid + off;
-              o.x += rp[0];
-              o.y += rp[1];
-              o.z += rp[2];
-              o.w += rp[3];
-            }
-            if (a.relu) {
-              o.x = fmaxf(o.x, 0.f);
-              o.y = fmaxf(o.y, 0.f);
-              o.z = fmaxf(o.z, 0.f);
-              o.w = fmaxf(o.w, 0.f);
-            }
-            float *yp = a.Y + off;
-            yp[0] = o.x;
-            yp[1] = o.y;
-            yp[2] = o.z;
-            yp[3] = o.w;
-          }
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row_lo = wbase + i * 32 + (r & 3) + 8 * (r >> 2);  // wave-uniform
-      const int m = row_lo + 4 * half;
-      const int c_lo = min(row_lo, a.M - 1), c_hi = min(row_lo + 4, a.M - 1);
-      float mul = 1.f, add = 0.f;
-      if (a.scale) {
-        float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
-        float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
-        mul = half ? s_hi : s_lo;
-        add = half ? t_hi : t_lo;
-      }
-      if (a.bias) {
-        float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
-        add += (half ? b_hi : b_lo) * mul;  // (acc + b) * s + t == acc * s + (b * s + t)
-      }
-      uint32_t mc = xm_div((uint32_t)min(m, a.M - 1), a.divMU);
-      const int moff = (int)mc * a.oChanStride + (min(m, a.M - 1) - (int)mc * (int)a.divMU.d) * a.oUStride;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (m < a.M && pok[j]) {
-          int off = obase[j] + moff;
-          float v = acc[i][j][r] * mul + add;
-          if (a.resid) v += a.resid[off];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.Y[off] = v;
-        }
-      }
-    }
-  }
+  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31);
 }
 
 template <int TM, int TN, int WGM, int WGN, int MODE>
@@ -529,6 +563,233 @@ conv_gemm_kernel(const ConvGemmArgs a) {
     }
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant for the layers that are plain GEMMs in memory: 1x1 convolutions with unit stride, no padding and
+// H*W % 4 == 0 (27 of the 36 1x1 layers of the ResNet-50 teachers; their dgrad as well).
+//   D[m][p] = sum_c A[m][c] * X[q(p) + HW * (c + C n(p))]
+// Both operands go global -> LDS with `buffer_load_dwordx4 ... lds` (CDNA4: 16 bytes per lane, no VGPR staging, no
+// ds_write, no per-element address arithmetic):
+//   A  [stage][g = k/4][row][k%4]   lane = row, 16 B = 4 consecutive k          (as conv_gemm_kernel)
+//   B  [stage][k][pixel]            lane = (k row, pixel quad), 16 B = 4 consecutive pixels of one channel
+// The MFMA B fragment is then four ds_read_b32 (one per k) instead of one ds_read_b128; everything else --
+// fragment / accumulator mapping, epilogue, split-K slabs -- is conv_gemm_kernel's.
+// Pipeline: NST LDS slots; per stage ONE barrier:
+//   s_waitcnt vmcnt(own loads of later stages) -> s_barrier -> issue the loads of stage kt+NST-1 into the slot the
+//   barrier has just freed -> MFMAs of stage kt.
+// The loads are inline asm: for the builtin form the compiler drains vmcnt(0) in front of every barrier (it cannot
+// tell the LDS slots apart), which would serialise the pipeline.
+struct DmaGeo {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  // raw buffer descriptor (what make_buffer_rsrc builds): base address, stride 0, size in bytes, DATA_FORMAT = 32 bit
+  static __device__ __forceinline__ i32x4 rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+  }
+  static __device__ __forceinline__ void load16(unsigned lds_byte, unsigned voff, const i32x4 &rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// PERSISTENT: the grid is one round of co-resident blocks (host: a.nbm * a.nbn tiles over gridDim.x blocks); a
+// block walks its tiles with the LDS ring running straight through the tile boundaries -- the loads of the next
+// tile are in flight while the current one is multiplied and stored, so a short reduction (K = 64 ... 512: 4 ... 32
+// stages) no longer pays a memory round trip per tile.  Tiles of one pixel column (same X tile, different filter
+// rows) go to neighbouring blocks of ONE XCD at the same time, so X is read from HBM once.
+template <int TM, int TN, int WGM, int WGN, int NST>
+__global__ void __launch_bounds__(256, (32 * TM * WGM) * (32 * TN * WGN) >= 128 * 128 ? 2 : 3)
+conv_gemm_dma_kernel(const ConvGemmArgs a) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  static_assert(BM == 64 || BM == 128, "A rows are loaded 64 at a time");
+  static_assert(BN == 64 || BN == 128 || BN == 256, "B rows are loaded 256 pixels per instruction");
+  constexpr int PLA = BM * 4 + 4;            // floats per k-group plane of A
+  constexpr int SA = kNG * PLA;              // floats per stage, A
+  constexpr int SB = kBK * BN;               // floats per stage, B (row pitch BN: DMA destinations are linear)
+  constexpr int NIA = kNG * (BM / 64);       // A load instructions per stage per block
+  constexpr int RPI = 256 / BN;              // k rows per B load instruction
+  constexpr int NIB = kBK / RPI;             // B load instructions per stage per block
+  constexpr int NWA = (NIA + 3) / 4, NWB = (NIB + 3) / 4;  // per wave
+  static_assert(NIA % 4 == 0 && NIB % 4 == 0, "every wave issues the same number of loads (vmcnt bookkeeping)");
+  __shared__ __attribute__((aligned(16))) float smem[NST * (SA + SB)];
+  float *sA = smem;
+  float *sB = smem + NST * SA;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave % WGM, wn = wave / WGM;
+  const int split = blockIdx.y;
+  const int kt0 = split * a.tilesPerSplit;
+  const int kt1 = min(a.nkt, kt0 + a.tilesPerSplit);
+  const int nst = kt1 - kt0;                 // stages per tile (this split)
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // ---- this block's tiles: XCD x = blockIdx % 8 owns a contiguous segment of the logical tile list (bm fastest);
+  // its blocks take the segment round-robin ----
+  const int ntl = a.nbm * a.nbn;
+  const int G = (int)gridDim.x;
+  int seg0, segn, bstep, bidx;
+  if (G >= 8 && G % 8 == 0) {
+    const int xcd = (int)blockIdx.x % 8, q = ntl / 8, r = ntl % 8;
+    seg0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    segn = q + (xcd < r ? 1 : 0);
+    bstep = G / 8;
+    bidx = (int)blockIdx.x / 8;
+  } else {
+    seg0 = 0, segn = ntl, bstep = G, bidx = (int)blockIdx.x;
+  }
+  const int mycnt = bidx < segn ? (segn - bidx + bstep - 1) / bstep : 0;
+  const int total = mycnt * nst;             // stages this block runs through
+
+  const DmaGeo::i32x4 arsrc = DmaGeo::rsrc(a.A, a.aBytes);
+  const DmaGeo::i32x4 xrsrc = DmaGeo::rsrc(a.X, a.xBytes);
+  const unsigned sAbase = (unsigned)(uintptr_t)sA, sBbase = (unsigned)(uintptr_t)sB;   // LDS byte addresses
+
+  // ---- issue side: per-lane global offsets of the tile whose stages are being requested ----
+  unsigned avoff[NWA], bvoff[NWB];
+  unsigned alds[NWA], blds[NWB];             // wave-uniform LDS byte offsets inside a stage
+#pragma unroll
+  for (int i = 0; i < NWA; ++i) {
+    const int id = wave + 4 * i;
+    alds[i] = (unsigned)(((id % kNG) * PLA + (id / kNG) * 64 * 4) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NWB; ++i) blds[i] = (unsigned)((wave + 4 * i) * RPI * BN * 4);
+  auto set_issue_tile = [&](int tile) {
+    const int bm = tile % a.nbm, bn = tile / a.nbm;
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+      const int id = wave + 4 * i;
+      const int row = min(bm * BM + (id / kNG) * 64 + lane, a.M - 1);   // rows >= M feed rows that are never stored
+      avoff[i] = ((unsigned)row * (unsigned)a.lda + 4u * (id % kNG)) * 4u;
+    }
+    const int qd = lane % (BN / 4), rr = lane / (BN / 4);
+    int p = bn * BN + 4 * qd;
+    p = p < a.NP ? p : a.NP - 4;                                        // NP % 4 == 0; clamped quads are never stored
+    const uint32_t n = xm_div((uint32_t)p, a.divPIJ);
+    const uint32_t q = (uint32_t)p - n * a.divPIJ.d;
+    const unsigned pix = (q + n * (unsigned)a.xSampleStride) * 4u;
+#pragma unroll
+    for (int i = 0; i < NWB; ++i) bvoff[i] = pix + (unsigned)((wave + 4 * i) * RPI + rr) * (unsigned)a.tapStride;
+  };
+  int ij = 0, ikt = kt0, islot = 0;          // next stage to request: tile sequence index, k stage, LDS slot
+  auto issue_next = [&]() {
+    const unsigned asoff = (unsigned)ikt * (kBK * 4u);                       // 16 k = 64 bytes along a filter row
+    const unsigned bsoff = (unsigned)ikt * (unsigned)kBK * (unsigned)a.tapStride;
+#pragma unroll
+    for (int i = 0; i < NWA; ++i)
+      DmaGeo::load16(__builtin_amdgcn_readfirstlane(sAbase + (unsigned)islot * (SA * 4u) + alds[i]), avoff[i], arsrc, asoff);
+#pragma unroll
+    for (int i = 0; i < NWB; ++i)
+      DmaGeo::load16(__builtin_amdgcn_readfirstlane(sBbase + (unsigned)islot * (SB * 4u) + blds[i]), bvoff[i], xrsrc, bsoff);
+    islot = islot + 1 == NST ? 0 : islot + 1;
+    if (++ikt == kt1) {
+      ikt = kt0;
+      if (++ij < mycnt) set_issue_tile(seg0 + bidx + ij * bstep);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
+  const float *sBr = sB + (4 * half) * BN + wn * TN * 32 + l31;
+
+  // fragments of 8-k chunk C (0 / 1) of LDS slot SLOT: A one ds_read_b128 per row tile, B four ds_read_b32 (k rows)
+#define XM_DREAD(SLOT, C, AF, BF)                                              \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                               \
+    AF[i] = *reinterpret_cast<const f32x4 *>(sAr + (SLOT) * SA + (2 * (C)) * PLA + i * 128); \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                              \
+      BF[j][e] = sBr[(SLOT) * SB + (8 * (C) + e) * BN + j * 32];
+#define XM_DMFMA(AF, BF)                                                       \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[i][e], BF[j][e], acc[i][j], 0, 0, 0);
+  // the fragment reads of the NEXT chunk are spread between the MFMAs of the current one
+#define XM_DSCHED                                                              \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, 1, 0);                  \
+  }                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 af0[TM], af1[TM];
+  float bf0[TN][4], bf1[TN][4];
+  if (total > 0) {
+    set_issue_tile(seg0 + bidx);
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+      if (s_ < total) issue_next();
+    // stage 0 landed?  (up to NST-2 later stages may stay in flight)
+    if (NST >= 4 && total >= 3) dma_wait<2 * (NWA + NWB)>();
+    else if (total >= 2) dma_wait<(NST >= 3 ? 1 : 0) * (NWA + NWB)>();
+    else dma_wait<0>();
+    __syncthreads();
+    int slot = 0, ckt = 0, ctile = seg0 + bidx;   // compute side: stage inside the tile, logical tile
+    XM_DREAD(slot, 0, af0, bf0)
+    for (int g = 0; g < total; ++g) {
+      // first half: MFMAs of chunk 0 | fragment reads of chunk 1
+      XM_DREAD(slot, 1, af1, bf1)
+      XM_DMFMA(af0, bf0)
+      XM_DSCHED
+      const int nslot = slot + 1 == NST ? 0 : slot + 1;
+      if (g + 1 < total) {
+        // stage g+1 must have landed; stages g+2 .. g+NST-2 (already requested) may stay in flight
+        const int later = min(total - 2 - g, NST - 3);
+        if (NST >= 4 && later >= 1) dma_wait<NWA + NWB>();
+        else dma_wait<0>();
+        __syncthreads();   // stage g+1 visible to all waves; every wave is done with stage g-1 (its slot is free)
+        if (g + NST - 1 < total) issue_next();
+        // second half: MFMAs of chunk 1 | fragment reads of chunk 0 of the next stage
+        XM_DREAD(nslot, 0, af0, bf0)
+      }
+      XM_DMFMA(af1, bf1)
+      XM_DSCHED
+      slot = nslot;
+      if (++ckt == nst) {
+        // tile complete: store it (the next tile's loads are already in flight) and start over
+        conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, ctile % a.nbm, ctile / a.nbm, split, wm, wn, half, l31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        ckt = 0;
+        ctile += bstep;
+      }
+    }
+  }
+#undef XM_DREAD
+#undef XM_DMFMA
+#undef XM_DSCHED
 }
 
 // Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity

@@ -487,3 +487,37 @@ def test_tuning_table_persists(gpu, tmp_path):
     assert any(l.split()[:3] == ["0", "24", str(19 * 23 * 3)] for l in lines[1:])
     assert L.xm_tune_load(path) == 0          # everything in the file is already in the table
     assert np.array_equal(vl.to_numpy(vl.vl_nnconv(x, f, None, pad=1)), y0)
+
+
+@pytest.mark.parametrize("geom", [(28, 28, 64, 48, 3), (14, 14, 160, 256, 5), (56, 8, 32, 200, 2), (4, 4, 1024, 96, 7)])
+def test_lds_dma_conv_configs(gpu, geom):
+    """conv_gemm_dma_kernel (both operands global -> LDS with buffer_load_dwordx4 ... lds): every DMA tile
+    configuration, forced, on 1x1 unit-stride layers with ragged M / pixel counts -- plain, fused epilogue
+    (bias + bnorm fold + residual + ReLU), and with a forced split-K -- against the oracle (fp64 accumulate)."""
+    from mcncrossmodalemotions_amd import _lib, vl
+    L = _lib.load()
+    H, W, C, K, N = geom
+    rng = np.random.default_rng(H * 1000 + C)
+    x = O.F(rng.standard_normal((H, W, C, N)))
+    f = O.F(rng.standard_normal((1, 1, C, K)) * 0.2)
+    b = O.F(rng.standard_normal(K))
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), O.F(rng.standard_normal(K))
+    y_ref = O.vl_nnconv(x, f, b, acc64=True)
+    res = O.F(rng.standard_normal(y_ref.shape))
+    yf_ref = np.maximum((y_ref * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1)) + res, 0)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(-1, 1))
+    scd, shd, rd = vl.from_numpy(sc.reshape(-1, 1)), vl.from_numpy(sh.reshape(-1, 1)), vl.from_numpy(res)
+    ncfg = L.xm_debug_num_conv_cfgs()
+    assert ncfg >= 11
+    try:
+        for cfg in range(7, ncfg):
+            for splits in (0, 3):
+                L.xm_debug_force_conv_cfg(cfg)
+                L.xm_debug_force_conv_splits(splits)
+                y = vl.to_numpy(vl.vl_nnconv(xd, fd, bd))
+                close(y, y_ref, 1e-5, "dma cfg %d splits %d" % (cfg, splits))
+                yf = vl.to_numpy(vl.vl_nnconv(xd, fd, bd, scale=scd, shift=shd, residual=rd, relu=True))
+                close(yf, yf_ref, 1e-5, "dma fused cfg %d splits %d" % (cfg, splits))
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+        L.xm_debug_force_conv_splits(0)
