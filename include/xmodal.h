@@ -96,6 +96,15 @@ int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *
                        int FC, int K, const float *dzdy, float *dx_out, float *df_out,
                        float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
                        int dx, void *stream);
+/* Extension: the DZDX GEMM reads the filter bank transposed (and split by stride parity); building that copy is
+ * ~20 us per layer on the critical path of the backward pass.  xm_nnconv_prepare_backward builds it ahead of time
+ * into a persistent buffer -- e.g. on a side stream while the forward pass of the same step runs -- and a later
+ * xm_nnconv_backward with the same F pointer and geometry uses it (waiting on the device for it if it was built on
+ * another stream).  Valid until the parameters change: xm_sgd_update / xm_average_update invalidate every prepared
+ * operand; a host that updates parameters by other means calls xm_params_changed(). */
+int xm_nnconv_prepare_backward(int H, int W, int C, int N, const float *f, int FH, int FW, int FC, int K,
+                               int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx, void *stream);
+int xm_params_changed(void);
 /* Extension: DX = dgrad + dx_accum.  dagnn sums the derivatives that reach a variable from several
  * consumers (a ResNet block input: shortcut + branch2a); the sum rides in the dgrad epilogue instead of a
  * separate pass.  dx_accum has the size of X, must not alias dx_out, NULL = plain backward. */

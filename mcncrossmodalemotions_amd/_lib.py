@@ -44,6 +44,8 @@ SIGNATURES = {
                           [_i] * 8 + [_vp],
     "xm_nnconv_backward_accum": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +
                                 [_i] * 8 + [c_fp, _vp],
+    "xm_nnconv_prepare_backward": [_i] * 4 + [c_fp] + [_i] * 12 + [_vp],
+    "xm_params_changed": [],
     "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
     "xm_nnpool_forward_argmax": [c_fp] + [_i] * 12 + [c_fp, c_fp, _vp],

@@ -137,7 +137,9 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
     last = np.zeros(N, np.int32)
     crops = []
     for k, ii in enumerate(batch):
-        total = int(imdb.num_samples[ii])
+        # getBatchEmoVoxCeleb.m:81-89: no clip of the dataset is longer than DATASET_LIMIT = 19.9 s; the sample count
+        # is thresholded accordingly (the cached teacher logits end there too)
+        total = min(int(imdb.num_samples[ii]), int(19.9 * imdb.fs))
         wr = int(rng.integers(0, max(total - int(audSamp), 0) + 1))  # random crop start (:109-119)
         crops.append((ii, wr))
         starttime = wr / imdb.fs

@@ -681,11 +681,41 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   return XM_OK;
 }
 
+// ---- prepared dgrad operands ------------------------------------------------------------------
+// The dgrad GEMM reads the filter bank transposed / split by stride parity (prep_dgrad_filter_kernel).  In a
+// training step that is ~20 us per layer ON THE CRITICAL PATH of the backward pass.  xm_nnconv_prepare_backward
+// lets the host run the transposition early -- typically while the forward pass of the same step runs, on a
+// side stream -- into a persistent buffer; the backward call then finds it and skips the kernel.  An entry is
+// valid while the parameter version it was built at is current (xm_sgd_update / xm_average_update /
+// xm_params_changed bump the version) and the geometry matches.
+struct PrepKey {
+  const float *f;
+  int FH, FW, FC, K, sy, sx, dy, dx, pt, pl, H, W, fold;
+  bool operator<(const PrepKey &o) const { return memcmp(this, &o, sizeof(PrepKey)) < 0; }
+};
+struct PrepEntry {
+  float *buf = nullptr;
+  size_t bytes = 0;
+  unsigned long long version = ~0ull;
+  hipEvent_t ev = nullptr;
+  hipStream_t st = nullptr;
+};
+static std::map<PrepKey, PrepEntry> g_prep;
+unsigned long long g_param_version = 1;   // bumped by every parameter update (misc.hip)
+static PrepKey prep_key(const float *f, const Geo &g, bool fold) {
+  PrepKey k;
+  memset(&k, 0, sizeof k);
+  k.f = f, k.FH = g.FH, k.FW = g.FW, k.FC = g.FC, k.K = g.K, k.sy = g.sy, k.sx = g.sx, k.dy = g.dy, k.dx = g.dx;
+  k.pt = g.pt, k.pl = g.pl, k.H = g.H, k.W = g.W, k.fold = fold ? 1 : 0;
+  return k;
+}
+
 // dX: one implicit GEMM per stride-parity class (a, b) of the input pixels.
 // accum != NULL: dX = dgrad + accum (the derivative another branch of a fork already produced), added in
 // the GEMM epilogue instead of by a separate pass
+// prepare_only: run just the filter transpositions into the persistent cache (xm_nnconv_prepare_backward)
 static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st,
-                      const float *accum = nullptr) {
+                      const float *accum = nullptr, bool prepare_only = false) {
   struct Cls {
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
@@ -739,7 +769,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       cls.push_back(c);
     }
   // pixels whose class has no tap (e.g. 1x1 stride 2) receive no gradient
-  if (!covers_all || cls.empty()) {
+  if (!prepare_only && (!covers_all || cls.empty())) {
     const size_t bytes = sizeof(float) * (size_t)g.H * g.W * g.C * g.N;
     if (accum)
       XM_HIP(hipMemcpyAsync(dxo, accum, bytes, hipMemcpyDeviceToDevice, st));
@@ -760,10 +790,35 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       slab_max = std::max(slab_max, gemm_slab_floats(proto, ci, &sp));
     }
   }
+  // transposed filters: from the persistent cache when a current entry exists (or is being built now), else scratch
+  const PrepKey pkey = prep_key(f, g, foldH);
+  PrepEntry *pe = nullptr;
+  bool have_prepared = false;
+  if (prepare_only) {
+    pe = &g_prep[pkey];
+    if (pe->bytes < abytes) {
+      if (pe->buf) {
+        XM_HIP(hipDeviceSynchronize());
+        (void)hipFree(pe->buf);
+      }
+      pe->buf = nullptr;
+      XM_HIP(hipMalloc((void **)&pe->buf, abytes));
+      pe->bytes = abytes;
+    }
+    if (!pe->ev) XM_HIP(hipEventCreateWithFlags(&pe->ev, hipEventDisableTiming));
+  } else {
+    auto it = g_prep.find(pkey);
+    if (it != g_prep.end() && it->second.version == g_param_version && it->second.bytes >= abytes) {
+      pe = &it->second;
+      have_prepared = true;
+      if (pe->st != st) XM_HIP(hipStreamWaitEvent(st, pe->ev, 0));
+    }
+  }
   WsCarver ws;
-  int rc = ws.init(abytes + WsCarver::need(slab_max, 4), st);
+  int rc = ws.init((pe ? 0 : abytes) + WsCarver::need(slab_max, 4), st);
   if (rc) return rc;
-  float *slab = slab_max ? (float *)(ws.base + abytes) : nullptr;
+  char *abase = pe ? (char *)pe->buf : ws.base;
+  float *slab = slab_max ? (float *)(ws.base + (pe ? 0 : abytes)) : nullptr;
   const size_t dyTotal = (size_t)g.Ho * g.Wo * g.K * g.N;
   double pair_total = 0;
   for (const Cls &c : cls) pair_total += (double)(foldH ? 1 : c.PI) * c.PJ * g.N * c.Rc;
@@ -799,10 +854,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     }
     const int2 *taps = (const int2 *)cached_device_table(t.data(), t.size() * sizeof(int2));
     if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
-    float *At = (float *)(ws.base + c.aoff);
+    float *At = (float *)(abase + c.aoff);
     for (int grp = 0; grp < g.G; ++grp) {
       float *Ag = At + (size_t)grp * g.FC * (foldH ? g.FH : 1) * c.Rp;
-      {
+      if (!have_prepared) {
         const int T = g.FH * g.FW;
         const int TS = T <= 14 ? 32 : (T <= 56 ? 16 : 8);
         size_t lds = sizeof(float) * (size_t)TS * (TS * T + 1);
@@ -811,6 +866,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
                            c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS, foldH ? 1 : 0);
         XM_LAUNCH_CHECK();
       }
+      if (prepare_only) continue;
       ConvGemmArgs a{};
       a.A = Ag;
       a.lda = c.Rp;
@@ -875,6 +931,12 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       rc = run(ci);
       if (rc) return rc;
     }
+  }
+  if (prepare_only) {
+    pe->version = g_param_version;
+    pe->st = st;
+    XM_HIP(hipEventRecord(pe->ev, st));
+    return XM_OK;
   }
   if (merge) {
     // all stride-parity classes in one launch (each alone is a fraction more than one round of the chip)
@@ -1139,6 +1201,20 @@ int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f
                       int pl, int pr, int dy, int dx, void *stream) {
   return xm_nnconv_forward_fused(x, H, W, C, N, f, FH, FW, FC, K, b, y, sy, sx, pt, pb, pl, pr, dy,
                                  dx, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int xm_nnconv_prepare_backward(int H, int W, int C, int N, const float *f, int FH, int FW, int FC, int K,
+                               int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!f) return fail(XM_EINVAL, "vl_nnconv: F is NULL");
+  return conv_dgrad(f, nullptr, nullptr, g, (hipStream_t)stream, nullptr, true);
+}
+
+int xm_params_changed(void) {
+  ++g_param_version;
+  return XM_OK;
 }
 
 int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -6,6 +6,10 @@
 #include "xm_common.h"
 
 namespace xm {
+extern unsigned long long g_param_version;   // conv.hip: prepared dgrad operands are valid for one version
+}
+
+namespace xm {
 
 static unsigned ew_grid(size_t work_items) {
   size_t b = (work_items + 255) / 256;
@@ -521,6 +525,7 @@ int xm_nnloss(const float *x, const float *labels, int C, int N, int loss, const
 
 int xm_sgd_update(float *w, float *m, const float *der, size_t n, float lr, float momentum,
                   float weight_decay, float batch, void *stream) {
+  ++xm::g_param_version;
   if (n == 0) return XM_OK;
   if (!w || !m || !der) return fail(XM_EINVAL, "sgd: NULL tensor");
   if (!(batch > 0.f)) return fail(XM_EINVAL, "sgd: batch must be > 0");
@@ -540,6 +545,7 @@ int xm_scale_f32(float *x, size_t n, float a, void *stream) {
 }
 
 int xm_average_update(float *w, const float *der, size_t n, float lr, float nworkers, void *stream) {
+  ++xm::g_param_version;
   if (n == 0) return XM_OK;
   if (!w || !der) return fail(XM_EINVAL, "average update: NULL tensor");
   hipLaunchKernelGGL(average_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,

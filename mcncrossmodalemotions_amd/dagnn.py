@@ -16,6 +16,7 @@ MI355X-specific additions (all optional, results identical):
     (grouped by learning-rate / weight-decay multipliers) so the optimiser is a handful of
     launches and the ParameterServer all-reduce is one RCCL call per bucket.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -452,6 +453,8 @@ class DagNN:
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
         self._side_pending = False
+        self._training = False
+        self.prepareBackward = os.environ.get("XM_NO_PREPARE") is None   # dgrad filter transposition during forward
         self.device = None
         self._flat = None
         # bumped whenever parameter VALUES change behind torch's back (raw-pointer HIP updates: xm_sgd_update /
@@ -644,6 +647,7 @@ class DagNN:
                 continue  # MatConvNet ignores unused inputs with a warning
             self.vars[k].value = t
         plan = self._plan(derOutputs is not None)
+        self._training = derOutputs is not None
         pending = dict(input_events or {})
         for step in plan:
             if pending:
@@ -748,6 +752,13 @@ class _Step:
     def forward(self, net):
         r = self.rec
         ins = [net.vars[v].value for v in r.inputs]
+        if net._training and net.wgradStream is not None and isinstance(r.block, Conv) and \
+                net.vars[r.inputs[0]].fanin > 0 and net.prepareBackward:
+            # the backward pass of this layer will need the transposed filters: build them now on the idle side
+            # stream instead of on the critical path of the backward pass (vl.conv_prepare_backward)
+            with torch.cuda.stream(net.wgradStream):
+                vl.conv_prepare_backward(ins[0], self._params(net)[0], stride=r.block.stride, pad=r.block.pad,
+                                         dilate=r.block.dilate)
         outs = r.block.forward(ins, self._params(net))
         for v, t in zip(r.outputs, outs):
             net.vars[v].value = t

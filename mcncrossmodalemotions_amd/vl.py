@@ -188,6 +188,18 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     return dxo, dfo, dbo
 
 
+def conv_prepare_backward(x, f, stride=1, pad=0, dilate=1):
+    """Extension: build the transposed filter operand of the DZDX GEMM now, on the current stream (see xmodal.h);
+    the backward call of the same layer finds it as long as the parameters have not been updated in between."""
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = _shape4(f)
+    sy, sx = _pair(stride, "STRIDE")
+    dy, dx = _pair(dilate, "DILATE")
+    pt, pb, pl, pr = _pad4(pad)
+    _lib.check(_L().xm_nnconv_prepare_backward(H, W, Cc, N, _ptr(f), FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx,
+                                               _stream()))
+
+
 # --------------------------------------------------------------------------------------------
 # vl_nnpool
 # --------------------------------------------------------------------------------------------
