@@ -451,11 +451,12 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
   static const bool verbose = getenv("XM_TUNE_VERBOSE") != nullptr;
+  static const int reps = getenv("XM_TUNE_REPS") ? std::max(1, atoi(getenv("XM_TUNE_REPS"))) : 2;
   float best = 1e30f;
   int bi = fallback;
   for (int ci = 0; ci < ncfg; ++ci) {
     float tmin = 1e30f;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < reps; ++rep) {
       (void)hipEventRecord(e0, st);
       if (launch(ci) != XM_OK) {
         tmin = 1e30f;

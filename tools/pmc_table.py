@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Merge rocprofv3 --pmc passes (separate directories) into one per-kernel table of per-launch
 averages + a JSON of HBM traffic per launch.
-usage: pmc_table.py <sq_dir> <fetch_dir> <write_dir> <out.txt> <out.json>
+usage: pmc_table.py <sq_dir> <fetch_dir> <write_dir> <out.txt> <out.json> [commit]
 FETCH_SIZE / WRITE_SIZE are KiB as reported by rocprofv3; per MI355X_MICROARCH.md ("HBM") the gfx950
 FETCH_SIZE under-reports wide coalesced reads by 2x, so the table carries fetch x 2 as well and the
 JSON traffic figure uses the doubled value (upper estimate for the dword gathers)."""
@@ -51,4 +51,6 @@ for k in names:
         us, gbs))
     traffic[k] = {"fetch_bytes_x2": 2 * f * 1e6, "write_bytes": w * 1e6, "launches": s["_n"]}
 open(sys.argv[4], "w").write("\n".join(out) + "\n")
+# the figures belong to the build they were measured on: bench.py reports this commit next to roofline.traffic
+traffic["_meta"] = {"commit": sys.argv[6] if len(sys.argv) > 6 else None}
 json.dump(traffic, open(sys.argv[5], "w"), indent=1)
