@@ -125,7 +125,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
     # main + wgrad + teacher streams + RCCL's: more than the default 4 hardware queues, see the package
     # __init__ (without this the stream overlap is serialised as soon as a process group exists)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     from mcncrossmodalemotions_amd import _lib, vl, zoo, train, batch as xbatch, dagnn

@@ -15,8 +15,10 @@ import os as _os
 # The step runs on 3-4 HIP streams (main, wgrad side stream, teacher stream, RCCL's own).  ROCm maps
 # streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has taken its queues the compute
 # streams start sharing one and the overlap is silently serialised (measured: 3380 -> 3080 pairs/s as soon
-# as a process group exists).  Must be set before the HIP runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# as a process group exists).  Must be set before the HIP runtime initialises.  16 since round 2: with a process
+# group AND the library's own communicator (--parserv rccl-capi) 8 queues serialise again (2600 vs 3140 pairs/s),
+# and the torch path with a process group gains too (3324 -> 3503 pairs/s).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 __version__ = "0.1.0"

@@ -1,73 +1,91 @@
 #!/usr/bin/env python
 """Regenerates profiles/README.md from the JSON / text evidence under profiles/<round>/.
-usage: python tools/make_profiles_readme.py r01"""
+usage: python tools/make_profiles_readme.py r02"""
 import json, os, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(root, "profiles", R)
-def L(n): return json.load(open(os.path.join(P, n + ".json")))
-d, ds, st, te, jo, mf = (L("bench_distill_n1"), L("bench_distill_serial_n1"), L("bench_student_n1"),
-                         L("bench_teacher_n1"), L("bench_joint_n1"), L("bench_distill_13frames_senet50_n1"))
+def L(n): return json.loads(open(os.path.join(P, n + ".json")).read().strip().splitlines()[-1])
+d, dd, ds, st, te, jo, mf = (L("bench_distill_n1"), L("bench_distill_driver_flags_n1"), L("bench_distill_serial_n1"),
+                             L("bench_student_n1"), L("bench_teacher_n1"), L("bench_joint_n1"),
+                             L("bench_distill_13frames_senet50_n1"))
+se, se256, r256, c1, capi = (L("bench_distill_senet50_n1"), L("bench_distill_senet50_b256_n1"), L("bench_distill_b256_n1"),
+                             L("bench_cpu_teacher"), L("bench_distill_capi_1rank"))
 r, c = d["roofline"], d["cpu_baseline"]
 tests = open(os.path.join(P, "pytest_gpu.txt")).read().strip().splitlines()[-1]
 ks = open(os.path.join(P, "kernel_stats.txt")).read()
 m = re.search(re.escape(r["kernel"]) + r".*?\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\n", ks)
 rocavg = float(m.group(3)) if m else float("nan")
+tot = re.search(r"TOTAL kernel time: .*", ks).group(0)
+meta = json.load(open(os.path.join(P, "pmc_traffic.json"))).get("_meta", {})
 pct = lambda x: "%.1f %%" % (100 * x)
-txt = f"""# profiles/ — measured evidence, round 1 (MI355X, 1 GPU, ROCm 7.2)
+w = d.get("windows") or {}
+rows = "\n".join("| `%s` | %.3f | %.1f | %d |" % (k["kernel"], k["ms_per_step"], k["tflops"], k["launches_per_step"])
+                 for k in r["per_kernel"])
+txt = f"""# profiles/ — measured evidence, round {int(R[1:])} (MI355X, 1 GPU, ROCm 7.2)
 
-Everything under `{R}/` comes from ONE `gpurun` call on a fresh MI355X box:
-`bash tools/collect_profiles.sh {R}` (the script lists every command); this file is generated from
-those files by `tools/make_profiles_readme.py`.
+Everything under `{R}/` comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
+`bash tools/collect_profiles.sh {R} <commit>` (the script lists every command); this file is generated from
+those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous round's evidence, unchanged.
 
 | file | what |
 |---|---|
 | `{R}/pytest_gpu.txt` | `python -m pytest tests -q -m gpu` on that box ({tests}) |
-| `{R}/bench_distill_n1.json` | `python bench.py` — the driver's contract line (default: distillation step, 32 pairs/GPU, 20 steps) incl. `roofline` + `cpu_baseline` |
+| `{R}/bench_distill_n1.json` | `python bench.py` — default line: distillation step, 32 pairs/GPU, K chosen for a >= 2 s timed region, incl. `roofline`, `cpu_baseline`, `windows` |
+| `{R}/bench_distill_driver_flags_n1.json` | `python bench.py --steps 20 --warmup 5` — the driver's command line (0.5 s settle phase in front of the 20 timed steps) |
 | `{R}/bench_distill_serial_n1.json` | `python bench.py --serial` — same step on ONE HIP stream (no overlap), the mode the roofline leg and the profiles below use |
-| `{R}/bench_under_rocprof.json`, `{R}/kernel_stats.txt` | `rocprofv3 --kernel-trace --stats -- python bench.py --serial --no-cpu-baseline` and its per-kernel summary (`tools/prof_summary.py`) |
+| `{R}/bench_under_rocprof.json`, `{R}/kernel_stats.txt` | `rocprofv3 --kernel-trace --stats -- python bench.py --serial --no-cpu-baseline --steps 60 --warmup 10` and its per-kernel summary (`tools/prof_summary.py`) |
 | `{R}/bench_student_n1.json`, `bench_teacher_n1.json`, `bench_joint_n1.json` | BASELINE configs 2, 3 and the config-5 shard (`--workload student|teacher|joint`) |
-| `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated (`--frames 13 --teacher senet50`) |
-| `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` from the JSON |
+| `{R}/bench_distill_senet50_n1.json` | the reference's default teacher (`run_distillation.m:82`): `--teacher senet50`, one face per pair |
+| `{R}/bench_distill_senet50_b256_n1.json`, `bench_distill_b256_n1.json` | north_star's batch 256 on ONE GPU (`--per-gpu-batch 256`), SE-ResNet-50 / ResNet-50 teacher |
+| `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
+| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only) |
+| `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
+| `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` (+ the commit) from the JSON |
 
 ## Headline (default bench line)
 
-* **{d['value']} pairs/s** on 1 MI355X ({d['ms_per_step']} ms/step; 32 faces 224x224x3 + 32 spectrograms 512x300; fp32)
-  = {d['model_tflops_per_gpu']} model-TFLOP/s = **{pct(d['model_frac_of_fp32_mfma_peak'])} of the 157.3 TFLOP/s fp32-MFMA peak for the WHOLE step**
-  (teacher fwd + student fwd/bwd + BN/pool/loss/SGD; algorithmic 24.345 GFLOP per pair, conv + FC only).
-  Streams: {d['config']['streams']}.  The same step on one stream: {ds['value']} pairs/s ({ds['ms_per_step']} ms).
+* **{d['value']} pairs/s** on 1 MI355X ({d['ms_per_step']} ms/step over {d['steps']} timed steps = {d['steps'] * d['ms_per_step'] / 1e3:.2f} s;
+  32 faces 224x224x3 + 32 spectrograms 512x300; fp32) = {d['model_tflops_per_gpu']} model-TFLOP/s =
+  **{pct(d['model_frac_of_fp32_mfma_peak'])} of the 157.3 TFLOP/s fp32-MFMA peak for the WHOLE step** (teacher fwd + student fwd/bwd +
+  BN/pool/loss/SGD; algorithmic 24.345 GFLOP per pair, conv + FC only).  Windows inside the timed region
+  ({w.get('n')} x {w.get('steps_each')} steps): min {w.get('min')} / median {w.get('median')} / max {w.get('max')} pairs/s.
+  With the driver's flags (`--steps 20 --warmup 5`): {dd['value']} pairs/s.  One stream: {ds['value']} pairs/s ({ds['ms_per_step']} ms).
 * dominant kernel `{r['kernel']}`: **{r['achieved']} TFLOP/s = {pct(r['frac'])} of the fp32-MFMA roofline**
   ({r['launches']} launches, avg {r['avg_launch_ms']} ms, {r['flop_per_launch']/1e9:.2f} GFLOP algorithmic per launch; HIP events on the
   launch stream, serial pass); `kernel_stats.txt` (rocprofv3, same command) has it at {rocavg:.1f} us average.
   All convolution kernels together: {r['all_conv_kernels']['achieved']} TFLOP/s over {r['all_conv_kernels']['ms_per_step']} ms per step.
-  HBM traffic of that kernel from the PMC passes: {(r.get('traffic') or 0)/1e6:.0f} MB per launch (FETCH_SIZE doubled per the guide).
-* `tools/mfma_peak.hip` (ceiling probe on the same kind of box): pure `v_mfma_f32_32x32x2_f32` sustains 155.4 TFLOP/s
-  (98.8 % of 157.3, no throttling over 3.6 s); with the LDS fragment reads + barrier of the conv main loop 148;
-  with this kernel's instruction mix (VALU address math, 5 buffer loads and 2 LDS stores per 16 MFMA) 128-135.
-* CPU baseline (oracle fp32 path = MatConvNet-CPU-equivalent restatement, OpenMP): {c['value']} pairs/s on {c['cores']} host cores
-  ({c['sample']}).
+  HBM traffic of that kernel from the PMC passes (commit `{r.get('traffic_profile_commit')}`): {(r.get('traffic') or 0)/1e6:.0f} MB per launch.
+* CPU baseline (oracle fp32 path = MatConvNet-CPU-equivalent restatement): {c['value']} pairs/s = {c.get('gflops')} GFLOP/s on {c['cores']} cores
+  of {c.get('cpu')} ({c['sample']}).  Config 1 by itself: {c1['value']} images/s ({c1['cpu_baseline'].get('gflops')} GFLOP/s).
+* `{tot}` (serial mode under rocprofv3).
+
+| kernel (serial pass, HIP events) | ms / step | TFLOP/s | launches / step |
+|---|---|---|---|
+{rows}
 
 | config | per-GPU batch | throughput | ms/step | whole-step fraction of fp32-MFMA peak |
 |---|---|---|---|---|
 | 4 (default): frozen ResNet50 teacher -> VGGVox student distillation step | 32 pairs | {d['value']} pairs/s | {d['ms_per_step']} | {pct(d['model_frac_of_fp32_mfma_peak'])} |
 | 4, one stream (`--serial`) | 32 pairs | {ds['value']} pairs/s | {ds['ms_per_step']} | {pct(ds['model_frac_of_fp32_mfma_peak'])} |
+| 4 with the reference's default teacher (SE-ResNet50), one face per pair | 32 pairs | {se['value']} pairs/s | {se['ms_per_step']} | {pct(se['model_frac_of_fp32_mfma_peak'])} |
+| north_star batch 256 on one GPU, ResNet50 teacher | 256 pairs | {r256['value']} pairs/s | {r256['ms_per_step']} | {pct(r256['model_frac_of_fp32_mfma_peak'])} |
+| north_star batch 256 on one GPU, SE-ResNet50 teacher | 256 pairs | {se256['value']} pairs/s | {se256['ms_per_step']} | {pct(se256['model_frac_of_fp32_mfma_peak'])} |
 | 2: VGGVox student fwd+bwd+update | 64 | {st['value']} samples/s | {st['ms_per_step']} | {pct(st['model_frac_of_fp32_mfma_peak'])} |
 | 3: SE-ResNet50 teacher fwd (2 sample-slice lanes) | 128 | {te['value']} img/s | {te['ms_per_step']} | {pct(te['model_frac_of_fp32_mfma_peak'])} |
 | 5 shard: SE-ResNet50 fwd+bwd + student fwd+bwd | 64 pairs | {jo['value']} pairs/s | {jo['ms_per_step']} | {pct(jo['model_frac_of_fp32_mfma_peak'])} |
 | 8f-1: 13 frames/pair, SE-ResNet50 teacher + student step | 32 pairs (416 faces) | {mf['value']} pairs/s | {mf['ms_per_step']} | {pct(mf['model_frac_of_fp32_mfma_peak'])} |
+| 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
-Progress within the round (default bench, N = 1): 1004 -> 1368 (branch-free staging) -> 1819 (buffer-load
-gathers + masks + MFMA/VALU interleave + split-K) -> 2300 (coalesced wgrad, pooling via argmax table) ->
-2667 (measured tile autotuner) -> 2899 (fused bnorm+relu+pool, fc6 dgrad fold, scalar-cache epilogue) ->
-3041 (parallel fixed-order split reduction) -> 3058 (register double-buffered MFMA fragments) ->
-3111 (wgrad side stream) -> 3172 (teacher on its own stream) -> 3407 (teacher one batch ahead) ->
-3482 (vectorised wgrad staging, one launch for all dgrad stride classes) -> **{d['value']:.0f} pairs/s**
-(bounded host run-ahead: no queue-full stalls).
+Round 2 did not move the default line ({d['value']} vs 3502 pairs/s in round 1): what was built is in DESIGN.md 2.1b / 2.1c — a
+persistent LDS-DMA kernel for the 1x1 layers (correct, at parity), and the measurements that say where the time goes
+(clock ramp, instruction-mix ceiling, epilogue stores that do not overlap: +10.5 % on this line with the stores compiled
+out).
 
 ## How the numbers were taken
 ```
 python bench.py                                           # value, roofline (2nd, serial pass with HIP events), cpu_baseline
-rocprofv3 --kernel-trace --stats -d ... -- python bench.py --serial --no-cpu-baseline
+rocprofv3 --kernel-trace --stats -d ... -- python bench.py --serial --no-cpu-baseline --steps 60 --warmup 10
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \\
           SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -- python bench.py --serial --steps 3 ...
 rocprofv3 --kernel-trace --pmc FETCH_SIZE  ...            # separate pass
@@ -75,9 +93,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE  ...            # separate pass
 ```
 Kernel durations (HIP events and rocprofv3 alike) are only meaningful when kernels do not share the chip,
 so both are taken in `--serial` mode; the throughput `value` is taken with the overlap streams on.
-`pmc_summary.txt`: `mfma%` = MFMA-pipe busy cycles / (4 SIMDs x CU-busy cycles) -- 73-78 % for the 128x128-tile
-kernels; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 under-reports wide reads by 2x; upper estimate
-for the dword gathers).
+`pmc_summary.txt`: `mfma%` = MFMA-pipe busy cycles / (4 SIMDs x CU-busy cycles); FETCH_SIZE is doubled per
+MI355X_MICROARCH.md (gfx950 under-reports wide reads by 2x; upper estimate for the dword gathers).
 """
 open(os.path.join(root, "profiles", "README.md"), "w").write(txt)
 print("wrote profiles/README.md")
