@@ -220,13 +220,25 @@ static int pick_cfg(long long M, long long NP, int nkt) {
   return bi;
 }
 
+#ifndef XM_DMA_NST7
+#define XM_DMA_NST7 4
+#endif
+#ifndef XM_DMA_NST9
+#define XM_DMA_NST9 4
+#endif
+#ifndef XM_DMA_NST10
+#define XM_DMA_NST10 4
+#endif
+#ifndef XM_DMA_PERCU
+#define XM_DMA_PERCU {2, 2, 4, 4}
+#endif
 static void launch_gemm_dma(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_t st) {
   dim3 block(256);
   switch (ci) {
-    case 7: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 2, 2, 3>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 2, 2, XM_DMA_NST7>), grid, block, 0, st, a); break;
     case 8: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 1, 4, 3>), grid, block, 0, st, a); break;
-    case 9: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 2, 2, 2, 4>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 1, 2, 2, 4>), grid, block, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 2, 2, 2, XM_DMA_NST9>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 1, 2, 2, XM_DMA_NST10>), grid, block, 0, st, a); break;
   }
 }
 
@@ -310,7 +322,7 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
     ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st);
     if (is_dma_cfg(ci)) {
       // persistent: one round of co-resident blocks (a multiple of 8 so that every XCD gets the same share)
-      static const int per_cu_tab[] = {3, 2, 4, 4};          // co-resident blocks per CU (LDS-limited)
+      static const int per_cu_tab[] = XM_DMA_PERCU;          // co-resident blocks per CU (LDS-limited)
       const int slots = std::max(8, 256 * per_cu_tab[ci - kNumBaseCfg] / std::max(1, splits));
       const int ntl = a.nbm * a.nbn;
       const int g = ntl <= slots ? ntl : slots - slots % 8;
@@ -1173,7 +1185,8 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
   const Cfg &c = kCfgs[ci];
   if (kind == 0 && is_dma_cfg(ci))
-    snprintf(buf, len, "conv_gemm_dma_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, ci >= 9 ? 4 : 3);
+    snprintf(buf, len, "conv_gemm_dma_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn,
+             ci == 7 ? XM_DMA_NST7 : ci == 8 ? 3 : ci == 9 ? XM_DMA_NST9 : XM_DMA_NST10);
   else if (kind == 0)
     snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, key % 2);
   else if (kind == 2)

@@ -220,29 +220,30 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     // accumulator registers holds 4 consecutive channel rows of one pixel; a 4x4 transpose inside
     // the lane quad turns that into 4 consecutive pixels of one row -> one 16-byte store per lane.
     const int iq = l31 & 3;
+    // Per-row constants of the rows THIS lane stores after the transpose (one row per (i, g4)), fetched with
+    // per-lane loads that are all in flight together.  (They used to come through the scalar cache group by group
+    // -- 8-16 s_loads and an s_waitcnt per group: a chain of eight scalar round trips per tile, 17-20 % of the
+    // store-heavy layers.)  Same fma operands as before the transpose, so the results are bit-identical.
+    float rmul[TM][4], radd[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rowc = min(wbase + i * 32 + 8 * g4 + 4 * half + iq, a.M - 1);
+        float m_ = 1.f, t_ = 0.f;
+        if (a.scale) {
+          m_ = a.scale[rowc];
+          t_ = a.shift[rowc];
+        }
+        if (a.bias) t_ += a.bias[rowc] * m_;
+        rmul[i][g4] = m_;
+        radd[i][g4] = t_;
+      }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int rb_lo = wbase + i * 32 + 8 * g4;  // wave-uniform; this lane half adds 4
-        float mul[4], add[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c_lo = min(rb_lo + k, a.M - 1), c_hi = min(rb_lo + k + 4, a.M - 1);
-          mul[k] = 1.f;
-          add[k] = 0.f;
-          if (a.scale) {
-            float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
-            float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
-            mul[k] = half ? s_hi : s_lo;
-            add[k] = half ? t_hi : t_lo;
-          }
-          if (a.bias) {
-            float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
-            add[k] += (half ? b_hi : b_lo) * mul[k];
-          }
-        }
-        const int row = rb_lo + 4 * half + iq;  // the row this lane stores after the transpose
+        const int row = wbase + i * 32 + 8 * g4 + 4 * half + iq;  // the row this lane stores after the transpose
         const int rowc = min(row, a.M - 1);
         uint32_t mc = xm_div((uint32_t)rowc, a.divMU);
         const int moff = (int)mc * a.oChanStride + (rowc - (int)mc * (int)a.divMU.d) * a.oUStride;
@@ -250,11 +251,12 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
         for (int j = 0; j < TN; ++j) {
           float v[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k] * mul[k] + add[k];
+          for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k];
           quad_transpose4(v, iq);
           if (row < a.M && pok[j]) {
             const int off = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
-            f32x4 o = {v[0], v[1], v[2], v[3]};
+            f32x4 o = {v[0] * rmul[i][g4] + radd[i][g4], v[1] * rmul[i][g4] + radd[i][g4],
+                       v[2] * rmul[i][g4] + radd[i][g4], v[3] * rmul[i][g4] + radd[i][g4]};
             if (a.resid) {
               // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
               // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
@@ -278,31 +280,33 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     }
     return;
   }
+  // scalar-store path (pixel quads straddle samples: H*W % 4 != 0).  Row constants: per-lane loads, all 16 rows of a
+  // row tile in flight together (see the wide path).
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    float rmul[16], radd[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row_lo = wbase + i * 32 + (r & 3) + 8 * (r >> 2);  // wave-uniform
-      const int m = row_lo + 4 * half;
-      const int c_lo = min(row_lo, a.M - 1), c_hi = min(row_lo + 4, a.M - 1);
-      float mul = 1.f, add = 0.f;
+      const int mc_ = min(wbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+      float m_ = 1.f, t_ = 0.f;
       if (a.scale) {
-        float s_lo = a.scale[c_lo], s_hi = a.scale[c_hi];
-        float t_lo = a.shift[c_lo], t_hi = a.shift[c_hi];
-        mul = half ? s_hi : s_lo;
-        add = half ? t_hi : t_lo;
+        m_ = a.scale[mc_];
+        t_ = a.shift[mc_];
       }
-      if (a.bias) {
-        float b_lo = a.bias[c_lo], b_hi = a.bias[c_hi];
-        add += (half ? b_hi : b_lo) * mul;  // (acc + b) * s + t == acc * s + (b * s + t)
-      }
+      if (a.bias) t_ += a.bias[mc_] * m_;  // (acc + b) * s + t == acc * s + (b * s + t)
+      rmul[r] = m_;
+      radd[r] = t_;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       uint32_t mc = xm_div((uint32_t)min(m, a.M - 1), a.divMU);
       const int moff = (int)mc * a.oChanStride + (min(m, a.M - 1) - (int)mc * (int)a.divMU.d) * a.oUStride;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (m < a.M && pok[j]) {
           int off = obase[j] + moff;
-          float v = acc[i][j][r] * mul + add;
+          float v = acc[i][j][r] * rmul[r] + radd[r];
           if (a.resid) v += a.resid[off];
           if (a.relu) v = fmaxf(v, 0.f);
           a.Y[off] = v;
@@ -748,9 +752,14 @@ conv_gemm_dma_kernel(const ConvGemmArgs a) {
     for (int s_ = 0; s_ < NST - 1; ++s_)
       if (s_ < total) issue_next();
     // stage 0 landed?  (up to NST-2 later stages may stay in flight)
-    if (NST >= 4 && total >= 3) dma_wait<2 * (NWA + NWB)>();
-    else if (total >= 2) dma_wait<(NST >= 3 ? 1 : 0) * (NWA + NWB)>();
-    else dma_wait<0>();
+    {
+      const int later0 = min(total - 1, NST - 2);
+      if (NST >= 6 && later0 >= 4) dma_wait<4 * (NWA + NWB)>();
+      else if (NST >= 5 && later0 >= 3) dma_wait<3 * (NWA + NWB)>();
+      else if (NST >= 4 && later0 >= 2) dma_wait<2 * (NWA + NWB)>();
+      else if (NST >= 3 && later0 >= 1) dma_wait<NWA + NWB>();
+      else dma_wait<0>();
+    }
     __syncthreads();
     int slot = 0, ckt = 0, ctile = seg0 + bidx;   // compute side: stage inside the tile, logical tile
     XM_DREAD(slot, 0, af0, bf0)
@@ -763,7 +772,9 @@ conv_gemm_dma_kernel(const ConvGemmArgs a) {
       if (g + 1 < total) {
         // stage g+1 must have landed; stages g+2 .. g+NST-2 (already requested) may stay in flight
         const int later = min(total - 2 - g, NST - 3);
-        if (NST >= 4 && later >= 1) dma_wait<NWA + NWB>();
+        if (NST >= 6 && later >= 3) dma_wait<3 * (NWA + NWB)>();
+        else if (NST >= 5 && later >= 2) dma_wait<2 * (NWA + NWB)>();
+        else if (NST >= 4 && later >= 1) dma_wait<NWA + NWB>();
         else dma_wait<0>();
         __syncthreads();   // stage g+1 visible to all waves; every wave is done with stage g-1 (its slot is free)
         if (g + NST - 1 < total) issue_next();

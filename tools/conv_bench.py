@@ -66,7 +66,7 @@ def main():
         N = CASES[nm][8] if len(CASES[nm]) > 8 else args.n
         x = vl.from_numpy(np.random.default_rng(0).standard_normal((H, W, C, N)).astype(np.float32))
         f = vl.from_numpy(np.random.default_rng(1).standard_normal((FH, FW, C, K)).astype(np.float32))
-        b = vl.from_numpy(np.zeros((K, 1), np.float32))
+        b = None if os.environ.get("CB_NOBIAS") else vl.from_numpy(np.zeros((K, 1), np.float32))
         y = vl.vl_nnconv(x, f, b, stride=s, pad=p)
         dz = vl.from_numpy(np.random.default_rng(2).standard_normal(tuple(y.shape)).astype(np.float32))
         Ho, Wo = int(y.shape[0]), int(y.shape[1])
