@@ -162,6 +162,8 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
  * over X that rebuild the routed, ReLU-masked derivative on the fly.  Results are identical to the
  * three separate operators.  `moments` (backward) is what the forward returned; train != 0 applies
  * the batch-statistics terms of vl_nnbnorm's backward (train mode), 0 treats them as constants.
+ * y_pool (backward, optional): the forward's pooled output; with it the two per-channel sums are formed from
+ * the pooled tensors alone (x is read once instead of twice).
  * dxsum_out (optional, C floats): per-channel sum of DX = the DZDB of a vl_nnconv that produced X. */
 int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *g,
                                  const float *b, float epsilon, const float *moments_in, int ph, int pw,
@@ -170,8 +172,8 @@ int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, con
 int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, const float *g,
                                   const float *b, const float *moments, int train, int ph, int pw,
                                   int sy, int sx, int pt, int pb, int pl, int pr,
-                                  const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
-                                  float *dg_out, float *db_out, float *dxsum_out, void *stream);
+                                  const unsigned char *argmax, const float *y_pool, const float *dzdy_pool,
+                                  float *dx_out, float *dg_out, float *db_out, float *dxsum_out, void *stream);
 
 /* ---- elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, mcnExtraLayers Scale/Axpy ------------
  * dzdy == NULL: forward; otherwise y receives DZDX. */

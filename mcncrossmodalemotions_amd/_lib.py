@@ -59,7 +59,7 @@ SIGNATURES = {
     "xm_nnbnorm_relu_pool_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp] + [_i] * 8 +
                                     [c_fp, c_fp, c_fp, _vp],
     "xm_nnbnorm_relu_pool_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _i] + [_i] * 8 +
-                                     [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
+                                     [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_nnrelu": [c_fp, _sz, _f, c_fp, c_fp, _vp],
     "xm_nnsigmoid": [c_fp, _sz, c_fp, c_fp, _vp],
     "xm_sum2": [c_fp, c_fp, _sz, _i, c_fp, _vp],

@@ -378,6 +378,7 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
   const int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
   const int w2 = min(w0 + g.pw, g.W), h2 = min(h0 + g.ph, g.H);
   const int w1 = max(w0, 0), h1 = max(h0, 0);
+#pragma unroll 2
   for (int plane = blockIdx.y * blockDim.z + threadIdx.z; plane < planes; plane += gridDim.y * blockDim.z) {
     const float *p = x + (size_t)plane * g.H * g.W;
     const size_t o = (size_t)plane * g.Ho * g.Wo + ho + (size_t)g.Ho * wo;
@@ -441,6 +442,82 @@ pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned cha
       r *= 1.0f / (float)((h2 - h1) * (w2 - w1));
     }
     if (y) y[o] = r;
+  }
+}
+
+// LDS-staged variant for max pooling with a compile-time window: one block owns `wob` output columns of one
+// plane.  The input columns under them are ONE contiguous run of the plane (H is the fastest axis): it is
+// copied into LDS with 16-byte loads (each element fetched once, the fused bnorm+relu applied once per element
+// instead of once per window tap), then every output reads its PH*PW taps from LDS.  The one-thread-per-output
+// kernel above issues PH*PW strided 4-byte loads per output and runs at ~2.7 TB/s on the student's first
+// pooling layer; this one is bound by the HBM stream.
+template <int PH, int PW>
+__global__ void __launch_bounds__(256)
+pool_fwd_lds_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ amax,
+                    PoolGeo g, FastDiv divHo, int wob, size_t total, const float *__restrict__ bn_g,
+                    const float *__restrict__ bn_b, const float *__restrict__ bn_mom, int C) {
+  extern __shared__ float tile[];
+  const int plane = blockIdx.y;
+  const int wo0 = blockIdx.x * wob;
+  const int nwo = min(wob, g.Wo - wo0);
+  const int wlo = max(wo0 * g.sx - g.pl, 0);
+  const int whi = min((wo0 + nwo - 1) * g.sx - g.pl + PW, g.W);
+  const size_t base = (size_t)plane * g.H * g.W + (size_t)wlo * g.H;
+  const int lead = (int)(base & 3);
+  const size_t start = base - lead;
+  const int cnt = (whi - wlo) * g.H + lead;
+  float bsc = 1.f, bmu = 0.f, bbb = 0.f;
+  if (bn_g) {
+    int c = plane % C;
+    bsc = bn_g[c] / bn_mom[C + c];
+    bmu = bn_mom[c];
+    bbb = bn_b[c];
+  }
+  for (int i = threadIdx.x * 4; i < cnt; i += 1024) {
+    float4 v;
+    if (start + i + 3 < total) {
+      v = *reinterpret_cast<const float4 *>(x + start + i);
+    } else {
+      v.x = x[start + i];
+      v.y = start + i + 1 < total ? x[start + i + 1] : 0.f;
+      v.z = start + i + 2 < total ? x[start + i + 2] : 0.f;
+      v.w = 0.f;
+    }
+    if (bn_g) {
+      v.x = fmaxf(bsc * (v.x - bmu) + bbb, 0.f);
+      v.y = fmaxf(bsc * (v.y - bmu) + bbb, 0.f);
+      v.z = fmaxf(bsc * (v.z - bmu) + bbb, 0.f);
+      v.w = fmaxf(bsc * (v.w - bmu) + bbb, 0.f);
+    }
+    *reinterpret_cast<float4 *>(tile + i) = v;
+  }
+  __syncthreads();
+  const float *t = tile + lead - wlo * g.H;  // t[h + H * w] for w in [wlo, whi)
+  for (int o = threadIdx.x; o < nwo * g.Ho; o += 256) {
+    const int wl = (int)xm_div((uint32_t)o, divHo);
+    const int ho = o - wl * g.Ho, wo = wo0 + wl;
+    const int w0 = wo * g.sx - g.pl, h0 = ho * g.sy - g.pt;
+    float v[PH * PW];
+#pragma unroll
+    for (int dw = 0; dw < PW; ++dw)
+#pragma unroll
+      for (int dh = 0; dh < PH; ++dh) {
+        int h = h0 + dh, w = w0 + dw;
+        bool ok = ((unsigned)h < (unsigned)g.H) & ((unsigned)w < (unsigned)g.W);
+        float ld = t[ok ? h + g.H * w : wlo * g.H];
+        v[dh + PH * dw] = ok ? ld : -INFINITY;
+      }
+    float r = -INFINITY;
+    int code = 0;
+#pragma unroll
+    for (int i = 0; i < PH * PW; ++i)
+      if (v[i] > r) {
+        r = v[i];
+        code = i;
+      }
+    const size_t oo = (size_t)plane * g.Ho * g.Wo + ho + (size_t)g.Ho * wo;
+    if (amax) amax[oo] = (unsigned char)code;
+    if (y) y[oo] = r;
   }
 }
 
@@ -577,6 +654,25 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
     XM_LAUNCH_CHECK();
     return XM_OK;
   }
+  // LDS-staged kernel: max pooling, 3x3 window, planes large enough to fill a block, 16-byte aligned tensor
+  if (method == XM_POOL_MAX && ph == 3 && pw == 3 && ((uintptr_t)x & 15) == 0 && (long long)C * N <= 65535 &&
+      g.Ho * g.Wo >= 256 && !getenv("XM_NO_POOL_LDS")) {
+    static const int lds_kb = getenv("XM_POOL_LDS_KB") ? atoi(getenv("XM_POOL_LDS_KB")) : 16;
+    const int maxcols = lds_kb * 256 / H;  // 16 KB of LDS per block: 10 blocks per CU, measured best of 8 / 16 / 32 / 64
+    int wob = maxcols >= pw ? (maxcols - pw) / sx + 1 : 0;
+    wob = std::min(wob, g.Wo);
+    if (wob >= 4 || (wob >= 1 && wob == g.Wo)) {
+      // even out the column groups (the last block would otherwise hold a sliver)
+      const int groups = (g.Wo + wob - 1) / wob;
+      wob = (g.Wo + groups - 1) / groups;
+      const int ncols = (wob - 1) * sx + pw;
+      const size_t lds = ((size_t)ncols * H + 8) * sizeof(float);
+      hipLaunchKernelGGL((pool_fwd_lds_kernel<3, 3>), dim3(groups, C * N), dim3(256), lds, st, x, y, amax, g,
+                         make_fastdiv((uint32_t)g.Ho), wob, (size_t)H * W * C * N, bn_g, bn_b, bn_mom, C);
+      XM_LAUNCH_CHECK();
+      return XM_OK;
+    }
+  }
   PoolLaunch pl_ = pool_launch(g.Ho, g.Wo, (long long)C * N);
   if (ph == 3 && pw == 3)
     hipLaunchKernelGGL((pool_fwd_kernel<3, 3>), pl_.grid, pl_.block, 0, st, x, y, amax, g, C * N, method, bn_g, bn_b,
@@ -652,6 +748,7 @@ bnpool_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__
   if (h < g.H && w < g.W) {
     const Route4 r = make_route(g, h, w, divSy, divSx);
     const float mu = mom[c], sc = gg[c] / mom[C + c], bc = bb[c];
+#pragma unroll 4
     for (int n = sp; n < N; n += S) {
       const size_t plane = (size_t)c + (size_t)C * n;
       float xv = x[plane * g.H * g.W + h + (size_t)g.H * w];
@@ -703,6 +800,7 @@ bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g
     const double gsd = (double)gg[c] / (double)sg;
     const double c1 = train ? sums[c] / m : 0.0;
     const double c2 = train ? sums[C + c] / (m * (double)sg * (double)sg) : 0.0;
+#pragma unroll 4
     for (int n = sp; n < N; n += S) {
       const size_t plane = (size_t)c + (size_t)C * n;
       const size_t xi = plane * g.H * g.W + h + (size_t)g.H * w;
@@ -712,6 +810,162 @@ bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g
       float o = (float)(gsd * ((double)d - c1 - ((double)xv - (double)mu) * c2));
       dx[xi] = o;
       acc += (double)o;
+    }
+  }
+  if (part2) {
+    __shared__ double red[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 4) red[tid] = 0.0;
+    __syncthreads();
+    acc = xm_wave_sum_d(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      size_t nb = (size_t)gridDim.x * gridDim.z;
+      part2[(size_t)c * nb + (size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+  }
+}
+
+// Pooled-domain sums.  The routed derivative is non-zero only at window maxima that passed the relu, and there
+//   y_p = g/sigma (x_argmax - mu) + b > 0    =>    x_argmax - mu = (y_p - b) sigma / g,
+// so   sum dz = sum_p [y_p > 0] dzdy_p   and   sum dz (x - mu) = sigma/g * sum_p [y_p > 0] dzdy_p (y_p - b):
+// two POOLED tensors are read instead of x + table + dzdy (3.7x fewer bytes on a 3x3 / stride-2 layer).
+// Channels whose gain is too small for the inversion (|b| > 100 |g|: rounding of y_p - b would be amplified)
+// gather x at the recorded argmax instead.  grid (C, S), part[c][s] = (sum dz, sum dz (x - mu)).
+__global__ void __launch_bounds__(256)
+bnpool_bwd_partial_pooled_kernel(const float *__restrict__ x, const float *__restrict__ yp,
+                                 const float *__restrict__ dp, const unsigned char *__restrict__ amax,
+                                 const float *__restrict__ gg, const float *__restrict__ bb,
+                                 const float *__restrict__ mom, double *__restrict__ part, PoolGeo g,
+                                 FastDiv divHo, int C, int N, int S) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int HWo = g.Ho * g.Wo;
+  const float gc = gg[c], bc = bb[c];
+  const double mu = mom[c];
+  const bool invert = fabsf(bc) <= 100.f * fabsf(gc);
+  double a = 0.0, b = 0.0;
+  for (int n = s; n < N; n += S) {
+    const size_t plane = (size_t)c + (size_t)C * n;
+    const size_t off = plane * HWo;
+    if (invert) {
+#pragma unroll 4
+      for (int i = threadIdx.x; i < HWo; i += 256) {
+        const float yv = yp[off + i];
+        const float d = yv > 0.f ? dp[off + i] : 0.f;
+        a += (double)d;
+        b += (double)d * ((double)yv - (double)bc);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HWo; i += 256) {
+        const float yv = yp[off + i];
+        const float d = yv > 0.f ? dp[off + i] : 0.f;
+        const int code = amax[off + i];
+        const int wo = (int)xm_div((uint32_t)i, divHo), ho = i - wo * g.Ho;
+        const int dw = code / g.ph, dh = code - dw * g.ph;
+        const int h = min(max(ho * g.sy - g.pt + dh, 0), g.H - 1), w = min(max(wo * g.sx - g.pl + dw, 0), g.W - 1);
+        a += (double)d;
+        b += (double)d * ((double)x[plane * g.H * g.W + h + (size_t)g.H * w] - mu);
+      }
+    }
+  }
+  if (invert) b *= (double)mom[C + c] / (double)gc;
+  __shared__ double red[8];
+  block_reduce2(a, b, red);
+  if (threadIdx.x == 0) {
+    part[2 * ((size_t)c * S + s)] = a;
+    part[2 * ((size_t)c * S + s) + 1] = b;
+  }
+}
+
+// Patch variant of bnpool_bwd_apply_kernel: a thread owns the SY x SX input elements whose (h + pt, w + pl)
+// fall in one stride cell.  With ph <= 2 SY and pw <= 2 SX they are covered by the same <= 2 x 2 windows, so
+// the 4 (dzdy, table byte) pairs are loaded once per PATCH instead of once per element (10 loads per four
+// elements instead of 36 on the 3x3 / stride-2 layers); contributions are added in the same window order.
+// grid (gx, C, gz * S), block (bx, by) over patches.  VEC2 (SY == 2, H and pt even): the two rows of a patch
+// column are one aligned 8-byte access.
+template <int SY, int SX, bool VEC2>
+__global__ void __launch_bounds__(256)
+bnpool_bwd_apply_patch_kernel(const float *__restrict__ x, const float *__restrict__ gg,
+                              const float *__restrict__ bb, const float *__restrict__ mom,
+                              const double *__restrict__ sums, const unsigned char *__restrict__ amax,
+                              const float *__restrict__ dp, float *__restrict__ dx, double *__restrict__ part2,
+                              PoolGeo g, int KH, int KW, int C, int N, int S, double m, int train) {
+  const int c = blockIdx.y;
+  const int zz = blockIdx.z / S, sp = blockIdx.z % S;
+  const int kh = zz * blockDim.x + threadIdx.x;
+  const int kw = blockIdx.x * blockDim.y + threadIdx.y;
+  double acc = 0.0;
+  if (kh < KH && kw < KW) {
+    int off[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ho = kh - 1 + i, wo = kw - 1 + j;
+        ok[i + 2 * j] = ((unsigned)ho < (unsigned)g.Ho) & ((unsigned)wo < (unsigned)g.Wo);
+        off[i + 2 * j] = min(max(ho, 0), g.Ho - 1) + g.Ho * min(max(wo, 0), g.Wo - 1);
+      }
+    const int h0 = kh * SY - g.pt, w0 = kw * SX - g.pl;
+    const float mu = mom[c], sg = mom[C + c];
+    const float gs = gg[c] / sg, bc = bb[c];
+    const double gsd = (double)gg[c] / (double)sg;
+    const double c1 = train ? sums[c] / m : 0.0;
+    const double c2 = train ? sums[C + c] / (m * (double)sg * (double)sg) : 0.0;
+#pragma unroll 2
+    for (int n = sp; n < N; n += S) {
+      const size_t plane = (size_t)c + (size_t)C * n;
+      const size_t ob = plane * g.Ho * g.Wo;
+      float d[4];
+      int a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = dp[ob + off[k]];
+        a[k] = ok[k] ? (int)amax[ob + off[k]] : -1;
+      }
+#pragma unroll
+      for (int rw = 0; rw < SX; ++rw) {
+        const int w = w0 + rw;
+        if ((unsigned)w >= (unsigned)g.W) continue;
+        const size_t xc = plane * g.H * g.W + (size_t)g.H * w;
+        float xv[SY], o[SY];
+        if (VEC2) {
+          if ((unsigned)h0 >= (unsigned)g.H) continue;  // H, pt even: both rows in or both out
+          const float2 t = *reinterpret_cast<const float2 *>(x + xc + h0);
+          xv[0] = t.x;
+          xv[SY - 1] = t.y;
+        } else {
+#pragma unroll
+          for (int rh = 0; rh < SY; ++rh) xv[rh] = (unsigned)(h0 + rh) < (unsigned)g.H ? x[xc + h0 + rh] : 0.f;
+        }
+#pragma unroll
+        for (int rh = 0; rh < SY; ++rh) {
+          float dz = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int dh = rh + (1 - i) * SY, dw = rw + (1 - j) * SX;
+              const bool hit = (dh < g.ph) & (dw < g.pw) & (a[i + 2 * j] == dh + g.ph * dw);
+              dz += hit ? d[i + 2 * j] : 0.f;
+            }
+          dz = (gs * (xv[rh] - mu) + bc > 0.f) ? dz : 0.f;
+          o[rh] = (float)(gsd * ((double)dz - c1 - ((double)xv[rh] - (double)mu) * c2));
+        }
+        if (VEC2) {
+          *reinterpret_cast<float2 *>(dx + xc + h0) = float2{o[0], o[SY - 1]};
+          acc += (double)o[0];
+          acc += (double)o[SY - 1];
+        } else {
+#pragma unroll
+          for (int rh = 0; rh < SY; ++rh)
+            if ((unsigned)(h0 + rh) < (unsigned)g.H) {
+              dx[xc + h0 + rh] = o[rh];
+              acc += (double)o[rh];
+            }
+        }
+      }
     }
   }
   if (part2) {
@@ -798,8 +1052,8 @@ static int bnrelupool_forward(const float *x, int H, int W, int C, int N, const 
 static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const float *g,
                                const float *b, const float *moments, int train, int ph, int pw, int sy,
                                int sx, int pt, int pb, int pl, int pr, const unsigned char *amax,
-                               const float *dzdy_pool, float *dx_out, float *dg_out, float *db_out,
-                               float *dxsum_out, hipStream_t st) {
+                               const float *y_pool, const float *dzdy_pool, float *dx_out, float *dg_out,
+                               float *db_out, float *dxsum_out, hipStream_t st) {
   PoolGeo pg;
   int rc = pool_geo(pg, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX);
   if (rc) return rc;
@@ -807,35 +1061,69 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
     return fail(XM_EINVAL, "bnorm+relu+pool: NULL tensor");
   if ((ph + sy - 1) / sy > 2 || (pw + sx - 1) / sx > 2)
     return fail(XM_ENOTSUP, "bnorm+relu+pool backward: more than 2x2 windows cover an element");
-  // blocks: (bx, by) threads own (h, w); grid.y = channel; the N samples are split S ways
+  if (dxsum_out && !dx_out) return fail(XM_EINVAL, "bnorm+relu+pool backward: dxsum needs dx");
+  static const bool no_patch = getenv("XM_NO_POOL_PATCH") != nullptr;
+  static const bool no_pooled = getenv("XM_NO_POOL_POOLED") != nullptr;
+  // element kernels: (bx, by) threads own (h, w); grid.y = channel; the N samples are split S ways
   int bx = pow2_ge(H, 256), by = 256 / bx;
   by = pow2_ge(W, by);
   int gx = (W + by - 1) / by, gz = (H + bx - 1) / bx;
   int S = std::max(1, std::min(N, 4096 / std::max(1, C * gx * gz)));
-  size_t nb = (size_t)gx * gz * S;
+  const size_t nb = (size_t)gx * gz * S;
+  // patch kernel (apply): threads own stride cells
+  const bool patch = !no_patch && dx_out && ((sy == 2 && sx == 2) || (sy == 3 && sx == 2));
+  const int KH = (H + pt + sy - 1) / sy, KW = (W + pl + sx - 1) / sx;
+  int pbx = pow2_ge(KH, 256), pby = pow2_ge(KW, 256 / pbx);
+  int pgx = (KW + pby - 1) / pby, pgz = (KH + pbx - 1) / pbx;
+  static const int ptarget = getenv("XM_PATCH_TARGET") ? atoi(getenv("XM_PATCH_TARGET")) : 16384;
+  int pS = std::max(1, std::min(N, ptarget / std::max(1, C * pgx * pgz)));
+  const size_t pnb = (size_t)pgx * pgz * pS;
+  // pooled-domain sums
+  const bool pooled = !no_pooled && y_pool != nullptr;
+  const int S2 = bn_splits(C, N);
+  const size_t npart = pooled ? (size_t)S2 : nb;
+  const size_t npart2 = patch ? pnb : nb;
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)2 * C * nb, 8) + WsCarver::need((size_t)2 * C, 8) +
-                   WsCarver::need((size_t)C * nb, 8), st);
+  rc = ws.init(WsCarver::need((size_t)2 * C * npart, 8) + WsCarver::need((size_t)2 * C, 8) +
+                   WsCarver::need((size_t)C * npart2, 8), st);
   if (rc) return rc;
-  double *part = ws.take<double>((size_t)2 * C * nb);
+  double *part = ws.take<double>((size_t)2 * C * npart);
   double *sums = ws.take<double>((size_t)2 * C);
-  double *part2 = dxsum_out ? ws.take<double>((size_t)C * nb) : nullptr;
-  if (dxsum_out && !dx_out) return fail(XM_EINVAL, "bnorm+relu+pool backward: dxsum needs dx");
+  double *part2 = dxsum_out ? ws.take<double>((size_t)C * npart2) : nullptr;
   dim3 grid(gx, C, gz * S), block(bx, by);
   FastDiv dsy = make_fastdiv((uint32_t)sy), dsx = make_fastdiv((uint32_t)sx);
-  hipLaunchKernelGGL(bnpool_bwd_partial_kernel, grid, block, 0, st, x, g, b, moments, amax, dzdy_pool,
-                     part, pg, dsy, dsx, C, N, S, gz);
+  if (pooled)
+    hipLaunchKernelGGL(bnpool_bwd_partial_pooled_kernel, dim3(C, S2), dim3(256), 0, st, x, y_pool, dzdy_pool, amax,
+                       g, b, moments, part, pg, make_fastdiv((uint32_t)pg.Ho), C, N, S2);
+  else
+    hipLaunchKernelGGL(bnpool_bwd_partial_kernel, grid, block, 0, st, x, g, b, moments, amax, dzdy_pool,
+                       part, pg, dsy, dsx, C, N, S, gz);
   XM_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, moments, sums,
-                     dg_out, db_out, C, (int)nb);
+                     dg_out, db_out, C, (int)npart);
   XM_LAUNCH_CHECK();
   if (dx_out) {
-    hipLaunchKernelGGL(bnpool_bwd_apply_kernel, grid, block, 0, st, x, g, b, moments, sums, amax,
-                       dzdy_pool, dx_out, part2, pg, dsy, dsx, C, N, S, (double)H * W * N, train);
+    const double m = (double)H * W * N;
+    if (patch) {
+      dim3 pgrid(pgx, C, pgz * pS), pblock(pbx, pby);
+      const bool vec2 = sy == 2 && (H & 1) == 0 && (pt & 1) == 0 && (((uintptr_t)x | (uintptr_t)dx_out) & 7) == 0;
+      if (sy == 2 && vec2)
+        hipLaunchKernelGGL((bnpool_bwd_apply_patch_kernel<2, 2, true>), pgrid, pblock, 0, st, x, g, b, moments, sums,
+                           amax, dzdy_pool, dx_out, part2, pg, KH, KW, C, N, pS, m, train);
+      else if (sy == 2)
+        hipLaunchKernelGGL((bnpool_bwd_apply_patch_kernel<2, 2, false>), pgrid, pblock, 0, st, x, g, b, moments,
+                           sums, amax, dzdy_pool, dx_out, part2, pg, KH, KW, C, N, pS, m, train);
+      else
+        hipLaunchKernelGGL((bnpool_bwd_apply_patch_kernel<3, 2, false>), pgrid, pblock, 0, st, x, g, b, moments,
+                           sums, amax, dzdy_pool, dx_out, part2, pg, KH, KW, C, N, pS, m, train);
+    } else {
+      hipLaunchKernelGGL(bnpool_bwd_apply_kernel, grid, block, 0, st, x, g, b, moments, sums, amax,
+                         dzdy_pool, dx_out, part2, pg, dsy, dsx, C, N, S, m, train);
+    }
     XM_LAUNCH_CHECK();
     if (part2) {
       hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dxsum_out, C,
-                         (int)nb);
+                         (int)npart2);
       XM_LAUNCH_CHECK();
     }
   }
@@ -921,9 +1209,9 @@ int xm_nnbnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, con
 int xm_nnbnorm_relu_pool_backward(const float *x, int H, int W, int C, int N, const float *g,
                                   const float *b, const float *moments, int train, int ph, int pw,
                                   int sy, int sx, int pt, int pb, int pl, int pr,
-                                  const unsigned char *argmax, const float *dzdy_pool, float *dx_out,
-                                  float *dg_out, float *db_out, float *dxsum_out, void *stream) {
-  return bnrelupool_backward(x, H, W, C, N, g, b, moments, train, ph, pw, sy, sx, pt, pb, pl, pr, argmax,
+                                  const unsigned char *argmax, const float *y_pool, const float *dzdy_pool,
+                                  float *dx_out, float *dg_out, float *db_out, float *dxsum_out, void *stream) {
+  return bnrelupool_backward(x, H, W, C, N, g, b, moments, train, ph, pw, sy, sx, pt, pb, pl, pr, argmax, y_pool,
                              dzdy_pool, dx_out, dg_out, db_out, dxsum_out, (hipStream_t)stream);
 }
 }

@@ -929,7 +929,7 @@ class _BnReluPoolStep(_Step):
         dx, dg, db = vl.bnorm_relu_pool_backward(x, g, b, mom if test else mo, am, out.der, pb.poolSize,
                                                  stride=pb.stride, pad=pb.pad, train=not test,
                                                  dg_out=do[0] if do else None, db_out=do[1] if do else None,
-                                                 dxsum_out=bias_der)
+                                                 dxsum_out=bias_der, y_pool=out.value)
         net._set_var_der(r.inputs[0], dx)
         for p, d in zip(r.params, [dg, db, mo]):
             net._set_param_der(p, d)

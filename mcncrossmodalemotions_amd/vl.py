@@ -317,9 +317,10 @@ def bnorm_relu_pool(x, g, b, pool, stride=1, pad=0, epsilon=1e-4, moments=None, 
 
 
 def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad=0, train=True,
-                             dg_out=None, db_out=None, need_dx=True, dxsum_out=None):
+                             dg_out=None, db_out=None, need_dx=True, dxsum_out=None, y_pool=None):
     """Backward of bnorm_relu_pool: returns (dx, dg, db).  dxsum_out (optional, C x 1): receives
-    sum(dx) per channel = the bias derivative of the convolution that produced x."""
+    sum(dx) per channel = the bias derivative of the convolution that produced x.  y_pool (optional): the
+    forward's pooled output -- the per-channel sums then come from the pooled tensors alone."""
     x, g, b, dzdy = _chk(x, "X"), _chk(g, "G"), _chk(b, "B"), _chk(dzdy, "DZDY")
     H, W, Cc, N = _shape4(x)
     ph, pw = _pair(pool, "POOL")
@@ -330,7 +331,8 @@ def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad
     db = db_out if db_out is not None else mat_empty(Cc, 1, device=x.device)
     _lib.check(_L().xm_nnbnorm_relu_pool_backward(
         _ptr(x), H, W, Cc, N, _ptr(g), _ptr(b), _ptr(_chk(moments, "MOMENTS")), 1 if train else 0, ph, pw,
-        sy, sx, pt, pb, pl, pr, C.c_void_p(argmax.data_ptr()), _ptr(dzdy), _ptr(dx), _ptr(dg), _ptr(db),
+        sy, sx, pt, pb, pl, pr, C.c_void_p(argmax.data_ptr()),
+        None if y_pool is None else _ptr(_chk(y_pool, "Y_POOL")), _ptr(dzdy), _ptr(dx), _ptr(dg), _ptr(db),
         _ptr(dxsum_out), _stream()))
     return dx, dg, db
 

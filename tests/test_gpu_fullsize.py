@@ -92,6 +92,11 @@ def test_bnorm_pool_chain_fullsize(gpu):
     assert (dx - dx_ref).abs().max().item() <= 1e-4 * sc
     assert (dg - dg_ref).abs().max().item() <= 1e-4 * max(1.0, dg_ref.abs().max().item())
     assert (db - db_ref).abs().max().item() <= 1e-4 * max(1.0, db_ref.abs().max().item())
+    # the same with the per-channel sums taken from the pooled tensors (what dagnn's fused step passes)
+    dx2, dg2, db2 = vl.bnorm_relu_pool_backward(x, g, b, mof, amf, dz, [3, 3], stride=2, y_pool=yf)
+    assert (dx2 - dx_ref).abs().max().item() <= 1e-4 * sc
+    assert (dg2 - dg_ref).abs().max().item() <= 1e-4 * max(1.0, dg_ref.abs().max().item())
+    assert (db2 - db_ref).abs().max().item() <= 1e-4 * max(1.0, db_ref.abs().max().item())
     # pooling bounds and routing conservation: every output gradient lands on exactly one input
     assert (yp >= 0).all() and abs(dot(d1, torch.ones_like(d1)) - dot(dz, torch.ones_like(dz))) < 1e-2
     # train-mode BN backward output sums to zero per channel (batch statistics absorb the mean)

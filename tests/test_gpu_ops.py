@@ -247,13 +247,16 @@ def test_bnorm(gpu, shape, relu):
 @pytest.mark.parametrize("case", [(13, 11, 5, 3, (3, 3), (2, 2), (0, 0, 0, 0)), (9, 8, 6, 2, (5, 3), (3, 2), (0, 0, 0, 0)),
                                   (12, 12, 4, 2, (3, 3), (2, 2), (0, 1, 0, 1)), (10, 9, 3, 2, (2, 2), (1, 1), (1, 0, 1, 0))])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_bnorm_relu_pool(gpu, case, train):
+@pytest.mark.parametrize("pooled", [False, True])
+def test_fused_bnorm_relu_pool(gpu, case, train, pooled):
     """extension op == vl_nnpool(vl_nnrelu(vl_nnbnorm(x))) forward and backward (oracle composition)."""
     from mcncrossmodalemotions_amd import vl
     H, W, C, N, pool, stride, pad = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + int(train))
     x = O.F(rng.standard_normal((H, W, C, N)) * 1.5 + 0.3)
     g, b = O.F(rng.uniform(0.5, 1.5, C) * rng.choice([-1, 1], C)), rnd(rng, C)  # negative gains too
+    g[0] = 1e-4 * np.sign(g[0])       # |b| > 100 |g|: the pooled-domain sums must gather x for this channel
+    b[0] = 0.5
     mom = None if train else O.F(np.stack([rng.standard_normal(C) * 0.3, rng.uniform(0.5, 1.5, C)], 1))
     yb, mref = O.vl_nnbnorm(x, g, b, moments=mom, acc64=True)
     yr = np.maximum(yb, 0)
@@ -269,7 +272,7 @@ def test_fused_bnorm_relu_pool(gpu, case, train):
     close(vl.to_numpy(mo), mref, what="fused moments")
     dxs = vl.mat_zeros(C, 1)
     dx, dg, db = vl.bnorm_relu_pool_backward(xd, gd, bd, mo, am, vl.from_numpy(dz), pool, stride=stride,
-                                             pad=pad, train=train, dxsum_out=dxs)
+                                             pad=pad, train=train, dxsum_out=dxs, y_pool=y if pooled else None)
     close(vl.to_numpy(dx), dx_ref, what="fused dx")
     # dxsum = dzdb of a convolution that produced x (sum of dx over pixels and samples)
     close(vl.to_numpy(dxs).ravel(), dx_ref.astype(np.float64).sum((0, 1, 3)), 2e-4, what="fused dxsum")
