@@ -29,25 +29,30 @@ __global__ void pad_filter_kernel(const float *__restrict__ f, float *__restrict
 // with u(iu) = u0 + iu*ustep (the taps whose u*dil == a mod sy), zero padded to lda columns.
 // A (c <-> k) transpose of T-float elements through LDS: reads are contiguous runs of TS*T floats
 // per output channel, writes contiguous runs of TS*nT floats per input channel.
+// index arithmetic through magic-number division: with runtime `/` and `%` the kernel was bound by the integer
+// division sequences (5 per element), 20 us per launch instead of the few us the bytes take
+struct PrepDiv {
+  FastDiv tsT, T, tsNT, nT, nU, padc, rows;
+};
 __global__ void __launch_bounds__(256)
 prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int FH, int FW, int FC,
                          int Kg, int u0, int ustep, int nU, int v0, int vstep, int nV, int lda,
-                         int TS, int fold) {
+                         int TS, int fold, PrepDiv dv) {
   extern __shared__ float tile[];  // [kl][cl][t], kl pitch TS*T + 1
   const int T = FH * FW, nT = nU * nV;
   const int c0 = blockIdx.x * TS, k0 = blockIdx.y * TS;
   const int pitch = TS * T + 1;
   for (int i = threadIdx.x; i < TS * TS * T; i += 256) {
-    int kl = i / (TS * T), rem = i - kl * (TS * T);
-    int cl = rem / T;
+    int kl = (int)xm_div((uint32_t)i, dv.tsT), rem = i - kl * (TS * T);
+    int cl = (int)xm_div((uint32_t)rem, dv.T);
     int c = c0 + cl, k = k0 + kl;
     tile[kl * pitch + rem] = (c < FC && k < Kg) ? f[(size_t)rem + (size_t)T * (c0 + (size_t)FC * k)] : 0.f;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TS * TS * nT; i += 256) {
-    int cl = i / (TS * nT), rem = i - cl * (TS * nT);
-    int kl = rem / nT, tt = rem - kl * nT;
-    int iu = tt % nU, iv = tt / nU;
+    int cl = (int)xm_div((uint32_t)i, dv.tsNT), rem = i - cl * (TS * nT);
+    int kl = (int)xm_div((uint32_t)rem, dv.nT), tt = rem - kl * nT;
+    int iv = (int)xm_div((uint32_t)tt, dv.nU), iu = tt - iv * nU;
     int t = (u0 + iu * ustep) + FH * (v0 + iv * vstep);
     int c = c0 + cl, k = k0 + kl;
     if (c < FC && k < Kg) {
@@ -61,8 +66,8 @@ prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int
     const int used = (fold ? nV : nT) * Kg, rows = fold ? nU : 1;
     int padc = lda - used;
     for (int i = threadIdx.x; i < TS * rows * padc; i += 256) {
-      int rl = i / padc, rr = used + i % padc;
-      int cl = rl / rows, ul = rl % rows;
+      int rl = (int)xm_div((uint32_t)i, dv.padc), rr = used + (i - rl * padc);
+      int cl = (int)xm_div((uint32_t)rl, dv.rows), ul = rl - cl * rows;
       if (c0 + cl < FC) o[((size_t)(c0 + cl) * rows + ul) * lda + rr] = 0.f;
     }
   }
@@ -123,20 +128,21 @@ static void launch_reduce_splits(const float *part, float *out, size_t total, in
 // fixed-order finalize (deterministic)
 __global__ void __launch_bounds__(256)
 bias_grad_partial_kernel(const float *__restrict__ dy, double *__restrict__ part, int HW, int K, int N,
-                         int S) {
+                         int S, FastDiv divRun) {
   int k = blockIdx.x, sp = blockIdx.y;
   double s = 0.0;
   const bool vec = (HW & 3) == 0;
-  for (int n = sp; n < N; n += S) {
-    const float *p = dy + (size_t)HW * (k + (size_t)K * n);
+  // flat (sample, position) index: FC-shaped layers (H*W = 8) keep all lanes busy
+  const int nper = (N - sp + S - 1) / S;
+  const int run = vec ? HW >> 2 : HW;
+  for (int j = threadIdx.x; j < nper * run; j += 256) {
+    const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * run;
+    const float *p = dy + (size_t)HW * (k + (size_t)K * (sp + nn * S));
     if (vec) {
-      const float4 *p4 = reinterpret_cast<const float4 *>(p);
-      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-        float4 v = p4[i];
-        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-      }
+      float4 v = reinterpret_cast<const float4 *>(p)[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
     } else {
-      for (int i = threadIdx.x; i < HW; i += 256) s += (double)p[i];
+      s += (double)p[i];
     }
   }
   __shared__ double red[4];
@@ -146,13 +152,14 @@ bias_grad_partial_kernel(const float *__restrict__ dy, double *__restrict__ part
   if (threadIdx.x == 0) part[(size_t)k * S + sp] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ db, int K,
-                                          int S) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ db, int K, int S) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per channel
   if (k >= K) return;
   double s = 0.0;
-  for (int i = 0; i < S; ++i) s += part[(size_t)k * S + i];
-  db[k] = (float)s;
+  for (int i = lane; i < S; i += 64) s += part[(size_t)k * S + i];
+  s = xm_wave_sum_d(s);
+  if (lane == 0) db[k] = (float)s;
 }
 
 // ---- tile configuration ---------------------------------------------------------------------
@@ -874,9 +881,16 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         const int T = g.FH * g.FW;
         const int TS = T <= 14 ? 32 : (T <= 56 ? 16 : 8);
         size_t lds = sizeof(float) * (size_t)TS * (TS * T + 1);
+        const int nT = c.nU * c.nV, used = (foldH ? c.nV : nT) * g.Kg;
+        PrepDiv pd;
+        pd.tsT = make_fastdiv((uint32_t)(TS * T)), pd.T = make_fastdiv((uint32_t)T);
+        pd.tsNT = make_fastdiv((uint32_t)std::max(1, TS * nT)), pd.nT = make_fastdiv((uint32_t)std::max(1, nT));
+        pd.nU = make_fastdiv((uint32_t)std::max(1, c.nU));
+        pd.padc = make_fastdiv((uint32_t)std::max(1, c.Rp - used));
+        pd.rows = make_fastdiv((uint32_t)(foldH ? std::max(1, c.nU) : 1));
         hipLaunchKernelGGL(prep_dgrad_filter_kernel, dim3((g.FC + TS - 1) / TS, (g.Kg + TS - 1) / TS),
                            dim3(256), lds, st, f + (size_t)g.R * g.Kg * grp, Ag, g.FH, g.FW, g.FC, g.Kg,
-                           c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS, foldH ? 1 : 0);
+                           c.u0, c.ustep, c.nU, c.v0, c.vstep, c.nV, c.Rp, TS, foldH ? 1 : 0, pd);
         XM_LAUNCH_CHECK();
       }
       if (prepare_only) continue;
@@ -1255,10 +1269,11 @@ int xm_nnconv_backward_accum(const float *x, int H, int W, int C, int N, const f
     rc = ws.init(WsCarver::need((size_t)K * S, 8), st);
     if (rc) return rc;
     double *part = ws.take<double>((size_t)K * S);
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(K, S), dim3(256), 0, st, dzdy, part, g.Ho * g.Wo,
-                       K, N, S);
+    const int HWo = g.Ho * g.Wo;
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(K, S), dim3(256), 0, st, dzdy, part, HWo, K, N, S,
+                       make_fastdiv((uint32_t)((HWo & 3) == 0 ? HWo >> 2 : HWo)));
     XM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part, db_out,
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((K + 3) / 4), dim3(256), 0, st, part, db_out,
                        K, S);
     XM_LAUNCH_CHECK();
   }

@@ -26,29 +26,32 @@ __device__ __forceinline__ void block_reduce2(double &a, double &b, double *red 
   __syncthreads();
 }
 
+// The (sample, position) pairs a block owns are walked as ONE flat index (magic division by the run length):
+// the FC-shaped layers have H*W = 8, where a loop over positions inside a loop over samples kept 2 of 256
+// threads busy and cost 30 us per call.
 __global__ void __launch_bounds__(256)
 bn_stats_partial_kernel(const float *__restrict__ x, double *__restrict__ part, int HW, int C, int N,
-                        int S) {
+                        int S, FastDiv divRun) {
   const int c = blockIdx.x, s = blockIdx.y;
   const float shift = x[(size_t)HW * c];
   double a = 0.0, b = 0.0;
   const bool vec = (HW & 3) == 0;
-  for (int n = s; n < N; n += S) {
-    const float *p = x + (size_t)HW * (c + (size_t)C * n);
-    if (vec) {
-      const float4 *p4 = reinterpret_cast<const float4 *>(p);
-      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-        float4 v = p4[i];
-        double d0 = (double)v.x - shift, d1 = (double)v.y - shift, d2 = (double)v.z - shift, d3 = (double)v.w - shift;
-        a += (d0 + d1) + (d2 + d3);
-        b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-    } else {
-      for (int i = threadIdx.x; i < HW; i += 256) {
-        double d = (double)p[i] - shift;
-        a += d;
-        b += d * d;
-      }
+  const int nper = (N - s + S - 1) / S;  // samples s, s + S, ...
+  if (vec) {
+    const int run = HW >> 2;
+    for (int j = threadIdx.x; j < nper * run; j += 256) {
+      const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * run;
+      const float4 v = reinterpret_cast<const float4 *>(x + (size_t)HW * (c + (size_t)C * (s + nn * S)))[i];
+      double d0 = (double)v.x - shift, d1 = (double)v.y - shift, d2 = (double)v.z - shift, d3 = (double)v.w - shift;
+      a += (d0 + d1) + (d2 + d3);
+      b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  } else {
+    for (int j = threadIdx.x; j < nper * HW; j += 256) {
+      const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * HW;
+      double d = (double)x[(size_t)HW * (c + (size_t)C * (s + nn * S)) + i] - shift;
+      a += d;
+      b += d * d;
     }
   }
   __shared__ double red[8];
@@ -60,16 +63,21 @@ bn_stats_partial_kernel(const float *__restrict__ x, double *__restrict__ part, 
 }
 
 // moments(c) = [mean, sqrt(var + eps)]
-__global__ void bn_finalize_kernel(const float *__restrict__ x, const double *__restrict__ part,
-                                   float *__restrict__ mom, int HW, int C, int S, double m,
-                                   float eps) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// (finalize kernels: one WAVE per channel -- lane l adds partials l, l + 64, ..., then a shuffle reduction; a
+// thread per channel walking its S partials one dependent load at a time cost 5-10 us per call)
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float *__restrict__ x, const double *__restrict__ part, float *__restrict__ mom, int HW,
+                   int C, int S, double m, float eps) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
-  for (int s = 0; s < S; ++s) {
+  for (int s = lane; s < S; s += 64) {
     a += part[2 * ((size_t)c * S + s)];
     b += part[2 * ((size_t)c * S + s) + 1];
   }
+  a = xm_wave_sum_d(a);
+  b = xm_wave_sum_d(b);
+  if (lane) return;
   double shift = x[(size_t)HW * c];
   double d = a / m;
   double var = b / m - d * d;
@@ -119,37 +127,37 @@ bn_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const float 
 __global__ void __launch_bounds__(256)
 bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                       const float *__restrict__ yfwd, const float *__restrict__ mom,
-                      double *__restrict__ part, int HW, int C, int N, int S) {
+                      double *__restrict__ part, int HW, int C, int N, int S, FastDiv divRun) {
   const int c = blockIdx.x, s = blockIdx.y;
   const double mu = mom[c];
   double a = 0.0, b = 0.0;
   const bool vec = (HW & 3) == 0;
-  for (int n = s; n < N; n += S) {
-    size_t off = (size_t)HW * (c + (size_t)C * n);
-    if (vec) {
-      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
-      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
-      const float4 *y4 = yfwd ? reinterpret_cast<const float4 *>(yfwd + off) : nullptr;
-      for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-        float4 xv = x4[i], dv = d4[i];
-        if (y4) {
-          float4 yv = y4[i];
-          dv.x = yv.x > 0.f ? dv.x : 0.f;
-          dv.y = yv.y > 0.f ? dv.y : 0.f;
-          dv.z = yv.z > 0.f ? dv.z : 0.f;
-          dv.w = yv.w > 0.f ? dv.w : 0.f;
-        }
-        a += ((double)dv.x + (double)dv.y) + ((double)dv.z + (double)dv.w);
-        b += ((double)dv.x * ((double)xv.x - mu) + (double)dv.y * ((double)xv.y - mu)) +
-             ((double)dv.z * ((double)xv.z - mu) + (double)dv.w * ((double)xv.w - mu));
+  const int nper = (N - s + S - 1) / S;
+  if (vec) {
+    const int run = HW >> 2;
+    for (int j = threadIdx.x; j < nper * run; j += 256) {
+      const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * run;
+      const size_t off = (size_t)HW * (c + (size_t)C * (s + nn * S));
+      float4 xv = reinterpret_cast<const float4 *>(x + off)[i], dv = reinterpret_cast<const float4 *>(dy + off)[i];
+      if (yfwd) {
+        float4 yv = reinterpret_cast<const float4 *>(yfwd + off)[i];
+        dv.x = yv.x > 0.f ? dv.x : 0.f;
+        dv.y = yv.y > 0.f ? dv.y : 0.f;
+        dv.z = yv.z > 0.f ? dv.z : 0.f;
+        dv.w = yv.w > 0.f ? dv.w : 0.f;
       }
-    } else {
-      for (int i = threadIdx.x; i < HW; i += 256) {
-        float d = dy[off + i];
-        if (yfwd && !(yfwd[off + i] > 0.f)) d = 0.f;
-        a += (double)d;
-        b += (double)d * ((double)x[off + i] - mu);
-      }
+      a += ((double)dv.x + (double)dv.y) + ((double)dv.z + (double)dv.w);
+      b += ((double)dv.x * ((double)xv.x - mu) + (double)dv.y * ((double)xv.y - mu)) +
+           ((double)dv.z * ((double)xv.z - mu) + (double)dv.w * ((double)xv.w - mu));
+    }
+  } else {
+    for (int j = threadIdx.x; j < nper * HW; j += 256) {
+      const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * HW;
+      const size_t off = (size_t)HW * (c + (size_t)C * (s + nn * S)) + i;
+      float d = dy[off];
+      if (yfwd && !(yfwd[off] > 0.f)) d = 0.f;
+      a += (double)d;
+      b += (double)d * ((double)x[off] - mu);
     }
   }
   __shared__ double red[8];
@@ -161,16 +169,19 @@ bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
 }
 
 // sums(c) = [sum dy, sum dy*(x-mu)];  dg = sums1 / sigma, db = sums0
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ part, const float *__restrict__ mom,
-                                       double *__restrict__ sums, float *__restrict__ dg,
-                                       float *__restrict__ db, int C, int S) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const double *__restrict__ part, const float *__restrict__ mom, double *__restrict__ sums,
+                       float *__restrict__ dg, float *__restrict__ db, int C, int S) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
-  for (int s = 0; s < S; ++s) {
+  for (int s = lane; s < S; s += 64) {
     a += part[2 * ((size_t)c * S + s)];
     b += part[2 * ((size_t)c * S + s) + 1];
   }
+  a = xm_wave_sum_d(a);
+  b = xm_wave_sum_d(b);
+  if (lane) return;
   sums[c] = a;
   sums[C + c] = b;
   if (dg) dg[c] = (float)(b / (double)mom[C + c]);
@@ -220,6 +231,8 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
   }
 }
 
+// run length of one sample inside the flat (sample, position) index of the reduction kernels
+static FastDiv bn_run_div(int HW) { return make_fastdiv((uint32_t)((HW & 3) == 0 ? HW >> 2 : HW)); }
 static int bn_splits(int C, int N) {
   int s = 2048 / (C > 0 ? C : 1);
   if (s < 1) s = 1;
@@ -255,9 +268,9 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
     if (rc) return rc;
     double *part = ws.take<double>((size_t)2 * C * S);
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S, bn_run_div(HW));
     XM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, part, momw, HW,
                        C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
@@ -295,9 +308,9 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
   const float *mom = moments_in;
   if (!moments_in) {
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S, bn_run_div(HW));
     XM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, momw, HW,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, part, momw, HW,
                        C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
@@ -305,9 +318,9 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
     XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
   }
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, x, dzdy, yfwd, mom, part, HW,
-                     C, N, S);
+                     C, N, S, bn_run_div(HW));
   XM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, mom, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, mom, sums,
                      dg_out, db_out, C, S);
   XM_LAUNCH_CHECK();
   if (dx_out) {
@@ -983,12 +996,14 @@ bnpool_bwd_apply_patch_kernel(const float *__restrict__ x, const float *__restri
   }
 }
 
-__global__ void sum_partials_kernel(const double *__restrict__ part, float *__restrict__ out, int C, int S) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(const double *__restrict__ part, float *__restrict__ out, int C, int S) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0.0;
-  for (int i = 0; i < S; ++i) s += part[(size_t)c * S + i];
-  out[c] = (float)s;
+  for (int i = lane; i < S; i += 64) s += part[(size_t)c * S + i];
+  s = xm_wave_sum_d(s);
+  if (lane == 0) out[c] = (float)s;
 }
 
 static int pool_backward(const float *x, const unsigned char *amax, int H, int W, int C, int N, int ph,
@@ -1037,9 +1052,9 @@ static int bnrelupool_forward(const float *x, int H, int W, int C, int N, const 
     rc = ws.init(WsCarver::need((size_t)2 * C * S, 8), st);
     if (rc) return rc;
     double *part = ws.take<double>((size_t)2 * C * S);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S, bn_run_div(HW));
     XM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, part, moments_out,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, part, moments_out,
                        HW, C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
   } else if (moments_out != moments_in) {
@@ -1099,7 +1114,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
     hipLaunchKernelGGL(bnpool_bwd_partial_kernel, grid, block, 0, st, x, g, b, moments, amax, dzdy_pool,
                        part, pg, dsy, dsx, C, N, S, gz);
   XM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, moments, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, moments, sums,
                      dg_out, db_out, C, (int)npart);
   XM_LAUNCH_CHECK();
   if (dx_out) {
@@ -1122,7 +1137,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
     }
     XM_LAUNCH_CHECK();
     if (part2) {
-      hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part2, dxsum_out, C,
+      hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part2, dxsum_out, C,
                          (int)npart2);
       XM_LAUNCH_CHECK();
     }
