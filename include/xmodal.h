@@ -44,7 +44,7 @@ enum { XM_LOSS_SOFTMAXLOG = 0, XM_LOSS_CLASSERROR = 1 };
 enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 
 /* fused-epilogue flags for xm_nnconv_forward_fused / xm_nnbnorm_forward_fused */
-enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2 };
+enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 int xm_version(void);
 const char *xm_last_error(void);
@@ -83,7 +83,8 @@ int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f
                       int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
                       int pl, int pr, int dy, int dx, void *stream);
 /* Extension (not a MatConvNet signature): same convolution with a fused epilogue
- *   y = act( (conv + b) .* scale_k + shift_k + residual ),  scale/shift/residual may be NULL.
+ *   y = act( (conv + b) .* scale_k + shift_k + residual ),  scale/shift/residual may be NULL;
+ *   act = vl_nnrelu (XM_FUSE_RELU) or vl_nnsigmoid (XM_FUSE_SIGMOID: the SE gate fc2 -> sigmoid).
  * Used to fold test-mode vl_nnbnorm, dagnn.Sum and vl_nnrelu of the frozen teacher into the
  * producing convolution (fetch_emovoxceleb_imdb.m:107 sets dag.mode = 'test'). */
 int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const float *f, int FH,

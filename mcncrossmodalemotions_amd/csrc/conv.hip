@@ -591,6 +591,127 @@ static const int4 *fwd_taps(const Geo &g, int count) {
   return (const int4 *)cached_device_table(t.data(), t.size() * sizeof(int4));
 }
 
+// ---- skinny fully-connected layers ------------------------------------------------------------
+// vl_nnconv with a 1 x 1 filter over few output values: the SE gates (1 x 1 x C x N), the teacher's classifier
+// (2048 -> 8), the student's fc8.  y[m, p] = act(b[m] + sum_k F[k + K m] X[p, k]).  An MFMA tile would be > 90 %
+// padding and a single block would walk K alone (31 us for 2048 -> 8 at 32 samples).  Here one BLOCK owns one output
+// row m and a chunk of <= 32 pixels: its 1-4 waves split K (VEC: 4 consecutive k per lane, 16-byte loads of the
+// filter row and of every pixel's channel run -- needs H*W == 1; otherwise one k per lane), 32 accumulators per
+// lane, a transposing butterfly (63 shuffles instead of 32 x 6) leaves the sum of pixel j in lanes 2j, 2j + 1,
+// and the waves' partials are added in wave order through LDS.  ACT: 0 none, 1 relu, 2 sigmoid.
+template <int ACT, bool VEC>
+__global__ void __launch_bounds__(256)
+fc_skinny_kernel(const float *__restrict__ x, const float *__restrict__ f, const float *__restrict__ b,
+                 float *__restrict__ y, int K, int M, int HW, int NP, int chunks, FastDiv divChunks, FastDiv divHW) {
+  __shared__ float red[4][32];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int m = (int)xm_div(blockIdx.x, divChunks);
+  const int p0 = ((int)blockIdx.x - m * chunks) * 32;
+  int xb[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int p = min(p0 + j, NP - 1);
+    const int n = (int)xm_div((uint32_t)p, divHW);
+    xb[j] = (p - n * HW) + HW * K * n;
+  }
+  float acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+  const float *fr = f + (size_t)K * m;
+  if (VEC) {
+    for (int k = (wv * 64 + lane) * 4; k < K; k += nw * 256) {
+      const float4 w = *reinterpret_cast<const float4 *>(fr + k);
+      // all loads of a half first, then the arithmetic: left alone, the scheduler pairs every load with its use
+      // (two loads in flight, 32 serial round trips -- 20 us per call)
+#pragma unroll
+      for (int jh = 0; jh < 32; jh += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4 *>(x + xb[jh + j] + k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(v[j]));  // pins the uses behind all 16 loads
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          acc[jh + j] = fmaf(w.w, v[j].w, fmaf(w.z, v[j].z, fmaf(w.y, v[j].y, fmaf(w.x, v[j].x, acc[jh + j]))));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    for (int k = wv * 64 + lane; k < K; k += nw * 64) {
+      const float w = fr[k];
+      const float *xk = x + (size_t)HW * k;
+      float v[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = xk[xb[j]];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+      for (int j = 0; j < 32; ++j) acc[j] = fmaf(w, v[j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // stage (o, h): lanes with bit o set keep the upper h values, the others the lower h, and add the partner's
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int o = 32 >> s, h = 16 >> s;
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      // (selecting which ELEMENT to send would halve the shuffles, but the compiler turns `up ? acc[i + h] : acc[i]`
+      // into a runtime-indexed register array: 5000 compare / select instructions)
+      const float lo = acc[i] + __shfl_xor(acc[i], o, 64);
+      const float hi = acc[i + h] + __shfl_xor(acc[i + h], o, 64);
+      acc[i] = up ? hi : lo;
+    }
+  }
+  float v = acc[0] + __shfl_xor(acc[0], 1, 64);
+  if ((lane & 1) == 0) red[wv][lane >> 1] = v;
+  __syncthreads();
+  const int p = p0 + (int)threadIdx.x;
+  if (threadIdx.x < 32 && p < NP) {
+    v = red[0][threadIdx.x];
+    for (int w = 1; w < nw; ++w) v += red[w][threadIdx.x];
+    if (b) v += b[m];
+    if (ACT == 1) v = fmaxf(v, 0.f);
+    if (ACT == 2) v = 1.f / (1.f + expf(-v));
+    const int n = (int)xm_div((uint32_t)p, divHW);
+    y[(p - n * HW) + (size_t)HW * (m + (size_t)M * n)] = v;
+  }
+}
+static bool fc_skinny_ok(const Geo &g) {
+  static const bool off = getenv("XM_NO_SKINNY") != nullptr;
+  if (off || g.FH != 1 || g.FW != 1 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.G != 1) return false;
+  if (g.pt | g.pb | g.pl | g.pr) return false;
+  const long long NP = (long long)g.Ho * g.Wo * g.N;
+  if (!(g.K <= 16 || NP <= 128)) return false;
+  return (long long)g.K * ((NP + 31) / 32) <= 65535 && (long long)g.H * g.W * g.C * g.N < (1ll << 31);
+}
+static int fc_skinny_forward(const float *x, const float *f, const float *b, float *y, const Geo &g, int act,
+                             hipStream_t st) {
+  const int HW = g.H * g.W, NP = HW * g.N, chunks = (NP + 31) / 32;
+  const bool vec = HW == 1 && (g.C & 3) == 0 && (((uintptr_t)x | (uintptr_t)f) & 15) == 0;
+  const int units = vec ? g.C / 4 : g.C;   // k positions handed out per lane step
+  const int nw = std::max(1, std::min(4, (units + 63) / 64));
+  dim3 grid(g.K * chunks), block(64 * nw);
+  FastDiv dc = make_fastdiv((uint32_t)chunks), dh = make_fastdiv((uint32_t)HW);
+#define XM_FC_LAUNCH(A, V) \
+  hipLaunchKernelGGL((fc_skinny_kernel<A, V>), grid, block, 0, st, x, f, b, y, g.C, g.K, HW, NP, chunks, dc, dh)
+  if (vec) {
+    if (act == 2) XM_FC_LAUNCH(2, true);
+    else if (act == 1) XM_FC_LAUNCH(1, true);
+    else XM_FC_LAUNCH(0, true);
+  } else {
+    if (act == 2) XM_FC_LAUNCH(2, false);
+    else if (act == 1) XM_FC_LAUNCH(1, false);
+    else XM_FC_LAUNCH(0, false);
+  }
+#undef XM_FC_LAUNCH
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st) {
@@ -1220,8 +1341,14 @@ int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const fl
   if (!x || !f || !y) return fail(XM_EINVAL, "vl_nnconv: NULL tensor");
   if ((scale == nullptr) != (shift == nullptr))
     return fail(XM_EINVAL, "vl_nnconv(fused): scale and shift must be given together");
-  return conv_forward(x, f, b, y, g, scale, shift, residual, (flags & XM_FUSE_RELU) ? 1 : 0,
-                      (hipStream_t)stream);
+  if ((flags & XM_FUSE_RELU) && (flags & XM_FUSE_SIGMOID))
+    return fail(XM_EINVAL, "vl_nnconv(fused): relu and sigmoid are exclusive");
+  hipStream_t st = (hipStream_t)stream;
+  if (!scale && !residual && fc_skinny_ok(g))
+    return fc_skinny_forward(x, f, b, y, g, (flags & XM_FUSE_SIGMOID) ? 2 : ((flags & XM_FUSE_RELU) ? 1 : 0), st);
+  rc = conv_forward(x, f, b, y, g, scale, shift, residual, (flags & XM_FUSE_RELU) ? 1 : 0, st);
+  if (rc || !(flags & XM_FUSE_SIGMOID)) return rc;
+  return xm_nnsigmoid(y, (size_t)g.Ho * g.Wo * g.K * g.N, nullptr, y, stream);  // in place (elementwise)
 }
 
 int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -937,6 +937,26 @@ class _BnReluPoolStep(_Step):
             out.der = None
 
 
+class _ConvActStep(_Step):
+    """forward-only plans: Conv -> ReLU / Sigmoid with the activation in the producing kernel (the SE gate's
+    fc1 -> relu and fc2 -> sigmoid: four launches become two skinny-FC kernels, see xm_nnconv_forward_fused)."""
+
+    def __init__(self, conv_rec, act_rec):
+        super().__init__(conv_rec)
+        self.act_rec = act_rec
+
+    def forward(self, net):
+        r, blk = self.rec, self.rec.block
+        par = self._params(net)
+        sig = isinstance(self.act_rec.block, Sigmoid)
+        y = vl.vl_nnconv(net.vars[r.inputs[0]].value, par[0], par[1] if blk.hasBias else None, stride=blk.stride,
+                         pad=blk.pad, dilate=blk.dilate, relu=not sig, sigmoid=sig)
+        net.vars[self.act_rec.outputs[0]].value = y
+
+    def backward(self, net):
+        raise RuntimeError("dagnn: a forward-only plan was asked for derivatives")
+
+
 class _ConvFoldStep(_Step):
     """test mode only: Conv -> BatchNorm [-> Sum(shortcut)] [-> ReLU] in the conv epilogue.
     scale_k = g_k / sigma_k, shift_k = b_k - mu_k * scale_k  (frozen moments)."""
@@ -1022,6 +1042,11 @@ def build_plan(net, training):
                     rl = None
                 steps.append(_ConvFoldStep(r, bn, sm, rl, out))
                 skip.update(id(q) for q in (bn, sm, rl) if q is not None)
+                continue
+            act = sole_consumer(r.outputs[0], (ReLU, Sigmoid))
+            if act is not None and (isinstance(act.block, Sigmoid) or act.block.leak == 0.0):
+                steps.append(_ConvActStep(r, act))
+                skip.add(id(act))
                 continue
         if isinstance(r.block, (Sum, Axpy)) and (not isinstance(r.block, Sum) or len(r.inputs) == 2):
             rl = sole_consumer(r.outputs[0], ReLU)

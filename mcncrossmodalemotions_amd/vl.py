@@ -135,10 +135,10 @@ def out_size(n, pa, pb, f, d, s):
 
 def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
               no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
-              relu=False, df_out=None, db_out=None, dx_accum=None):
+              relu=False, df_out=None, db_out=None, dx_accum=None, sigmoid=False):
     """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
 
-    `scale/shift/residual/relu` select the fused forward epilogue (extension; see xmodal.h);
+    `scale/shift/residual/relu/sigmoid` select the fused forward epilogue (extension; see xmodal.h);
     `dx_accum` (backward, extension): DX = dgrad + dx_accum in the dgrad epilogue."""
     x, f = _chk(x, "X"), _chk(f, "F")
     H, W, Cc, N = _shape4(x)
@@ -156,7 +156,7 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     Wo = L.xm_out_size(W, pl, pr, FW, dx, sx)
     if dzdy is None:
         y = mat_empty(max(Ho, 0), max(Wo, 0), K, N, device=x.device)
-        fused = scale is not None or residual is not None or relu
+        fused = scale is not None or residual is not None or relu or sigmoid
         if fused:
             if residual is not None:
                 _chk(residual, "RESIDUAL")
@@ -164,7 +164,7 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
                     raise ValueError("vl_nnconv: residual shape mismatch")
             _lib.check(L.xm_nnconv_forward_fused(
                 _ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb), _ptr(y), sy, sx, pt, pb,
-                pl, pr, dy, dx, _ptr(scale), _ptr(shift), _ptr(residual), 1 if relu else 0,
+                pl, pr, dy, dx, _ptr(scale), _ptr(shift), _ptr(residual), (1 if relu else 0) | (4 if sigmoid else 0),
                 _stream()))
         else:
             _lib.check(L.xm_nnconv_forward(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb),

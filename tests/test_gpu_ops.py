@@ -67,6 +67,42 @@ def test_conv_forward_backward(gpu, case):
     close(vl.to_numpy(dx2), dx_ref + acc, what="conv dx + accum")
 
 
+# (H, W, C, N, K, activation): 1x1 filters over few output values -> fc_skinny_kernel (SE gates, classifier, fc8)
+SKINNY_CASES = [(1, 1, 2048, 32, 128, "relu"), (1, 1, 128, 32, 2048, "sigmoid"), (1, 1, 2048, 32, 8, None),
+                (1, 8, 1024, 32, 8, None), (1, 1, 77, 5, 3, "relu"), (2, 3, 40, 7, 5, "sigmoid"),
+                (1, 1, 16, 128, 256, "sigmoid"), (1, 1, 300, 33, 9, None)]
+
+
+@pytest.mark.parametrize("case", SKINNY_CASES)
+def test_conv_skinny_fc(gpu, case):
+    """the skinny fully-connected path of vl_nnconv (+ fused vl_nnrelu / vl_nnsigmoid) against the oracle"""
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N, K, act = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x, f, b = rnd(rng, H, W, C, N), O.F(rng.standard_normal((1, 1, C, K)) / np.sqrt(C)), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, acc64=True)
+    if act == "relu":
+        y_ref = O.vl_nnrelu(y_ref)
+    elif act == "sigmoid":
+        y_ref = O.vl_nnsigmoid(y_ref)
+    y = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), relu=act == "relu",
+                     sigmoid=act == "sigmoid")
+    close(vl.to_numpy(y), y_ref, 2e-6, what="skinny fc %s" % (act,))
+    # no bias
+    y0 = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), None)
+    close(vl.to_numpy(y0), O.vl_nnconv(x, f, None, acc64=True), 2e-6, what="skinny fc, no bias")
+
+
+def test_conv_fused_sigmoid_general_path(gpu):
+    """XM_FUSE_SIGMOID on a geometry the skinny kernel does not take (3x3): convolution, then sigmoid in place"""
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(77)
+    x, f, b = rnd(rng, 9, 7, 6, 3), rnd(rng, 3, 3, 6, 20), rnd(rng, 20)
+    y_ref = O.vl_nnsigmoid(O.vl_nnconv(x, f, b, pad=1, acc64=True))
+    y = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(20, 1)), pad=1, sigmoid=True)
+    close(vl.to_numpy(y), y_ref, 1e-5, what="conv + sigmoid")
+
+
 # enough pixels per stride-parity class for the merged single-launch dgrad (conv_gemm_multi_kernel)
 MERGED_DGRAD_CASES = [
     (200, 200, 8, 4, 3, 3, 8, 8, (2, 2), (1, 1, 1, 1), (1, 1)),     # 4 classes, 3x3
