@@ -341,9 +341,14 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   }
   XM_LAUNCH_CHECK();
   if (splits > 1) {
-    size_t n = (size_t)a.M * a.NP;
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       a, splits);
+    const bool vec = a.vecStore && (a.NP & 3) == 0 && (a.NPs & 3) == 0 && ((uintptr_t)a.slab & 15) == 0;
+    const size_t n = (size_t)a.M * (vec ? a.NP / 4 : a.NP);
+    if (vec)
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         a, splits, make_fastdiv((uint32_t)(a.NP / 4)));
+    else
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         a, splits, make_fastdiv((uint32_t)a.NP));
     XM_LAUNCH_CHECK();
   }
   return XM_OK;

@@ -817,15 +817,17 @@ conv_gemm_multi_kernel(const ConvGemmMulti m) {
   conv_gemm_body<TM, TN, WGM, WGN, 1>(a);
 }
 
-// combine split-K slabs in split order and apply the fused epilogue; one thread per (m, p)
+// combine split-K slabs in split order and apply the fused epilogue.  VEC (vecStore destinations, slab pitch and
+// pixel count multiples of 4): a thread owns 4 consecutive pixels of one row -- 16-byte slab loads, one 16-byte
+// store; otherwise one (m, p) per thread.  divCols = NP / 4 resp. NP.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
-conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits) {
-  size_t idx = blockIdx.x * (size_t)256 + threadIdx.x;
-  if (idx >= (size_t)a.M * a.NP) return;
-  int m = (int)(idx / a.NP);
-  int p = (int)(idx - (size_t)m * a.NP);
-  float v = 0.f;
-  for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + p];
+conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t cols = divCols.d;
+  if (idx >= (uint32_t)a.M * cols) return;
+  const int m = (int)xm_div(idx, divCols);
+  const int p = (int)(idx - (uint32_t)m * cols) * (VEC ? 4 : 1);
   uint32_t n = xm_div((uint32_t)p, a.divPIJ);
   uint32_t q = (uint32_t)p - n * a.divPIJ.d;
   uint32_t jj = xm_div(q, a.divPI);
@@ -833,11 +835,28 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits) {
   uint32_t mc = xm_div((uint32_t)m, a.divMU);
   int off = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride +
             (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
-  if (a.bias) v += a.bias[m];
-  if (a.scale) v = v * a.scale[m] + a.shift[m];
-  if (a.resid) v += a.resid[off];
-  if (a.relu) v = fmaxf(v, 0.f);
-  a.Y[off] = v;
+  if (VEC) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(a.slab + ((size_t)z * a.M + m) * a.NPs + p);
+    if (a.bias) v += a.bias[m];
+    if (a.scale) v = v * a.scale[m] + a.shift[m];
+    if (a.resid) v += *reinterpret_cast<const f32x4 *>(a.resid + off);
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<f32x4 *>(a.Y + off) = v;
+  } else {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + p];
+    if (a.bias) v += a.bias[m];
+    if (a.scale) v = v * a.scale[m] + a.shift[m];
+    if (a.resid) v += a.resid[off];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.Y[off] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
