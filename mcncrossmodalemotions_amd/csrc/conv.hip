@@ -810,7 +810,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     // 4 consecutive output pixels are contiguous (same sample) and every tile starts on a multiple
     // of 32 pixels; 16-byte alignment of (y, residual) rows needs Ho*Wo % 4 == 0
     a.vecStore = ((g.Ho * g.Wo) % 4 == 0 && (((uintptr_t)a.Y | (uintptr_t)a.resid) & 15) == 0) ? 1 : 0;
-    a.dmaOk = dma_ok ? 1 : 0;
+    a.dmaOk = (dma_ok && a.vecStore) ? 1 : 0;   // the LDS-DMA kernel only carries the 16-byte-store epilogue
     a.aBytes = (unsigned)((size_t)g.Kg * lda * 4);
     a.tapStride = (unsigned)((size_t)g.H * g.W * 4);
     auto run = [&](int ci) {
@@ -820,7 +820,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       return launch_gemm(aa, mode, ci, sp, slab, st);
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, dma_ok ? kNumCfg : kNumBaseCfg);
+    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
     rc = run(ci);
     if (rc) return rc;
   }

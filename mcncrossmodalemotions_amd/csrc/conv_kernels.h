@@ -165,7 +165,28 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
 
 // Epilogue shared by the implicit-GEMM kernels: split-K slab store, or y = act((acc + bias) * scale + shift +
 // residual) with scalar-cache row constants and 16-byte stores through an in-quad transpose.
-template <int TM, int TN, int WGM, int WGN>
+// Epilogue stores.  ASMST (the persistent LDS-DMA kernel): inline-asm stores the compiler does not track.  That
+// kernel keeps its epilogue INSIDE the k loop; with ordinary stores the compiler's wait-count pass sees "VMEM
+// possibly outstanding" on the loop back edge and puts `s_waitcnt vmcnt(0)` at the loop header -- in front of
+// every k stage -- which also drains the hand-counted LDS-DMA prefetch ring (the asm loads share vmcnt): the ring
+// degenerated to one stage of look-ahead and the epilogue loads each waited for the stores issued before them.
+// gfx9 stores read their data registers in issue order, so nothing has to wait for an untracked store.
+template <bool ASMST>
+__device__ __forceinline__ void xm_st16(float *p, f32x4 v) {
+  if constexpr (ASMST)
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  else
+    *reinterpret_cast<f32x4 *>(p) = v;
+}
+template <bool ASMST>
+__device__ __forceinline__ void xm_st4(float *p, float v) {
+  if constexpr (ASMST)
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  else
+    *p = v;
+}
+
+template <int TM, int TN, int WGM, int WGN, bool ASMST = false>
 __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                    int split, int wm, int wn, int half, int l31) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -192,7 +213,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int m = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m < a.M) out[(size_t)m * a.NPs + p] = acc[i][j][r];
+          if (m < a.M) xm_st4<ASMST>(out + (size_t)m * a.NPs + p, acc[i][j][r]);
         }
     }
     return;
@@ -225,22 +246,44 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     // -- 8-16 s_loads and an s_waitcnt per group: a chain of eight scalar round trips per tile, 17-20 % of the
     // store-heavy layers.)  Same fma operands as before the transpose, so the results are bit-identical.
     float rmul[TM][4], radd[TM][4];
+    {
+      // one uniform branch per KIND of constant, all its loads back to back (a branch per row group makes the
+      // compiler wait for each group before it issues the next)
+      int rowc[TM][4];
+      float bi_[TM][4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int rowc = min(wbase + i * 32 + 8 * g4 + 4 * half + iq, a.M - 1);
-        float m_ = 1.f, t_ = 0.f;
-        if (a.scale) {
-          m_ = a.scale[rowc];
-          t_ = a.shift[rowc];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          rowc[i][g4] = min(wbase + i * 32 + 8 * g4 + 4 * half + iq, a.M - 1);
+          rmul[i][g4] = 1.f;
+          radd[i][g4] = 0.f;
+          bi_[i][g4] = 0.f;
         }
-        if (a.bias) t_ += a.bias[rowc] * m_;
-        rmul[i][g4] = m_;
-        radd[i][g4] = t_;
+      if (a.scale) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            rmul[i][g4] = a.scale[rowc[i][g4]];
+            radd[i][g4] = a.shift[rowc[i][g4]];
+          }
       }
+      if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) bi_[i][g4] = a.bias[rowc[i][g4]];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) radd[i][g4] += bi_[i][g4] * rmul[i][g4];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      int offs[4][TN];
+      bool ok[4][TN];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int row = wbase + i * 32 + 8 * g4 + 4 * half + iq;  // the row this lane stores after the transpose
@@ -249,19 +292,40 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
         const int moff = (int)mc * a.oChanStride + (rowc - (int)mc * (int)a.divMU.d) * a.oUStride;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          offs[g4][j] = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
+          ok[g4][j] = row < a.M && pok[j];
+        }
+      }
+      // ASMST: the residual quads of the whole row tile first -- a load issued behind untracked stores makes the
+      // compiler's vmcnt(0) in front of its use wait for those stores as well (in-order counter).
+      // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
+      // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
+      f32x4 rv[ASMST ? 4 : 1][ASMST ? TN : 1];
+      if (ASMST && a.resid) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            rv[g4 % (ASMST ? 4 : 1)][j % (ASMST ? TN : 1)] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok[g4][j]) rv[g4 % (ASMST ? 4 : 1)][j % (ASMST ? TN : 1)] = *reinterpret_cast<const f32x4 *>(a.resid + offs[g4][j]);
+          }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
           float v[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g4 + k];
           quad_transpose4(v, iq);
-          if (row < a.M && pok[j]) {
-            const int off = obase[j] - iq + moff;  // pixel quad base (4 consecutive pixels contiguous)
+          if (ok[g4][j]) {
             f32x4 o = {v[0] * rmul[i][g4] + radd[i][g4], v[1] * rmul[i][g4] + radd[i][g4],
                        v[2] * rmul[i][g4] + radd[i][g4], v[3] * rmul[i][g4] + radd[i][g4]};
             if (a.resid) {
-              // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
-              // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
-              const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.resid + off);
-              o += rv;
+              if constexpr (ASMST)
+                o += rv[g4 % (ASMST ? 4 : 1)][j % (ASMST ? TN : 1)];
+              else
+                o += *reinterpret_cast<const f32x4 *>(a.resid + offs[g4][j]);
             }
             if (a.relu) {
               o.x = fmaxf(o.x, 0.f);
@@ -270,9 +334,9 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
               o.w = fmaxf(o.w, 0.f);
             }
 #if defined(XM_VARIANT) && XM_VARIANT == 3
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(a.Y + off));
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(a.Y + offs[g4][j]));
 #else
-            *reinterpret_cast<f32x4 *>(a.Y + off) = o;
+            xm_st16<ASMST>(a.Y + offs[g4][j], o);
 #endif
           }
         }
@@ -280,6 +344,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     }
     return;
   }
+  if constexpr (ASMST) return;  // the LDS-DMA kernel is only dispatched with vecStore (conv_forward: dmaOk)
   // scalar-store path (pixel quads straddle samples: H*W % 4 != 0).  Row constants: per-lane loads, all 16 rows of a
   // row tile in flight together (see the wide path).
 #pragma unroll
@@ -309,7 +374,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
           float v = acc[i][j][r] * rmul[r] + radd[r];
           if (a.resid) v += a.resid[off];
           if (a.relu) v = fmaxf(v, 0.f);
-          a.Y[off] = v;
+          xm_st4<ASMST>(a.Y + off, v);
         }
       }
     }
@@ -786,7 +851,7 @@ conv_gemm_dma_kernel(const ConvGemmArgs a) {
       slot = nslot;
       if (++ckt == nst) {
         // tile complete: store it (the next tile's loads are already in flight) and start over
-        conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, ctile % a.nbm, ctile / a.nbm, split, wm, wn, half, l31);
+        conv_gemm_epilogue<TM, TN, WGM, WGN, true>(a, acc, ctile % a.nbm, ctile / a.nbm, split, wm, wn, half, l31);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
