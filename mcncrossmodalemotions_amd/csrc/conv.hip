@@ -415,7 +415,7 @@ static std::map<TuneKey, int> g_tuned;
 // are then the same in every process, and shapes already in the table pay no timed launches on the caller's
 // stream.  Shapes that are not in the table are still measured once per process (and written back by
 // xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
-constexpr int XM_TUNE_REV = 3;
+constexpr int XM_TUNE_REV = 4;
 static bool g_tune_loaded = false;
 static int g_tune_new = 0;  // entries measured in this process (not yet saved)
 
