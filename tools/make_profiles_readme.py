@@ -77,10 +77,13 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
 | 8f-1: 13 frames/pair, SE-ResNet50 teacher + student step | 32 pairs (416 faces) | {mf['value']} pairs/s | {mf['ms_per_step']} | {pct(mf['model_frac_of_fp32_mfma_peak'])} |
 | 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
-Round 2 did not move the default line ({d['value']} vs 3502 pairs/s in round 1): what was built is in DESIGN.md 2.1b / 2.1c — a
-persistent LDS-DMA kernel for the 1x1 layers (correct, at parity), and the measurements that say where the time goes
-(clock ramp, instruction-mix ceiling, epilogue stores that do not overlap: +10.5 % on this line with the stores compiled
-out).
+Round 1 -> round 2 on the default line: 3502 -> {d['value']} pairs/s (+{round(100 * (d['value'] / 3502 - 1), 1)} %).  Where it came from:
+conv epilogue constants as per-lane loads (+2.4 %); the student's pooling layers rewritten (LDS-staged forward, per-channel
+backward sums from the pooled tensors, patch-per-thread apply: +3.8 %); reduction / finalize / filter-transpose kernels that were
+bound by index arithmetic or idle lanes (+1.8 %); the LDS-DMA kernel's epilogue stores made invisible to the compiler's
+wait-count pass, whose `s_waitcnt vmcnt(0)` at the k-loop header drained the DMA ring every stage (+1.0 % here, the 1x1 layers'
+ceiling 106 -> 134 TFLOP/s on a long-K fill case).  SE-ResNet50 teacher: 3197 -> {se['value']} pairs/s (skinny FC kernel for the gates).
+Serial non-convolution time: 2.1 -> see `kernel_stats.txt`.
 
 ## How the numbers were taken
 ```
