@@ -103,6 +103,30 @@ def test_conv_fused_sigmoid_general_path(gpu):
     close(vl.to_numpy(y), y_ref, 1e-5, what="conv + sigmoid")
 
 
+# (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
+STEM_CASES = [(512, 60, 2, 96, (1, 1, 1, 1)), (131, 45, 3, 96, (1, 1, 1, 1)), (64, 33, 2, 64, (3, 3, 3, 3)),
+              (40, 41, 2, 33, (0, 0, 0, 0)), (29, 23, 1, 7, (2, 1, 0, 3)), (300, 18, 1, 96, (1, 0, 1, 0))]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_conv_stem7(gpu, case):
+    """the student's first layer geometry (7x7 / 2, C = 1, K = 49 padded to 64): plain and fused epilogue, odd and
+    even output heights, ragged tiles in both directions, K below / at the 96-row tile -- against the oracle"""
+    from mcncrossmodalemotions_amd import vl
+    H, W, N, K, pad = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x, f, b = rnd(rng, H, W, 1, N), O.F(rng.standard_normal((7, 7, 1, K)) * 0.2), rnd(rng, K)
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, stride=2, pad=pad, acc64=True)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(-1, 1))
+    close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad)), y_ref, 1e-5, "stem")
+    close(vl.to_numpy(vl.vl_nnconv(xd, fd, None, stride=2, pad=pad)), O.vl_nnconv(x, f, None, stride=2, pad=pad, acc64=True),
+          1e-5, "stem, no bias")
+    yf = vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad, scale=vl.from_numpy(sc.reshape(-1, 1)),
+                      shift=vl.from_numpy(sh.reshape(-1, 1)), relu=True)
+    close(vl.to_numpy(yf), np.maximum(y_ref * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1), 0), 1e-5, "stem fused")
+
+
 # enough pixels per stride-parity class for the merged single-launch dgrad (conv_gemm_multi_kernel)
 MERGED_DGRAD_CASES = [
     (200, 200, 8, 4, 3, 3, 8, 8, (2, 2), (1, 1, 1, 1), (1, 1)),     # 4 classes, 3x3
