@@ -79,8 +79,7 @@ int xm_parserv_push(float *buf, size_t n, void *producer_stream) {
   if (!e) return xm::fail(XM_EHIP, "parserv: event creation failed");
   XM_HIP(hipEventRecord(e, (hipStream_t)producer_stream));
   XM_HIP(hipStreamWaitEvent(g_ps_stream, e, 0));
-  static const int dbg = getenv("XM_PS_DEBUG") ? atoi(getenv("XM_PS_DEBUG")) : 0;   // experiments only
-  if (dbg != 1) XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, g_ps_stream));
+  XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, g_ps_stream));
   ++g_ps_pending;
   return XM_OK;
 }

@@ -670,8 +670,7 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
   // LDS-staged kernel: max pooling, 3x3 window, planes large enough to fill a block, 16-byte aligned tensor
   if (method == XM_POOL_MAX && ph == 3 && pw == 3 && ((uintptr_t)x & 15) == 0 && (long long)C * N <= 65535 &&
       g.Ho * g.Wo >= 256 && !getenv("XM_NO_POOL_LDS")) {
-    static const int lds_kb = getenv("XM_POOL_LDS_KB") ? atoi(getenv("XM_POOL_LDS_KB")) : 16;
-    const int maxcols = lds_kb * 256 / H;  // 16 KB of LDS per block: 10 blocks per CU, measured best of 8 / 16 / 32 / 64
+    const int maxcols = 16 * 256 / H;  // 16 KB of LDS per block: 10 blocks per CU, measured best of 8 / 16 / 32 / 64
     int wob = maxcols >= pw ? (maxcols - pw) / sx + 1 : 0;
     wob = std::min(wob, g.Wo);
     if (wob >= 4 || (wob >= 1 && wob == g.Wo)) {
@@ -1090,8 +1089,7 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   const int KH = (H + pt + sy - 1) / sy, KW = (W + pl + sx - 1) / sx;
   int pbx = pow2_ge(KH, 256), pby = pow2_ge(KW, 256 / pbx);
   int pgx = (KW + pby - 1) / pby, pgz = (KH + pbx - 1) / pbx;
-  static const int ptarget = getenv("XM_PATCH_TARGET") ? atoi(getenv("XM_PATCH_TARGET")) : 16384;
-  int pS = std::max(1, std::min(N, ptarget / std::max(1, C * pgx * pgz)));
+  int pS = std::max(1, std::min(N, 16384 / std::max(1, C * pgx * pgz)));   // >= 16 k blocks (4 k and 64 k measured worse)
   const size_t pnb = (size_t)pgx * pgz * pS;
   // pooled-domain sums
   const bool pooled = !no_pooled && y_pool != nullptr;
