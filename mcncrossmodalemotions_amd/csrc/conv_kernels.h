@@ -174,7 +174,9 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
 template <bool ASMST>
 __device__ __forceinline__ void xm_st16(float *p, f32x4 v) {
   if constexpr (ASMST)
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    // trailing s_nop 1: the compiler pads nothing after an asm statement, and a VALU write to the data registers in
+    // the two wait states behind a > 8-byte store would overtake the store's read of them
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else
     *reinterpret_cast<f32x4 *>(p) = v;
 }
@@ -666,7 +668,7 @@ struct DmaGeo {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
+        "s_nop 2\n\t"   // m0 write -> LDS-DMA use, and 5 wait states in all between a VALU-written SGPR operand and its read
         "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
