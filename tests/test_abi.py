@@ -66,3 +66,21 @@ def test_product_path_has_no_cpu_fallback():
             elif isinstance(node, ast.ImportFrom):
                 mods = [node.module or ""]
             assert not any(m.split(".")[0] == "oracle" for m in mods), (fn, mods)
+
+
+def test_shipped_tuning_table_matches_the_library():
+    """mcncrossmodalemotions_amd/tune_gfx950.txt must carry the revision / configuration count of the library it
+    ships with (a kernel change bumps XM_TUNE_REV; a stale table would be ignored silently and every process
+    would re-tune): the library's own loader accepts it, and it covers the default bench step."""
+    from mcncrossmodalemotions_amd import _lib
+    L = _lib.load()
+    path = os.path.join(ROOT, "mcncrossmodalemotions_amd", "tune_gfx950.txt")
+    assert os.path.exists(path)
+    first = L.xm_tune_load(path.encode())
+    tot, new = C.c_int(), C.c_int()
+    assert L.xm_tune_entries(C.byref(tot), C.byref(new)) == 0
+    # either this call or an earlier lookup in this process loaded it; nothing in it was measured here
+    assert tot.value >= 300 and new.value == 0 and first in (0, tot.value), (first, tot.value, new.value)
+    rows = [l.split() for l in open(path).read().splitlines()[1:]]
+    # student conv2 forward at 32 samples: kind 0, M 256, NP 62*36*32, Rp 2400
+    assert any(r[:4] == ["0", "256", str(62 * 36 * 32), "2400"] for r in rows)
