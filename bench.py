@@ -48,7 +48,7 @@ def parse():
                          "warm-up (the clocks of this part need ~0.3 s of sustained load to settle: a 0.2 s timed "
                          "region under-reports by 5-10 %)")
     ap.add_argument("--warmup", type=int, default=0,
-                    help="untimed steps W; 0 = 10.  Untimed 'settle' steps follow until 0.5 s of load have passed")
+                    help="untimed steps W; 0 = 10.  Untimed 'settle' steps follow until 1.5 s of load have passed")
     ap.add_argument("--min-seconds", type=float, default=2.0)
     ap.add_argument("--workload", default="distill",
                     choices=["distill", "student", "teacher", "joint", "cpu-teacher"])
@@ -336,14 +336,15 @@ def main():
     _mp = os.environ.get("XM_MAIN_PRIO")
     if _mp is not None:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(_mp)))
-    # warm-up: Wm steps (default 10) and at least 0.5 s -- tile tuning happens here, and the shader clock of this
+    # warm-up: Wm steps (default 10) and at least 1.5 s -- tile tuning happens here, and the shader clock of this
     # part takes ~0.3 s of sustained load to reach its steady state (tools/power_probe.py)
     Wm = args.warmup or 10
     tw = time.perf_counter()
     for it in range(Wm):
         throttled_step(it)
     # settle: the contract's W warm-up steps can be as short as 50 ms; keep stepping (untimed, reported as
-    # "settle_steps") until the device has seen 0.5 s of sustained load, so that the K timed steps run at the
+    # "settle_steps") until the device has seen 1.5 s of sustained load (0.3 s for the clock; the first process on a
+    # cold box also shows a one-off ~50 ms stall about 1.2 s after its first kernel), so that the K timed steps run at the
     # steady-state clock whatever W was
     barrier()
     t1 = time.perf_counter()
@@ -352,7 +353,7 @@ def main():
     barrier()
     est = (time.perf_counter() - t1) / 3
     settle = 3
-    more = max(0, int(np.ceil((0.5 - (time.perf_counter() - tw)) / max(est, 1e-6))))
+    more = max(0, int(np.ceil((1.5 - (time.perf_counter() - tw)) / max(est, 1e-6))))
     if world > 1:   # same count on every rank: each step contains collectives
         t = torch.tensor([more], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,6 +403,7 @@ def main():
                  for i in range(len(marks) - 1)]
         windows = {"n": len(rates), "steps_each": marks[1][0] - marks[0][0], "min": round(min(rates), 1),
                    "median": round(float(np.median(rates)), 1), "max": round(max(rates), 1),
+                   "rates": [round(r, 1) for r in rates],
                    "note": "rank-0 stream time between event marks inside the timed region (value uses the wall clock)"}
 
     # ---- roofline leg: same K steps again with HIP events around every conv launch ---------

@@ -32,7 +32,7 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
 |---|---|
 | `{R}/pytest_gpu.txt` | `python -m pytest tests -q -m gpu` on that box ({tests}) |
 | `{R}/bench_distill_n1.json` | `python bench.py` — default line: distillation step, 32 pairs/GPU, K chosen for a >= 2 s timed region, incl. `roofline`, `cpu_baseline`, `windows` |
-| `{R}/bench_distill_driver_flags_n1.json` | `python bench.py --steps 20 --warmup 5` — the driver's command line (0.5 s settle phase in front of the 20 timed steps) |
+| `{R}/bench_distill_driver_flags_n1.json` | `python bench.py --steps 20 --warmup 5` — the driver's command line (settle phase in front of the 20 timed steps: `settle_steps` in the line) |
 | `{R}/bench_distill_serial_n1.json` | `python bench.py --serial` — same step on ONE HIP stream (no overlap), the mode the roofline leg and the profiles below use |
 | `{R}/bench_under_rocprof.json`, `{R}/kernel_stats.txt` | `rocprofv3 --kernel-trace --stats -- python bench.py --serial --no-cpu-baseline --steps 60 --warmup 10` and its per-kernel summary (`tools/prof_summary.py`) |
 | `{R}/bench_student_n1.json`, `bench_teacher_n1.json`, `bench_joint_n1.json` | BASELINE configs 2, 3 and the config-5 shard (`--workload student|teacher|joint`) |
