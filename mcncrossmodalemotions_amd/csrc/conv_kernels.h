@@ -221,9 +221,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     return;
   }
   // ---- epilogue: y = act((acc + bias) * scale + shift + residual) ----
-  // Per-row constants are wave-uniform up to lane>>5 (rows r and r+4 of an MFMA tile), so they are
-  // fetched through the scalar cache (two candidates per output, selected by the lane half) instead
-  // of three vector loads per output element.
+  // Per-row constants: per-lane loads of the rows the lane stores, all in flight together (both paths below).
   const int wbase = __builtin_amdgcn_readfirstlane(bm * BM + wm * TM * 32);
   int obase[TN];
   bool pok[TN];
