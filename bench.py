@@ -135,13 +135,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    # XM_DEBUG_DIST=gloo0: every rank on cuda:0, exchange over gloo -- a functional run of the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); the throughput it prints means nothing
+    shared_gpu = os.environ.get("XM_DEBUG_DIST") == "gloo0"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("XM_DEBUG_DIST") in ("1", "2")   # exercise the RCCL path with a single rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     L = _lib.load()
 
     wl = args.workload
