@@ -542,14 +542,34 @@ pool_global_kernel(const float *__restrict__ x, float *__restrict__ y, int HW, i
   if (plane >= planes) return;
   const float *p = x + (size_t)plane * HW;
   int lane = threadIdx.x & 63;
+  // 16-byte loads when the plane is a whole number of aligned quads (the SE squeeze: 56^2 ... 14^2 maps)
+  const bool vec = (HW & 3) == 0 && (((uintptr_t)p) & 15) == 0;
   if (method == XM_POOL_MAX) {
     float r = -INFINITY;
-    for (int i = lane; i < HW; i += 64) r = fmaxf(r, p[i]);
+    if (vec) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll 4
+      for (int i = lane; i < (HW >> 2); i += 64) {
+        const float4 v = p4[i];
+        r = fmaxf(fmaxf(r, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) r = fmaxf(r, p[i]);
+    }
     r = xm_wave_max(r);
     if (lane == 0) y[plane] = r;
   } else {
     float r = 0.f;
-    for (int i = lane; i < HW; i += 64) r += p[i];
+    if (vec) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll 4
+      for (int i = lane; i < (HW >> 2); i += 64) {
+        const float4 v = p4[i];
+        r += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) r += p[i];
+    }
     r = xm_wave_sum(r);
     if (lane == 0) y[plane] = r * (1.0f / (float)HW);
   }
