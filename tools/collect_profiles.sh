@@ -33,6 +33,23 @@ PY
 )
 python tools/prof_summary.py "$DB" $STEPS > $O/kernel_stats.txt
 rm -rf $O/kt
+# the same summary for the other configurations (serial mode, 20 timed steps each)
+kstats() {   # kstats <tag> <bench flags...>
+  local tag=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_$tag -o run -- $B --serial --no-cpu-baseline --no-roofline --steps 20 --warmup 5 "$@" \
+      > $O/kt_$tag.json 2> /dev/null
+  local db=$(find $O/kt_$tag -name "*.db" | head -1)
+  local n=$(python -c "import json; d=json.loads(open('$O/kt_$tag.json').read().strip().splitlines()[-1]); print(d['warmup'] + d['settle_steps'] + d['steps'])")
+  python tools/prof_summary.py "$db" $n > $O/kernel_stats_$tag.txt
+  rm -rf $O/kt_$tag $O/kt_$tag.json
+}
+if [ -z "$XM_PROFILE_SKIP_EXTRA" ]; then
+  kstats student --workload student
+  kstats teacher --workload teacher
+  kstats joint --workload joint
+  kstats senet50 --teacher senet50
+  kstats b256 --per-gpu-batch 256
+fi
 # PMC passes, each on its own (no tracing domains besides the kernel trace)
 P="--serial --steps 3 --warmup 3 --no-cpu-baseline --no-roofline"
 SQC="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"

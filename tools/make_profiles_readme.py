@@ -36,6 +36,7 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
 | `{R}/bench_distill_serial_n1.json` | `python bench.py --serial` — same step on ONE HIP stream (no overlap), the mode the roofline leg and the profiles below use |
 | `{R}/bench_under_rocprof.json`, `{R}/kernel_stats.txt` | `rocprofv3 --kernel-trace --stats -- python bench.py --serial --no-cpu-baseline --steps 60 --warmup 10` and its per-kernel summary (`tools/prof_summary.py`) |
 | `{R}/bench_student_n1.json`, `bench_teacher_n1.json`, `bench_joint_n1.json` | BASELINE configs 2, 3 and the config-5 shard (`--workload student|teacher|joint`) |
+| `{R}/kernel_stats_student.txt`, `kernel_stats_teacher.txt`, `kernel_stats_joint.txt`, `kernel_stats_senet50.txt`, `kernel_stats_b256.txt` | the same rocprofv3 per-kernel summary (serial mode, 20 timed steps) for configs 2, 3, the config-5 shard, the SE-ResNet50 distillation step and the batch-256 step |
 | `{R}/bench_distill_senet50_n1.json` | the reference's default teacher (`run_distillation.m:82`): `--teacher senet50`, one face per pair |
 | `{R}/bench_distill_senet50_b256_n1.json`, `bench_distill_b256_n1.json` | north_star's batch 256 on ONE GPU (`--per-gpu-batch 256`), SE-ResNet-50 / ResNet-50 teacher |
 | `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
