@@ -46,6 +46,8 @@ enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 /* fused-epilogue flags for xm_nnconv_forward_fused / xm_nnbnorm_forward_fused */
 enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
+/* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
+ * XM_EINVAL without a communicator.  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -241,7 +243,9 @@ int xm_allreduce_sum_f32(float *buf, size_t n, void *stream);   /* blocking-in-s
  *                                      stream -- the producer stream goes on with the rest of the backward pass;
  *   xm_parserv_sync(consumer)          once per minibatch before accumulateGradients: `consumer` waits (on the
  *                                      device, not the host) for every push since the previous sync.
- * Every element must be pushed exactly once per minibatch.  world == 1: both are no-ops. */
+ * Every element must be pushed exactly once per minibatch.  After xm_comm_init(.., world == 1) both are no-ops;
+ * WITHOUT a successful xm_comm_init they (and xm_allreduce_sum_f32) return XM_EINVAL -- a worker must never go on
+ * training with derivatives that were silently not exchanged. */
 int xm_parserv_push(float *buf, size_t n, void *producer_stream);
 int xm_parserv_sync(void *consumer_stream);
 /* ncclCommCount of the communicator (1 when no communicator exists): proof of the worker count */

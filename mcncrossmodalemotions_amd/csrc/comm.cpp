@@ -10,6 +10,7 @@
 
 static ncclComm_t g_comm = nullptr;
 static int g_world = 1;
+static int g_inited = 0;                   // xm_comm_init succeeded (a real single worker has no communicator)
 static int g_force_single = 0;             // debugging: a real 1-rank communicator (xm_debug_comm_force_single)
 // ParameterServer push/sync: the exchange runs on the communicator's OWN stream so that a bucket's all-reduce
 // overlaps whatever the producer stream does next (the rest of the backward pass)
@@ -48,12 +49,17 @@ int xm_comm_unique_id(void *id128) {
 int xm_comm_init(const void *id128, int rank, int world) {
   if (g_comm) return xm::fail(XM_EINVAL, "comm: already initialised");
   if (world < 1 || rank < 0 || rank >= world) return xm::fail(XM_EINVAL, "comm: bad rank/world");
-  g_world = world;
-  if (world == 1 && !g_force_single) return XM_OK;  // single worker: ParameterServer is bypassed (numel(gpus) == 1)
+  if (world == 1 && !g_force_single) {  // single worker: ParameterServer is bypassed (numel(gpus) == 1)
+    g_world = 1;
+    g_inited = 1;
+    return XM_OK;
+  }
   if (!id128) return xm::fail(XM_EINVAL, "comm: NULL id");
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   XM_NCCL(ncclCommInitRank(&g_comm, world, id, rank));
+  g_world = world;
+  g_inited = 1;
   return XM_OK;
 }
 
@@ -71,8 +77,18 @@ int xm_comm_count(int *ranks) {
 
 // ParameterServer.push: start the sum of `buf` over all workers as soon as everything already enqueued on
 // `producer_stream` has finished; returns at once (the exchange runs on the communicator's stream).
+// An exchange without a communicator is a no-op ONLY after a successful single-worker xm_comm_init; a host that
+// skipped the init (or whose init failed) must not train on silently un-exchanged derivatives.
+static int comm_missing(const char *what) {
+  if (g_comm) return 0;
+  if (g_inited && g_world == 1) return 1;   // real single worker
+  xm::fail(XM_EINVAL, "%s: no communicator (xm_comm_init was not called or failed)", what);
+  return -1;
+}
+
 int xm_parserv_push(float *buf, size_t n, void *producer_stream) {
-  if (!g_comm || n == 0) return XM_OK;
+  if (int m = comm_missing("parserv push")) return m > 0 ? XM_OK : XM_EINVAL;
+  if (n == 0) return XM_OK;
   if (!buf) return xm::fail(XM_EINVAL, "parserv: NULL buffer");
   if (!g_ps_stream) XM_HIP(hipStreamCreateWithFlags(&g_ps_stream, hipStreamNonBlocking));
   hipEvent_t e = ps_event();
@@ -87,7 +103,11 @@ int xm_parserv_push(float *buf, size_t n, void *producer_stream) {
 // ParameterServer.sync + pull: `consumer_stream` waits for every push issued since the last sync; the summed
 // values are then in place.  Does not block the host.
 int xm_parserv_sync(void *consumer_stream) {
-  if (!g_comm || !g_ps_pending) {
+  if (int m = comm_missing("parserv sync")) {
+    g_ps_next = 0;
+    return m > 0 ? XM_OK : XM_EINVAL;
+  }
+  if (!g_ps_pending) {
     g_ps_next = 0;
     return XM_OK;
   }
@@ -101,7 +121,8 @@ int xm_parserv_sync(void *consumer_stream) {
 }
 
 int xm_allreduce_sum_f32(float *buf, size_t n, void *stream) {
-  if (!g_comm || n == 0) return XM_OK;
+  if (int m = comm_missing("allreduce")) return m > 0 ? XM_OK : XM_EINVAL;
+  if (n == 0) return XM_OK;
   if (!buf) return xm::fail(XM_EINVAL, "comm: NULL buffer");
   XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, (hipStream_t)stream));
   return XM_OK;
@@ -122,6 +143,7 @@ int xm_comm_destroy(void) {
     g_comm = nullptr;
   }
   g_world = 1;
+  g_inited = 0;
   return XM_OK;
 }
 }

@@ -863,7 +863,7 @@ bnpool_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g
 //   y_p = g/sigma (x_argmax - mu) + b > 0    =>    x_argmax - mu = (y_p - b) sigma / g,
 // so   sum dz = sum_p [y_p > 0] dzdy_p   and   sum dz (x - mu) = sigma/g * sum_p [y_p > 0] dzdy_p (y_p - b):
 // two POOLED tensors are read instead of x + table + dzdy (3.7x fewer bytes on a 3x3 / stride-2 layer).
-// Channels whose gain is too small for the inversion (|b| > 100 |g|: rounding of y_p - b would be amplified)
+// Channels whose gain is too small for the inversion (g == 0 or |b| > 100 |g|: rounding of y_p - b would be amplified)
 // gather x at the recorded argmax instead.  grid (C, S), part[c][s] = (sum dz, sum dz (x - mu)).
 __global__ void __launch_bounds__(256)
 bnpool_bwd_partial_pooled_kernel(const float *__restrict__ x, const float *__restrict__ yp,
@@ -875,7 +875,7 @@ bnpool_bwd_partial_pooled_kernel(const float *__restrict__ x, const float *__res
   const int HWo = g.Ho * g.Wo;
   const float gc = gg[c], bc = bb[c];
   const double mu = mom[c];
-  const bool invert = fabsf(bc) <= 100.f * fabsf(gc);
+  const bool invert = gc != 0.f && fabsf(bc) <= 100.f * fabsf(gc);   // g == 0 (zero-initialised gain): 0 * inf
   double a = 0.0, b = 0.0;
   for (int n = s; n < N; n += S) {
     const size_t plane = (size_t)c + (size_t)C * n;

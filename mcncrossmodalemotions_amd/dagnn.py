@@ -648,6 +648,11 @@ class DagNN:
             self.vars[k].value = t
         plan = self._plan(derOutputs is not None)
         self._training = derOutputs is not None
+        if self._training and self.wgradStream is not None:
+            # the side stream reads the parameters (filter transposition for dgrad, vl.conv_prepare_backward) and
+            # overwrites the transposed copies the previous step's dgrad read: both happened on THIS stream (the
+            # previous step's xm_sgd_update / backward pass), so the side stream must not start before them
+            self.wgradStream.wait_stream(torch.cuda.current_stream())
         pending = dict(input_events or {})
         for step in plan:
             if pending:
@@ -785,6 +790,10 @@ class _Step:
                 dins, dpar = r.block.backward(ins, self._params(net), douts, need_dx=need_dx,
                                               der_out=net._direct_der(r), skip_db=skip_db, dx_accum=accum)
                 if net.gradHook is not None:
+                    if net._side_pending:
+                        # the hook may push a bucket that also covers layers whose filter derivatives were
+                        # enqueued on the side stream: the push is ordered against THIS stream only
+                        torch.cuda.current_stream().wait_stream(net.wgradStream)
                     net.gradHook(r.name)
             else:
                 # dzdw / dzdb are off the critical path of the backward pass: they run on the side

@@ -10,6 +10,7 @@ Data parallelism follows MatConvNet: each worker takes a shard of the minibatch,
 are per worker, gradients are summed and divided by the GLOBAL batch size.
 """
 import ctypes as C
+import pickle
 
 import numpy as np
 import torch
@@ -421,27 +422,39 @@ def save_checkpoint(net, path, info, epoch):
 
 
 def load_checkpoint(net, path, strict=True):
-    """inverse of save_checkpoint (values stored in the flat buffers' memory order: reversed MATLAB shape)"""
+    """inverse of save_checkpoint (values stored in the flat buffers' memory order: reversed MATLAB shape).
+    The whole file is validated against the net BEFORE anything is copied: a mismatch leaves the net untouched."""
     ck = torch.load(path, map_location=net.device, weights_only=True)
-    if ck.get("format") != "xmodal-params-v2":
-        raise ValueError("%s: not an xmodal checkpoint" % path)
+    if not isinstance(ck, dict) or ck.get("format") != "xmodal-params-v2":
+        raise CheckpointMismatch("%s: not an xmodal checkpoint" % path)
     if net._flat is None:
         net.pack_params()
+    todo = []
     for name, p in net.params.items():
         if name not in ck["params"]:
             if strict:
-                raise KeyError("checkpoint has no parameter %r" % name)
+                raise CheckpointMismatch("checkpoint has no parameter %r" % name)
             continue
         n = int(p.value.numel())
-        off = p._flat_off
         src = ck["params"][name]
         if int(src.numel()) != n:
-            raise ValueError("parameter %r: %d values in the checkpoint, %d in the net" % (name, src.numel(), n))
+            raise CheckpointMismatch("parameter %r: %d values in the checkpoint, %d in the net" %
+                                     (name, src.numel(), n))
+        mom = ck.get("momentum", {}).get(name)
+        if mom is not None and int(mom.numel()) != n:
+            raise CheckpointMismatch("momentum of %r: %d values in the checkpoint, %d in the net" %
+                                     (name, mom.numel(), n))
+        todo.append((p._flat_off, n, src, mom))
+    for off, n, src, mom in todo:
         net._flat.val[off:off + n].copy_(src.reshape(-1))
-        if name in ck.get("momentum", {}):
-            net._flat.mom[off:off + n].copy_(ck["momentum"][name].reshape(-1))
+        if mom is not None:
+            net._flat.mom[off:off + n].copy_(mom.reshape(-1))
     net.paramGeneration = getattr(net, "paramGeneration", 0) + 1
     return ck
+
+
+class CheckpointMismatch(ValueError):
+    """the file is a readable checkpoint of a DIFFERENT net (names / shapes): never skipped by `cont`"""
 
 
 def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpochs=300, train=None, val=None,
@@ -476,7 +489,9 @@ def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpoch
         while done:                      # newest readable checkpoint wins; unreadable ones are skipped
             try:
                 ck = load_checkpoint(net, path(done[-1]))
-            except Exception as e:       # noqa: BLE001 -- a damaged file must not stop `cont`
+            except CheckpointMismatch:   # readable, but of another net: restarting would overwrite those files
+                raise
+            except (OSError, EOFError, RuntimeError, pickle.UnpicklingError, KeyError) as e:   # truncated / damaged
                 print("cnn_train_dag: skipping unreadable checkpoint %s (%s)" % (path(done[-1]), e), flush=True)
                 done.pop()
                 continue

@@ -31,7 +31,15 @@ def test_library_exports_every_declared_symbol():
 def test_error_reporting_without_gpu():
     from mcncrossmodalemotions_amd import _lib
     L = _lib.load()
-    assert L.xm_version() >= 100
+    assert L.xm_version() >= 101
+    # an exchange without a communicator is an error (a worker that skipped xm_comm_init must not train on
+    # derivatives that were silently not exchanged); after a single-worker init it is the documented no-op
+    assert L.xm_parserv_sync(None) == 1 and b"no communicator" in L.xm_last_error()
+    assert L.xm_allreduce_sum_f32(None, 4, None) == 1
+    assert L.xm_comm_init(None, 0, 1) == 0
+    assert L.xm_parserv_sync(None) == 0 and L.xm_parserv_push(None, 0, None) == 0
+    assert L.xm_comm_destroy() == 0
+    assert L.xm_parserv_push(None, 4, None) == 1
     assert L.xm_out_size(512, 1, 1, 7, 1, 2) == 254
     # invalid arguments are rejected before any device work, with a MATLAB-style message
     rc = L.xm_nnconv_forward(None, 8, 8, 4, 2, None, 3, 3, 3, 5, None, None, 1, 1, 0, 0, 0, 0, 1, 1, None)

@@ -33,11 +33,24 @@ def _worker(rank, world, port, outdir):
 
     net = zoo.emoVoxZoo(numSeconds=T.W / 100.0, width_mult=T.WIDTH, seed=3)    # fused plans, device resident
     net.pack_params()
+    # side stream for the filter derivatives, made to LAG (a sleep in front of every filter transposition it runs
+    # during the forward pass): a bucket pushed from the main stream (conv1's hook) covers derivatives enqueued on
+    # the side stream and must wait for them
+    net.wgradStream = torch.cuda.Stream()
+    real_prep = vl.conv_prepare_backward
+
+    def slow_prep(*a, **k):
+        torch.cuda._sleep(4_000_000)
+        return real_prep(*a, **k)
+    vl.conv_prepare_backward = slow_prep
     ps = train.ParameterServer("torch")
     ps.start()
     assert ps.world == world and ps.comm_count() == world
-    net._grad_buckets = train.GradBuckets(net, target_bytes=2048)
-    assert len(net._grad_buckets.buckets) >= 3
+    # one bucket per filter segment, triggered by its EARLIEST layer: conv1 (no input derivative -> its hook runs
+    # on the main stream) pushes the derivatives of conv2 ... fc8, which were enqueued on the lagging side stream
+    # (the many-small-buckets plan is covered by the CPU test)
+    net._grad_buckets = train.GradBuckets(net, target_bytes=1 << 30)
+    assert any(t == "conv1" and b - a > 4096 for a, b, t in net._grad_buckets.buckets)
     opts = train.TrainOpts(learningRate=[1e-2], batchSize=T.BATCH)
     stats = train.process_epoch(net, None, getBatch, list(range(T.N_DATA)), opts, 0, "train", ps)
     vstats = train.process_epoch(net, None, getBatch, list(range(T.N_DATA)), opts, 0, "val", ps)

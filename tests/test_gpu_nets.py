@@ -211,6 +211,48 @@ def test_wgrad_side_stream_is_bit_identical(gpu):
     assert torch.equal(res[0], res[1])
 
 
+def test_side_stream_ordering_under_lag(gpu, monkeypatch):
+    """Ordering between the main stream and DagNN.wgradStream, provoked with artificial lag (a host that runs one or
+    two steps ahead of the GPU sees exactly these interleavings):
+      * the filter transposition the forward pass enqueues on the side stream (vl.conv_prepare_backward) must not
+        read the filters before the previous step's xm_sgd_update -- a sleep in front of every update on the MAIN
+        stream makes a missing wait visible as stale transposed filters in the next dgrad;
+      * a filter derivative enqueued on the side stream must be complete before anything on the main stream consumes
+        the flat derivative buffer -- a sleep in front of every prepare on the SIDE stream makes it lag.
+    Three steps with both lags leave parameters bit-identical to three steps without a side stream."""
+    import torch
+    from mcncrossmodalemotions_amd import train, vl, zoo
+    rng = np.random.default_rng(5)
+    x = O.F(rng.standard_normal((512, 100, 1, 4)))
+    lg = O.F(rng.standard_normal((1, 1, 8, 4)) * 3)
+    res = []
+    real_sgd, real_prep = vl.sgd_update, vl.conv_prepare_backward
+    for side in (False, True):
+        net = zoo.emoVoxZoo(numSeconds=1, seed=11, width_mult=0.125)
+        net.pack_params()
+        if side:
+            net.wgradStream = torch.cuda.Stream()
+            assert net.prepareBackward
+
+            def slow_sgd(*a, **k):
+                torch.cuda._sleep(30_000_000)      # ~15 ms on the stream the update runs on
+                return real_sgd(*a, **k)
+
+            def slow_prep(*a, **k):
+                torch.cuda._sleep(3_000_000)       # the side stream falls behind the forward pass
+                return real_prep(*a, **k)
+            monkeypatch.setattr(vl, "sgd_update", slow_sgd)
+            monkeypatch.setattr(vl, "conv_prepare_backward", slow_prep)
+        opts = train.TrainOpts(learningRate=[1e-1], batchSize=4)    # a large step: stale filters change the bits
+        xd, lgd = vl.from_numpy(x), vl.from_numpy(lg)
+        for it in range(3):
+            train.train_step(net, ["data", xd, "logitTarget", lgd, "maxLabel", vl.max_label(lgd)], opts, it,
+                             None, 4)
+        torch.cuda.synchronize()
+        res.append(net._flat.val.clone())
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("lossType", ["euclidean", "huber", "softmaxlog"])
 def test_student_alternative_loss_heads(gpu, lossType):
     """configureForRegression's other heads (emoVoxZoo.m:138-150): loss value and every parameter
