@@ -78,6 +78,10 @@ def parse():
                          "batch).  The reference decouples the two as well: buildImdb runs the teacher at batch 128 "
                          "(fetch_emovoxceleb_imdb.m:63), the student trains at 64 (run_distillation.m:75).  One pass "
                          "feeds teacher-batch / per-gpu-batch consecutive steps; every pair still gets its own face")
+    ap.add_argument("--north-star", type=int, default=-1,
+                    help="1: after the main measurement, time north_star's own configuration (SE-ResNet50 teacher + "
+                         "VGGVox student, 256 pairs on this GPU) for a bounded number of steps in a child process and "
+                         "attach it as `north_star_b256`.  -1 = on for the default single-GPU distill line only")
     ap.add_argument("--teacher-prefetch", type=int, default=1,
                     help="1: the teacher stream works one batch ahead of the student (needs --overlap-teacher 1)")
     ap.add_argument("--overlap-teacher", type=int, default=1,
@@ -120,6 +124,10 @@ def host_info():
 
 def main():
     args = parse()
+    # CPU baseline threads: one per physical core, pinned (must be in the environment before the first OpenMP
+    # runtime of the process -- torch's -- starts)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
     if args.workload == "cpu-teacher":
         return cpu_teacher_line(args)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
@@ -341,6 +349,16 @@ def main():
         if len(inflight) > 2:
             inflight.pop(0).synchronize()
 
+    # diagnostics (XM_BENCH_MARKS=1): timing events on the main stream at the phase boundaries of the student step;
+    # printed to stderr after the timed region (where the main stream spends its time, incl. the wait for the side
+    # stream) -- a rocprofv3 trace cannot show this, its launch overhead makes the run host-bound
+    marks_log = []
+    if os.environ.get("XM_BENCH_MARKS") and student is not None:
+        def _mark(label):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks_log.append((label, e))
+        student.markHook = _mark
     _mp = os.environ.get("XM_MAIN_PRIO")
     if _mp is not None:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(_mp)))
@@ -403,6 +421,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    if marks_log:
+        student.markHook = None
+        seq = marks_log[-6 * min(args.steps, 40):]
+        while seq and seq[0][0] != "fwd0":
+            seq.pop(0)
+        acc = {}
+        for (la, ea), (lb, eb) in zip(seq, seq[1:]):
+            k = "%s->%s" % (la, lb)
+            acc.setdefault(k, []).append(ea.elapsed_time(eb))
+        print("[marks] " + "  ".join("%s %.3f ms" % (k, float(np.mean(v))) for k, v in acc.items()), file=sys.stderr)
     units = nb * world
     value = units * args.steps / dt
     windows = None
@@ -439,11 +467,16 @@ def main():
         fl = (C.c_double * cap)()
         cnt = (C.c_longlong * cap)()
         n = L.xm_prof_collect(cap, keys, ms, fl, cnt)
+        bkeys = (C.c_int * cap)()
+        by = (C.c_double * cap)()
+        nb_ = L.xm_prof_collect_bytes(cap, bkeys, by)
+        bytes_of = {bkeys[i]: by[i] for i in range(min(nb_, cap))}
         rows = []
         for i in range(min(n, cap)):
             buf = C.create_string_buffer(128)
             L.xm_prof_kernel_name(keys[i], buf, 128)
-            rows.append({"kernel": buf.value.decode(), "ms": ms[i], "flops": fl[i], "launches": int(cnt[i])})
+            rows.append({"kernel": buf.value.decode(), "ms": ms[i], "flops": fl[i], "launches": int(cnt[i]),
+                         "bytes": bytes_of.get(keys[i], 0.0)})
         rows.sort(key=lambda r: -r["ms"])
         if rows:
             d = rows[0]
@@ -454,6 +487,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(ach, 2),
                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        # x + f + y (+ residual) of the kernel's launches, every operand once, per launch: what the
+                        # PMC `traffic` (same unit) is to be compared with
+                        "algorithmic_bytes": int(d["bytes"] / max(1, d["launches"])),
                         "traffic_source": tsrc, "traffic_profile_commit": tcommit,
                         "mode": "serial pass (one stream): launch durations of isolated kernels",
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
@@ -469,6 +505,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and F == 1:
         cpu = cpu_baseline(wl, args.cpu_pairs, W)
+
+    # ---- north_star configuration (bounded second pass, child process: its own nets and tuning lookups) --------
+    north = None
+    want_ns = args.north_star == 1 or (args.north_star < 0 and wl == "distill" and world == 1 and F == 1 and
+                                       not args.per_gpu_batch and args.teacher == "resnet50" and not args.serial
+                                       and W == 300 and not args.teacher_batch)
+    if rank == 0 and world == 1 and want_ns:
+        north = north_star_pass()
 
     if wl == "distill":
         gflop_unit = F * GFLOP["%s_fwd" % args.teacher] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
@@ -491,12 +535,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"distill": "run_distillation step: frozen %s-ferplus teacher fwd -> " % args.teacher +
-                                               "VGGVox student fwd+bwd, soft-target CE T=2, SGD (BASELINE config 4 shard)" +
-                                               ("" if F == 1 else "; %d face frames per pair, max-aggregated" % F),
+            "config": {"workload": {"distill": "BASELINE config 4 shard: frozen %s teacher fwd + VGGVox student fwd/bwd/SGD" % args.teacher +
+                                               ("" if F == 1 else ", %d frames/pair" % F),
                                     "student": "VGGVox student fwd+bwd+update (BASELINE config 2)",
                                     "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",
                                     "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
+                       "step": "run_distillation.m:170-182: teacher logits -> soft-target CE (T=2) -> backward -> "
+                               "ParameterServer sum -> SGD-momentum",
                        "per_gpu_batch": nb, "global_batch": units, "face": "224x224x3",
                        "teacher_batch": nb * (tmult if wl == "distill" else 1),
                        "spectrogram": "512x%dx1" % W, "parallelism": "dp%d" % world,
@@ -510,6 +555,8 @@ def main():
             "settle_steps": settle, "windows": windows, "rccl_ranks": rccl_ranks,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if north is not None:
+            out["north_star_b256"] = north
     if os.environ.get("XM_TUNE_SAVE") and rank == 0:
         vl.tune_save()          # persist the tile choices measured in this run (tools/collect_profiles.sh)
     # tear the process group down BEFORE printing: RCCL writes its banner / teardown lines to stdout
@@ -529,6 +576,27 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def north_star_pass(steps=12, warmup=3):
+    """north_star: "SENet50-teacher + VGGVox-student distillation step at batch 256" on this one GPU, timed by the same
+    code (a child `bench.py --teacher senet50 --per-gpu-batch 256`: `steps` timed steps after the usual warm-up /
+    settle phase) so that it falls inside the driver's clock around this invocation."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--teacher", "senet50", "--per-gpu-batch", "256", "--steps",
+           str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-roofline", "--north-star", "0"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XM_DEBUG_DIST", "XM_BENCH_MARKS"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, env=env, check=True)
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:80])}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "settle_steps": d["settle_steps"], "per_gpu_batch": 256, "teacher": "senet50-ferplus",
+            "model_frac": d["model_frac_of_fp32_mfma_peak"], "model_tflops": d["model_tflops_per_gpu"],
+            "note": "same step code, SE-ResNet50 teacher fwd + student fwd/bwd/SGD on 256 pairs, one GPU"}
+
+
 def _cpu_teacher(name, n, heads=False):
     """oracle fp32 path (MatConvNet's CPU algorithm: im2row + SGEMM per image) over the oracle's own graph tables"""
     from oracle import graphs as G
@@ -544,15 +612,9 @@ def _cpu_teacher(name, n, heads=False):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(wl, pairs, W):
-    """MatConvNet-CPU-equivalent restatement (oracle fp32 path: im2row + vectorised SGEMM, images in parallel,
-    OpenMP on all host cores) on a bounded sample of the same workload.  Checker code used as a timed baseline
-    only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv would be faster still (this
-    SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an upper bound."""
+def _cpu_pass(wl, pairs, W):
+    """one timed pass of the oracle's fp32 path over `pairs` units of the workload; returns (seconds, GFLOP)"""
     from oracle import oracle as O, graphs as G
-    cores = O.set_num_threads()          # one thread per physical core this process may use
-    if pairs <= 0:
-        pairs = max(16, cores // 4)
     t_total, gflop = 0.0, 0.0
     if wl in ("distill", "teacher", "joint"):
         name = "resnet50-ferplus" if wl == "distill" else "senet50-ferplus"
@@ -581,11 +643,29 @@ def cpu_baseline(wl, pairs, W):
                 O.sgd_update(P[k], np.zeros_like(P[k]), d.reshape(P[k].shape, order="F"), 1e-4, 0.9, 5e-4, pairs)
         t_total += time.perf_counter() - t0
         gflop += pairs * GFLOP["student_fwd_bwd_300"] * (W / 300.0)
-    return {"value": round(pairs / t_total, 4), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",
-            "cores": cores, "kind": "port", "cpu": host_info(), "gflops": round(gflop / t_total, 1),
-            "sample": "%d unit(s) of the same workload, oracle fp32 path (im2row + vectorised SGEMM, images in "
-                      "parallel, OpenMP x %d), %.1f s; MatConvNet-CPU-equivalent restatement, not MatConvNet"
-                      % (pairs, cores, t_total)}
+    return t_total, gflop
+
+
+def cpu_baseline(wl, pairs, W, passes=3):
+    """MatConvNet-CPU-equivalent restatement (oracle fp32 path: im2row + vectorised SGEMM, images in parallel,
+    OpenMP, one thread pinned to each physical core -- OMP_PLACES / OMP_PROC_BIND are set in main() before any
+    OpenMP runtime starts) on a bounded sample of the same workload: `passes` timed passes, the MEDIAN is the value,
+    min / max are in the line (a shared host moved single passes by 30 % between boxes).  Checker code used as a timed
+    baseline only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv would be faster still
+    (this SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an upper bound."""
+    from oracle import oracle as O
+    cores = O.set_num_threads()          # one thread per physical core this process may use
+    if pairs <= 0:
+        pairs = max(16, cores // 8)
+    runs = [_cpu_pass(wl, pairs, W) for _ in range(max(1, passes))]
+    ts = sorted(t for t, _ in runs)
+    med, gflop = ts[len(ts) // 2], runs[0][1]
+    return {"value": round(pairs / med, 4), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",
+            "cores": cores, "kind": "port", "cpu": host_info(), "gflops": round(gflop / med, 1),
+            "passes": len(ts), "min": round(pairs / ts[-1], 4), "max": round(pairs / ts[0], 4),
+            "sample": "median of %d passes over %d unit(s) of the same workload (%.1f s in all), oracle fp32 path: "
+                      "im2row + vectorised SGEMM, OpenMP x %d pinned to physical cores; a restatement, not MatConvNet"
+                      % (len(ts), pairs, sum(ts), cores)}
 
 
 def cpu_teacher_line(args):

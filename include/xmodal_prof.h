@@ -13,6 +13,8 @@ extern "C" {
 int xm_prof_enable(int on);
 /* after the stream has been synchronised: per-kernel totals; returns #distinct kernels */
 int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, long long *launches);
+/* algorithmic HBM bytes (x + f + y [+ residual], every operand once) of the recorded launches, per kernel */
+int xm_prof_collect_bytes(int cap, int *keys, double *total_bytes);
 /* name of a key, identical to the kernel name rocprofv3 --kernel-trace prints (sans namespace) */
 int xm_prof_kernel_name(int key, char *buf, int len);
 /* test hooks: force one tile configuration for every convolution launch (-1 = automatic) */

@@ -99,6 +99,7 @@ _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           "xm_prof_enable": [_i],
           "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_longlong)],
+          "xm_prof_collect_bytes": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)],
           "xm_prof_kernel_name": [_i, C.c_char_p, _i]}
 
 _lib = None

@@ -118,14 +118,37 @@ class SyntheticEmoVoxImdb:
         return self._dev
 
 
+def crop_window(total_samples, audSamp, fs, num_logit_rows, rng, fixedSegments=False, timeOffset=None):
+    """(wr, startIdx, endIdx) of one clip, all 1-based as in cnn_get_batch_wav_emo (getBatchEmoVoxCeleb.m:81-152):
+    wr is the first sample audioread takes, [startIdx, endIdx] the rows of the cached logits that are aggregated.
+      random crop (:109-119):  total = min(19.9 fs, total) (:81-89);  wd = total - audSamp;
+                               wd >= 1: wr = randi(wd) in [1, wd];  else wr = 1 (short clip, zero padded)
+                               starttime = wr / fs, endtime = (wr + audSamp - 1) / fs (:141-142) -- wr enters 1-BASED --
+                               rows time2idx(starttime) .. min(time2idx(endtime), #rows) (:145-152)
+      fixedSegments (:91-101): wr = timeOffset * fs + 1, every row of the clip's logits (:136-137)."""
+    if fixedSegments:
+        if timeOffset is None:
+            raise IndexError("fixedSegments: timeOffsets is empty (Index exceeds matrix dimensions upstream, :92)")
+        return int(round(timeOffset * fs)) + 1, 1, int(num_logit_rows)
+    total = min(int(total_samples), int(19.9 * fs))
+    wd = total - int(round(audSamp))
+    wr = int(rng.integers(1, wd + 1)) if wd >= 1 else 1
+    s, e = time2idx(wr / fs), time2idx((wr + audSamp - 1) / fs)
+    return wr, s, min(e, int(num_logit_rows))
+
+
 def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, logitAggregator="max",
                         lossType="hot-cross-ent", transformation="I", rng=None, spec_source=None,
-                        device=None, use_wav=False):
+                        device=None, use_wav=False, fixedSegments=False, timeOffsets=None):
     """inputs = getBatchEmoVoxCeleb(imdb, batch, ...) -> ['data', im, 'logitTarget', lgo,
     'maxLabel', maxLabel] (getBatchEmoVoxCeleb.m:31-43).  Spectrogram magnitudes come from
     `spec_source` (H x W x 1 x N device tensor), from the imdb's waveforms through the device
     front-end (`use_wav`: crop [wr, wr+audSamp) with zero padding of short clips :109-119, runSpec
-    :162), or from a seeded half-normal generator."""
+    :162), or from a seeded half-normal generator.
+    `fixedSegments` (:91-101, :136-137; off upstream, run_distillation.m:86): the crop of clip k starts at
+    timeOffsets[k] seconds, clips are not thresholded to DATASET_LIMIT, and ALL cached logit rows of the clip are
+    aggregated.  (Upstream always passes timeOffsets = [] (:15), so the branch cannot run there; an offset list is
+    required here.)"""
     device = device or torch.device("cuda", torch.cuda.current_device())
     rng = rng or np.random.default_rng(0)
     batch = list(batch)
@@ -139,13 +162,9 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
     for k, ii in enumerate(batch):
         # getBatchEmoVoxCeleb.m:81-89: no clip of the dataset is longer than DATASET_LIMIT = 19.9 s; the sample count
         # is thresholded accordingly (the cached teacher logits end there too)
-        total = min(int(imdb.num_samples[ii]), int(19.9 * imdb.fs))
-        wr = int(rng.integers(0, max(total - int(audSamp), 0) + 1))  # random crop start (:109-119)
-        crops.append((ii, wr))
-        starttime = wr / imdb.fs
-        endtime = (wr + audSamp - 1) / imdb.fs
-        s, e = time2idx(starttime), time2idx(endtime)
-        e = min(e, imdb.wavLogits[ii].shape[0])  # :152
+        wr, s, e = crop_window(int(imdb.num_samples[ii]), audSamp, imdb.fs, imdb.wavLogits[ii].shape[0], rng,
+                               fixedSegments, None if timeOffsets is None else timeOffsets[k])
+        crops.append((ii, wr - 1))        # 0-based slice start of audioread(audfile, [wr wr+audSamp-1])
         first[k], last[k] = offs[ii] + s, offs[ii] + e
     if spec_source is None and use_wav:
         L = int(round(audSamp))

@@ -271,6 +271,7 @@ struct ProfRec {
   hipEvent_t start, stop;
   int key;  // kind * 100 + cfg * 2 + check
   double flops;
+  double bytes;  // algorithmic HBM bytes of the launch: every operand once (x + f + y [+ residual])
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -290,10 +291,11 @@ struct ProfScope {
   bool on;
   ProfRec r;
   hipStream_t st;
-  ProfScope(int key, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+  ProfScope(int key, double flops, hipStream_t s, double bytes = 0) : on(g_prof_on), st(s) {
     if (!on) return;
     r.key = key;
     r.flops = flops;
+    r.bytes = bytes;
     r.start = prof_event();
     r.stop = prof_event();
     (void)hipEventRecord(r.start, st);
@@ -326,7 +328,9 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   a.dbgCycles = g_dbg_cycles;
   dim3 grid(a.nbm * a.nbn, splits);
   {
-    ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st);
+    const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
+    ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st,
+                 abytes);
     if (is_dma_cfg(ci)) {
       // persistent: one round of co-resident blocks (a multiple of 8 so that every XCD gets the same share)
       static const int per_cu_tab[] = XM_DMA_PERCU;          // co-resident blocks per CU (LDS-limited)
@@ -373,7 +377,7 @@ static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipS
   const Cfg &c = kCfgs[ci];
   ConvGemmMulti m{};
   int maxTiles = 0;
-  double flops = 0;
+  double flops = 0, abytes = args.empty() ? 0.0 : (double)args[0].xBytes;   // the classes share one source tensor
   for (size_t i = 0; i < args.size(); ++i) {
     ConvGemmArgs a = args[i];
     a.nbm = (a.M + c.bm() - 1) / c.bm();
@@ -384,10 +388,11 @@ static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipS
     a.slab = nullptr;
     maxTiles = std::max(maxTiles, a.nbm * a.nbn);
     flops += a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue;
+    abytes += 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
     m.c[i] = a;
   }
   {
-    ProfScope ps(2 * 100 + ci * 2, flops, st);
+    ProfScope ps(2 * 100 + ci * 2, flops, st, abytes);
     launch_gemm_multi_cfg(ci, m, dim3(maxTiles, 1, (unsigned)args.size()), st);
   }
   XM_LAUNCH_CHECK();
@@ -1166,7 +1171,8 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
     a.splitStride = slab;
     {
       const int av = wgrad_av(a);
-      ProfScope ps(1 * 100 + ci * 4 + (av == 4 ? 2 : av == 2 ? 1 : 0), 2.0 * g.Kg * (double)NP * g.R, st);
+      ProfScope ps(1 * 100 + ci * 4 + (av == 4 ? 2 : av == 2 ? 1 : 0), 2.0 * g.Kg * (double)NP * g.R, st,
+                   (double)a.xBytes + (double)a.dyBytes + 4.0 * g.Kg * g.R);
       launch_wgrad_cfg(ci, a, dim3(nbm * nbn, splits), st);
     }
     XM_LAUNCH_CHECK();
@@ -1314,6 +1320,27 @@ int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, l
     total_ms[i] = ms[i];
     total_flops[i] = fl[i];
     launches[i] = cnt[i];
+  }
+  return (int)ks.size();
+}
+
+// algorithmic bytes (every operand once) summed per kernel instantiation, same order / keys as xm_prof_collect
+int xm_prof_collect_bytes(int cap, int *keys, double *total_bytes) {
+  std::vector<int> ks;
+  std::vector<double> by;
+  for (auto &r : g_prof) {
+    size_t i = 0;
+    for (; i < ks.size(); ++i)
+      if (ks[i] == r.key) break;
+    if (i == ks.size()) {
+      ks.push_back(r.key);
+      by.push_back(0);
+    }
+    by[i] += r.bytes;
+  }
+  for (size_t i = 0; i < ks.size() && (int)i < cap; ++i) {
+    keys[i] = ks[i];
+    total_bytes[i] = by[i];
   }
   return (int)ks.size();
 }

@@ -452,6 +452,7 @@ class DagNN:
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
+        self.markHook = None     # diagnostics: callable(label) at the phase boundaries of eval (bench.py XM_BENCH_MARKS)
         self._side_pending = False
         self._training = False
         self.prepareBackward = os.environ.get("XM_NO_PREPARE") is None   # dgrad filter transposition during forward
@@ -654,6 +655,8 @@ class DagNN:
             # previous step's xm_sgd_update / backward pass), so the side stream must not start before them
             self.wgradStream.wait_stream(torch.cuda.current_stream())
         pending = dict(input_events or {})
+        mark = self.markHook or (lambda label: None)
+        mark("fwd0")
         for step in plan:
             if pending:
                 recs = [step.rec] + [getattr(step, n) for n in ("relu_rec", "pool_rec", "bn_rec", "sum_rec")
@@ -664,6 +667,7 @@ class DagNN:
                         if ev is not None:
                             torch.cuda.current_stream().wait_event(ev)
             step.forward(self)
+        mark("fwd1")
         if derOutputs is None:
             return
         for k, d in derOutputs.items():
@@ -682,9 +686,11 @@ class DagNN:
         self._pending_param_ders = {}
         for step in reversed(plan):
             step.backward(self)
+        mark("bwd1")
         if self._side_pending:
             torch.cuda.current_stream().wait_stream(self.wgradStream)
             self._side_pending = False
+        mark("join")
 
     # helpers used by the plan steps
     def _set_var_der(self, name, d):

@@ -31,8 +31,6 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
         miniEpochRatio = 0.05 * len(gpus)                      # :77
     if learningRate is None:
         learningRate = np.logspace(-4, -5, numEpochs)          # :87
-    if fixedSegments:
-        raise NotImplementedError("fixedSegments (deterministic crops) is not built")
     if imdb is None:
         imdb = xbatch.SyntheticEmoVoxImdb(num_tracks=numTracks, seed=seed, num_emotions=8,
                                           min_seconds=numSeconds + 0.5, max_seconds=numSeconds + 5.0,
@@ -59,7 +57,8 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
         return xbatch.getBatchEmoVoxCeleb(imdb_, batch, imageSize=(512, int(round(numSeconds * 100))),
                                           numPredEmotions=numPredEmotions, logitAggregator=logitAggregator,
                                           lossType=lossType, transformation=net.meta["augmentation"]["transformation"],
-                                          rng=brng)
+                                          rng=brng, fixedSegments=fixedSegments)   # bopts.fixedSegments, :220
+        # (fixedSegments = true fails upstream as well: getBatchEmoVoxCeleb.m:15 passes timeOffsets = [])
 
     return train.cnn_train_dag(net, imdb, getBatch, learningRate=learningRate, batchSize=batchSize,
                                numEpochs=numEpochs, train=trainSamples, val=valSamples, cont=cont,

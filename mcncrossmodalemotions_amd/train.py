@@ -275,6 +275,8 @@ def train_step(net, inputs, opts, epoch=0, parserv=None, global_batch=None, inpu
     net.gradHook = None
     lr = float(opts.learningRate[min(epoch, len(opts.learningRate) - 1)])
     accumulate_gradients(net, opts, lr, global_batch, float(global_batch) if exchange else 1.0)
+    if net.markHook is not None:
+        net.markHook("upd")
 
 
 def extractStats(stats, net):

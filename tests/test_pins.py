@@ -94,3 +94,46 @@ def test_student_macs_match_survey():
             h = O.conv_out_size(h, 0, 0, b.poolSize[0], 1, b.stride[0])
             w = O.conv_out_size(w, 0, 0, b.poolSize[1], 1, b.stride[1])
     assert abs(macs - 2.8311e9) / 2.8311e9 < 1e-3
+
+
+def test_crop_window_is_one_based():
+    """getBatchEmoVoxCeleb.m:109-119,141-152: wr = randi(wd) lies in [1, wd] and enters starttime = wr / fs as a
+    1-BASED sample number; a short clip uses wr = 1; the window of logit rows is time2idx(start) .. time2idx(end),
+    clipped to the rows that exist.  Hand-computed boundary: time2idx steps from 1 to 2 at t = 0.28 s, i.e. at
+    sample 4480 -- a 0-based draw (wr = 4479) would still map to row 1."""
+    fs, aud = 16000, batch.aud_samples(300)
+
+    class Fixed:                       # stands in for randi: returns the requested draw
+        def __init__(self, v):
+            self.v = v
+
+        def integers(self, lo, hi):
+            assert lo == 1, "randi(wd) draws from 1"
+            self.hi = hi
+            return self.v
+    total = 8 * fs
+    r = Fixed(4480)
+    wr, s, e = batch.crop_window(total, aud, fs, 40, r)
+    assert r.hi == total - 48384 + 1                     # numpy's exclusive upper bound: draws reach wd
+    assert (wr, s) == (4480, 2)                          # 4480 / 16000 = 0.28 s -> floor((7 - 1) / 6) + 1 = 2
+    assert e == batch.time2idx((4480 + 48384 - 1) / fs) == 14
+    wr, s, e = batch.crop_window(total, aud, fs, 40, Fixed(4479))
+    assert (wr, s) == (4479, 1)
+    # endIdx is clipped to the cached rows (:152)
+    assert batch.crop_window(total, aud, fs, 9, Fixed(4480))[2] == 9
+    # short clip: wr = 1, never a draw (:113-118)
+    class NoDraw:
+        def integers(self, lo, hi):
+            raise AssertionError("no random draw for a short clip")
+    assert batch.crop_window(2 * fs, aud, fs, 40, NoDraw()) == (1, 1, batch.time2idx((1 + 48384 - 1) / fs))
+    # clips are thresholded at DATASET_LIMIT = 19.9 s before the draw (:81-89)
+    r = Fixed(1)
+    batch.crop_window(30 * fs, aud, fs, 200, r)
+    assert r.hi == int(19.9 * fs) - 48384 + 1
+    # fixedSegments (:91-101,136-137): wr = offset * fs + 1, all rows; upstream's empty timeOffsets is an index error
+    assert batch.crop_window(30 * fs, aud, fs, 77, None, True, 2.5) == (40001, 1, 77)
+    try:
+        batch.crop_window(30 * fs, aud, fs, 77, None, True, None)
+        assert False
+    except IndexError:
+        pass
