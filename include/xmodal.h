@@ -47,7 +47,8 @@ enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
- * XM_EINVAL without a communicator.  A binding checks xm_version() >= the revision it was written against. */
+ * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments (additions never change the revision's meaning
+ * for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -93,6 +94,15 @@ int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const fl
                             int FW, int FC, int K, const float *b, float *y, int sy, int sx,
                             int pt, int pb, int pl, int pr, int dy, int dx, const float *scale,
                             const float *shift, const float *residual, int flags, void *stream);
+/* Extension: Y = vl_nnconv(X, F, B, ...) AND the batch moments of Y that a train-mode vl_nnbnorm(Y, G, B) would
+ * compute first -- moments_out (K x 2, column-major) = [mean_k, sqrt(var_k + epsilon)] over H x W x N, biased
+ * variance (emoVoxZoo.m:118-123: every dagnn.Conv of the student is followed by dagnn.BatchNorm).  Hand them to
+ * xm_nnbnorm_forward_fused / xm_nnbnorm_relu_pool_forward as `moments_in` and to the backward calls with
+ * XM_BN_BATCH_MOMENTS / train = 1: same results as letting vl_nnbnorm compute them, minus one pass over Y (462 MB
+ * for the student's first layer at 32 spectrograms) -- the per-channel sums ride in the GEMM epilogue. */
+int xm_nnconv_forward_moments(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                              int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                              int pl, int pr, int dy, int dx, float epsilon, float *moments_out, void *stream);
 /* [DX, DF, DB] = vl_nnconv(X, F, B, DZDY, ...); dx_out / df_out / db_out may be NULL
  * (= 'NoDerData' / 'NoDerFilters' / 'NoDerBiases'). */
 int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -162,6 +162,40 @@ bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ d
   if (lane == 0) db[k] = (float)s;
 }
 
+// batch moments from the convolution epilogue's partial sums (ConvGemmArgs::statPart, [row][ncg] pairs of fp32
+// {sum, sum of squares} over <= 128 values each): fp64 accumulation over the column groups in a fixed order.
+// mom = [mean, sqrt(var + eps)] (C x 2).  One block per channel.
+__global__ void __launch_bounds__(256)
+conv_stats_finalize_kernel(const float *__restrict__ part, float *__restrict__ mom, int M, int ncg, double m,
+                           float eps) {
+  const int c = blockIdx.x;
+  const float2 *p = reinterpret_cast<const float2 *>(part) + (size_t)c * ncg;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < ncg; i += 256) {
+    const float2 v = p[i];
+    a += (double)v.x;
+    b += (double)v.y;
+  }
+  a = xm_wave_sum_d(a);
+  b = xm_wave_sum_d(b);
+  __shared__ double red[8];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[w] = a;
+    red[4 + w] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    const double mu = a / m;
+    double var = b / m - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    mom[c] = (float)mu;
+    mom[M + c] = (float)sqrt(var + (double)eps);
+  }
+}
+
 // ---- tile configuration ---------------------------------------------------------------------
 struct Cfg {
   int tm, tn, wgm, wgn;
@@ -722,9 +756,12 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
   return XM_OK;
 }
 
+// moments_out != NULL: also the batch moments [mean, sqrt(var + eps)] of Y (the statistics half of the train-mode
+// vl_nnbnorm that follows the convolution), from per-wave partial sums of the GEMM epilogue when the launch allows it
+// (16-byte-store epilogue, no split-K, no filter groups), else by a pass over Y.
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
-                        hipStream_t st) {
+                        hipStream_t st, float *moments_out = nullptr, float eps = 0.f) {
   // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
   // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
   const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
@@ -750,8 +787,13 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   const bool dma_ok = !need_pad && mode == 0 && g.FH == 1 && g.FW == 1 && g.sy == 1 && g.sx == 1 && g.dy == 1 &&
                       g.dx == 1 && (g.H * g.W) % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)f & 15) == 0 &&
                       g.R % kBK == 0 && getenv("XM_NO_DMA") == nullptr;
+  static const bool no_fstats = getenv("XM_NO_FUSED_STATS") != nullptr;
+  const bool want_stats = moments_out != nullptr && g.G == 1 && !no_fstats;
+  // partial sums: one {sum, sum sq} pair per row and per 32-pixel column group at the finest (TN = 1)
+  const size_t statf = want_stats ? (size_t)2 * g.K * ((proto.NP + 31) / 32) : 0;
   WsCarver ws;
-  int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4), st);
+  int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4) +
+                       WsCarver::need(statf, 4), st);
   if (rc) return rc;
   const int2 *taps = fwd_taps2(g, Rp, bigTaps);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
@@ -767,6 +809,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     lda = Rp;
   }
   float *slab = slabf ? ws.take<float>(slabf) : nullptr;
+  float *statp = statf ? ws.take<float>(statf) : nullptr;
+  bool stats_done = false;
   const size_t xTotal = (size_t)g.H * g.W * g.C * g.N;
   for (int grp = 0; grp < g.G; ++grp) {
     ConvGemmArgs a{};
@@ -816,19 +860,37 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     // of 32 pixels; 16-byte alignment of (y, residual) rows needs Ho*Wo % 4 == 0
     a.vecStore = ((g.Ho * g.Wo) % 4 == 0 && (((uintptr_t)a.Y | (uintptr_t)a.resid) & 15) == 0) ? 1 : 0;
     a.dmaOk = (dma_ok && a.vecStore) ? 1 : 0;   // the LDS-DMA kernel only carries the 16-byte-store epilogue
+    const bool stats_ok = want_stats && a.vecStore && !relu && !resid;
+    if (stats_ok) a.dmaOk = 0;                  // the partial sums ride in the register-staged kernel's epilogue
     a.aBytes = (unsigned)((size_t)g.Kg * lda * 4);
     a.tapStride = (unsigned)((size_t)g.H * g.W * 4);
+    int stat_ncg = 0;
     auto run = [&](int ci) {
       int sp;
+      ci = a.dmaOk ? ci : base_cfg(ci);
       gemm_slab_floats(a, ci, &sp);
       ConvGemmArgs aa = a;
+      stat_ncg = 0;
+      if (stats_ok && sp == 1 && (g_force_splits <= 1)) {
+        const Cfg &c = kCfgs[ci];
+        stat_ncg = ((a.NP + c.bn() - 1) / c.bn()) * c.wgn;
+        aa.statPart = statp;
+        aa.statNcg = stat_ncg;
+      }
       return launch_gemm(aa, mode, ci, sp, slab, st);
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
     rc = run(ci);
     if (rc) return rc;
+    if (stat_ncg > 0) {
+      hipLaunchKernelGGL(conv_stats_finalize_kernel, dim3(g.K), dim3(256), 0, st, statp, moments_out, g.K, stat_ncg,
+                         (double)a.NP, eps);
+      XM_LAUNCH_CHECK();
+      stats_done = true;
+    }
   }
+  if (moments_out && !stats_done) return bn_batch_moments(y, g.Ho, g.Wo, g.K, g.N, eps, moments_out, st);
   return XM_OK;
 }
 
@@ -1381,6 +1443,21 @@ int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const fl
   rc = conv_forward(x, f, b, y, g, scale, shift, residual, (flags & XM_FUSE_RELU) ? 1 : 0, st);
   if (rc || !(flags & XM_FUSE_SIGMOID)) return rc;
   return xm_nnsigmoid(y, (size_t)g.Ho * g.Wo * g.K * g.N, nullptr, y, stream);  // in place (elementwise)
+}
+
+int xm_nnconv_forward_moments(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                              int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                              int pl, int pr, int dy, int dx, float epsilon, float *moments_out, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!x || !f || !y || !moments_out) return fail(XM_EINVAL, "vl_nnconv(+moments): NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  if (fc_skinny_ok(g)) {
+    rc = fc_skinny_forward(x, f, b, y, g, 0, st);
+    return rc ? rc : bn_batch_moments(y, g.Ho, g.Wo, g.K, g.N, epsilon, moments_out, st);
+  }
+  return conv_forward(x, f, b, y, g, nullptr, nullptr, nullptr, 0, st, moments_out, epsilon);
 }
 
 int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -61,6 +61,11 @@ struct ConvGemmArgs {
   int vecStore;       // 1: 4 consecutive pixels are contiguous & 16-B friendly -> dwordx4 epilogue
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
+  // != NULL (vecStore, no split-K, not the LDS-DMA kernel): every wave also leaves {sum, sum of squares} of the values
+  // it stores, per row and per column group (the 32 * TN pixels of the wave): statPart[row][statNcg][2].  The batch
+  // moments of the train-mode bnorm that follows the convolution then cost no second pass over Y (conv_forward).
+  float *statPart;
+  int statNcg;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
   unsigned long long *dbgCycles;  // debug (xm_debug_conv_cycles): per-block {first clock, last clock, HW_ID, XCC_ID}
 };
@@ -116,6 +121,18 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int iq) {
   t0 = dpp_quad(t0, 0);
   t1 = dpp_quad(t1, 0);
   if (b1) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
+}
+
+// sum over the 8 lanes l31 = iq + 4 q (q = 0..7) of each 32-lane half: two DPP rotations inside the 16-lane rows, one
+// swizzle across the two rows.  Every lane ends up with the sum of its residue class iq = l31 & 3.
+__device__ __forceinline__ float quad_class_sum8(float x) {
+  int xi = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x124, 0xF, 0xF, false));   // row_ror:4
+  xi = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false));   // row_ror:8
+  xi = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(xi, 0x401F));                      // lane ^ 16
+  return x;
 }
 
 // sched_group_barrier masks
@@ -300,6 +317,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
       // compiler's vmcnt(0) in front of its use wait for those stores as well (in-order counter).
       // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
       // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
+      float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // a.statPart: this lane's share per row
       f32x4 rv[ASMST ? 4 : 1][ASMST ? TN : 1];
       if (ASMST && a.resid) {
 #pragma unroll
@@ -327,6 +345,10 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
               else
                 o += *reinterpret_cast<const f32x4 *>(a.resid + offs[g4][j]);
             }
+            if (!ASMST && a.statPart) {
+              st1[g4] += (o.x + o.y) + (o.z + o.w);
+              st2[g4] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            }
             if (a.relu) {
               o.x = fmaxf(o.x, 0.f);
               o.y = fmaxf(o.y, 0.f);
@@ -339,6 +361,17 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
             xm_st16<ASMST>(a.Y + offs[g4][j], o);
 #endif
           }
+        }
+      }
+      if (!ASMST && a.statPart) {
+        // lanes iq + 4 q of a half hold pixel quads of the SAME row: sum them, lanes q == 0 store the wave's partial
+        const int cg = bn * WGN + wn;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float u = quad_class_sum8(st1[g4]), v = quad_class_sum8(st2[g4]);
+          const int row = wbase + i * 32 + 8 * g4 + 4 * half + iq;
+          if ((l31 >> 2) == 0 && row < a.M)
+            *reinterpret_cast<float2 *>(a.statPart + ((size_t)row * a.statNcg + cg) * 2) = make_float2(u, v);
         }
       }
     }

@@ -253,6 +253,22 @@ static int bn_check(int H, int W, int C, int N) {
   return XM_OK;
 }
 
+int bn_batch_moments(const float *x, int H, int W, int C, int N, float eps, float *moments_out, hipStream_t st) {
+  int rc = bn_check(H, W, C, N);
+  if (rc) return rc;
+  const int HW = H * W, S = bn_splits(C, N);
+  WsCarver ws;
+  rc = ws.init(WsCarver::need((size_t)2 * C * S, 8), st);
+  if (rc) return rc;
+  double *part = ws.take<double>((size_t)2 * C * S);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, S), dim3(256), 0, st, x, part, HW, C, N, S, bn_run_div(HW));
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, part, moments_out, HW, C, S,
+                     (double)HW * N, eps);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int bnorm_forward(const float *x, int H, int W, int C, int N, const float *g, const float *b,
                          float eps, const float *moments_in, float *y, float *moments_out, int relu,
                          hipStream_t st) {
@@ -274,7 +290,7 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
                        C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
-  } else if (moments_out) {
+  } else if (moments_out && moments_out != moments_in) {
     XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
   }
   size_t total = (size_t)HW * C * N;
@@ -314,7 +330,7 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
                        C, S, (double)HW * N, eps);
     XM_LAUNCH_CHECK();
     mom = momw;
-  } else if (moments_out) {
+  } else if (moments_out && moments_out != moments_in) {
     XM_HIP(hipMemcpyAsync(moments_out, moments_in, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, st));
   }
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, x, dzdy, yfwd, mom, part, HW,

@@ -59,6 +59,10 @@ struct WsCarver {
 // persistent small device objects keyed by content (tap tables)
 const void *cached_device_table(const void *host, size_t bytes);
 
+// batch moments of vl_nnbnorm [mean, sqrt(var + eps)] (C x 2) by a pass over x (norm_pool.hip) -- what the fused
+// convolution epilogue of conv.hip replaces when its tile configuration cannot carry the partial sums
+int bn_batch_moments(const float *x, int H, int W, int C, int N, float eps, float *moments_out, hipStream_t st);
+
 static inline int out_size(int in, int pa, int pb, int f, int d, int s) {
   int feff = (f - 1) * d + 1;
   int t = in + pa + pb - feff;

@@ -112,11 +112,18 @@ class BatchNorm(Layer):
         self.numChannels = int(numChannels)
         self.epsilon = float(epsilon)
         self.moments = None  # last batch moments (train mode), the 'der' of the moments param
+        self._pre_moments = None  # batch moments of the input, left by the producing convolution's epilogue
+
+    def take_pre_moments(self):
+        """batch moments the producing Conv step already computed for this eval (vl_nnconv moments_out), or None"""
+        pre, self._pre_moments = self._pre_moments, None
+        return pre
 
     def forward(self, inputs, params, relu=False):
         test = self.net is not None and self.net.mode == "test"
+        pre = None if test else self.take_pre_moments()
         y, mom = vl.vl_nnbnorm(inputs[0], params[0], params[1], epsilon=self.epsilon,
-                               moments=params[2] if test else None, relu=relu)
+                               moments=params[2] if test else pre, relu=relu, moments_out=pre)
         self.moments = None if test else mom
         return [y]
 
@@ -449,6 +456,7 @@ class DagNN:
         self.conserveMemory = True
         self.accumulateParamDers = False
         self.fuse = True  # MI355X peephole fusion (results identical)
+        self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
@@ -756,6 +764,7 @@ class _Step:
     def __init__(self, rec):
         self.rec = rec
         self.bias_from = None  # fused consumer step that already produced this conv's bias derivative
+        self.moments_for = None  # _LayerRec of the train-mode BatchNorm this conv step computes the batch moments for
 
     def _params(self, net):
         return [net.params[p].value for p in self.rec.params]
@@ -770,7 +779,19 @@ class _Step:
             with torch.cuda.stream(net.wgradStream):
                 vl.conv_prepare_backward(ins[0], self._params(net)[0], stride=r.block.stride, pad=r.block.pad,
                                          dilate=r.block.dilate)
-        outs = r.block.forward(ins, self._params(net))
+        bn = self.moments_for
+        if bn is not None and net._training and net.mode != "test" and net.fuseStats:
+            # the train-mode bnorm that consumes this convolution needs the batch moments of its output: the GEMM
+            # epilogue leaves them (straight in the flat derivative slot of the moments parameter when there is one)
+            do = net._direct_der(bn)
+            mo = do[2] if do else vl.mat_empty(bn.block.numChannels, 2, device=ins[0].device)
+            prm = self._params(net)
+            blk = r.block
+            outs = [vl.vl_nnconv(ins[0], prm[0], prm[1] if blk.hasBias else None, stride=blk.stride, pad=blk.pad,
+                                 dilate=blk.dilate, moments_out=mo, epsilon=bn.block.epsilon)]
+            bn.block._pre_moments = mo
+        else:
+            outs = r.block.forward(ins, self._params(net))
         for v, t in zip(r.outputs, outs):
             net.vars[v].value = t
 
@@ -916,9 +937,10 @@ class _BnReluPoolStep(_Step):
         g, b, mom = self._params(net)
         test = net.mode == "test"
         do = net._direct_der(r) if not test else None
+        pre = None if test else r.block.take_pre_moments()
         y, am, mo = vl.bnorm_relu_pool(x, g, b, pb.poolSize, stride=pb.stride, pad=pb.pad,
-                                       epsilon=r.block.epsilon, moments=mom if test else None,
-                                       moments_out=do[2] if do else None)
+                                       epsilon=r.block.epsilon, moments=mom if test else pre,
+                                       moments_out=pre if pre is not None else (do[2] if do else None))
         r.block.moments = None if test else mo
         self._saved = (am, mo)
         net.vars[self.pool_rec.outputs[0]].value = y
@@ -1090,4 +1112,14 @@ def build_plan(net, training):
     # a fused step may now sit before the producer of one of its operands is scheduled; the
     # `ready` test above guarantees producers precede the conv, so plain order is still valid.
     del produced_before
+    if training:
+        # Conv -> BatchNorm (train mode): the convolution's epilogue computes the batch moments (vl_nnconv
+        # moments_out), the bnorm step -- plain, +relu or +relu+pool -- takes them instead of re-reading its input
+        conv_of = {st.rec.outputs[0]: st for st in steps if type(st) is _Step and isinstance(st.rec.block, Conv)}
+        for st in steps:
+            r = st.rec
+            if isinstance(r.block, BatchNorm) and type(st) in (_Step, _BnReluStep, _BnReluPoolStep):
+                cs = conv_of.get(r.inputs[0])
+                if cs is not None and len(consumers.get(r.inputs[0], [])) == 1:
+                    cs.moments_for = r
     return steps

@@ -135,9 +135,11 @@ def out_size(n, pa, pb, f, d, s):
 
 def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
               no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
-              relu=False, df_out=None, db_out=None, dx_accum=None, sigmoid=False):
+              relu=False, df_out=None, db_out=None, dx_accum=None, sigmoid=False, moments_out=None, epsilon=1e-4):
     """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
 
+    `moments_out` (forward, extension; a K x 2 device matrix): also receives the batch moments [mean, sqrt(var +
+    epsilon)] of Y -- the statistics pass of the train-mode vl_nnbnorm that follows (xm_nnconv_forward_moments).
     `scale/shift/residual/relu/sigmoid` select the fused forward epilogue (extension; see xmodal.h);
     `dx_accum` (backward, extension): DX = dgrad + dx_accum in the dgrad epilogue."""
     x, f = _chk(x, "X"), _chk(f, "F")
@@ -157,7 +159,16 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     if dzdy is None:
         y = mat_empty(max(Ho, 0), max(Wo, 0), K, N, device=x.device)
         fused = scale is not None or residual is not None or relu or sigmoid
-        if fused:
+        if moments_out is not None:
+            if fused:
+                raise ValueError("vl_nnconv: moments_out cannot be combined with a fused epilogue")
+            mo = _chk(moments_out, "MOMENTS")
+            if mo.numel() != 2 * K:
+                raise ValueError("vl_nnconv: moments_out must be %d x 2" % K)
+            _lib.check(L.xm_nnconv_forward_moments(_ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb), _ptr(y),
+                                                   sy, sx, pt, pb, pl, pr, dy, dx, float(epsilon), _ptr(mo),
+                                                   _stream()))
+        elif fused:
             if residual is not None:
                 _chk(residual, "RESIDUAL")
                 if _shape4(residual) != [Ho, Wo, K, N]:

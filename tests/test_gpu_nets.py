@@ -163,10 +163,12 @@ def test_batch_provider(gpu):
     rng = np.random.default_rng(0)
     lg = vl.to_numpy(d["logitTarget"]).reshape(8, 8)
     for k in range(8):
-        total = int(imdb.num_samples[k])
+        total = min(int(imdb.num_samples[k]), int(19.9 * 16000))
         aud = batch.aud_samples(300)
-        wr = int(rng.integers(0, max(total - int(aud), 0) + 1))
+        wd = total - int(round(aud))
+        wr = int(rng.integers(1, wd + 1)) if wd >= 1 else 1       # wr = randi(wd): 1-based (:109-114)
         s, e = O.time2idx(wr / 16000), O.time2idx((wr + aud - 1) / 16000)
+        e = min(e, imdb.wavLogits[k].shape[0])
         ref = O.aggregate_logits(imdb.wavLogits[k], s, e, "max")
         rng.integers(0, 2 ** 31) if k == 7 else None
         assert np.abs(lg[:, k] - ref).max() < 1e-6
@@ -175,9 +177,10 @@ def test_batch_provider(gpu):
     inp2 = batch.getBatchEmoVoxCeleb(imdb, [2, 5], imageSize=(512, 100), rng=rng, use_wav=True)
     rng = np.random.default_rng(1)
     for k, ii in enumerate([2, 5]):
-        L = int(batch.aud_samples(100))
-        wr = int(rng.integers(0, max(int(imdb.num_samples[ii]) - L, 0) + 1))
-        w = imdb.device_wav(ii, inp2[1].device)[wr:wr + L].cpu().numpy()
+        L = int(round(batch.aud_samples(100)))
+        wd = min(int(imdb.num_samples[ii]), int(19.9 * 16000)) - L
+        wr = int(rng.integers(1, wd + 1)) if wd >= 1 else 1
+        w = imdb.device_wav(ii, inp2[1].device)[wr - 1:wr - 1 + L].cpu().numpy()   # audioread(f, [wr wr+L-1])
         ref = O.spec_rownorm(O.run_spec(w))
         close(vl.to_numpy(inp2[1])[:, :, 0, k], ref[:, :, 0, 0], 1e-3, "wav front-end sample %d" % k)
     faces = batch.getImageBatch(4)

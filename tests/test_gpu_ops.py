@@ -197,6 +197,58 @@ def test_conv_all_tile_configs(gpu):
         L.xm_debug_force_conv_cfg(-1)
 
 
+# (H, W, C, N, FH, K, stride, pad, bias offset): Ho*Wo % 4 == 0 -> partial sums in the GEMM epilogue; otherwise (and
+# with split-K / groups / skinny layers) the moments come from a pass over Y -- same contract either way
+MOMENT_CASES = [(19, 15, 12, 3, 3, 100, 1, 1, 0.0),      # 285 pixels / sample: scalar-store epilogue -> fallback pass
+                (20, 16, 12, 3, 3, 100, 1, 1, 0.0),      # 320 pixels / sample: fused partial sums, M and pixel tails
+                (20, 16, 12, 3, 3, 100, 1, 1, 25.0),     # mean >> sigma: cancellation in E[y^2] - mean^2
+                (41, 32, 1, 3, 7, 24, 2, 1, 0.0),        # student conv1 shape (C = 1, stride 2)
+                (8, 8, 64, 4, 1, 48, 1, 0, 0.0),         # 1x1 (LDS-DMA eligible: must take the register-staged kernel)
+                (1, 8, 256, 4, 1, 40, 1, 0, 0.0),        # FC-shaped, few pixels
+                (1, 1, 64, 6, 1, 5, 1, 0, 0.0)]          # skinny FC -> fallback pass
+
+
+@pytest.mark.parametrize("case", MOMENT_CASES)
+def test_conv_forward_with_batch_moments(gpu, case):
+    """xm_nnconv_forward_moments: Y = vl_nnconv(X, F, B) plus the batch moments vl_nnbnorm(Y, ...) computes first
+    ([mean, sqrt(var + eps)], biased variance), for every tile configuration and for a forced split-K launch."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, FH, K, stride, pad, off = case
+    rng = np.random.default_rng(H * 131 + W * 17 + K)
+    x, f = rnd(rng, H, W, C, N), rnd(rng, FH, FH, C, K)
+    b = O.F(rng.standard_normal(K) + off)
+    y_ref = O.vl_nnconv(x, f, b, stride=stride, pad=pad, acc64=True)
+    _, m_ref = O.vl_nnbnorm(y_ref, O.F(np.ones(K)), O.F(np.zeros(K)), acc64=True)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+
+    def check(tag):
+        mo = vl.mat_empty(K, 2, device=xd.device)
+        mo.fill_(float("nan"))
+        y = vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad, moments_out=mo)
+        close(vl.to_numpy(y), y_ref, what="conv fwd " + tag)
+        m = vl.to_numpy(mo)
+        close(m[:, 0], m_ref[:, 0], what="mean " + tag)
+        # sigma relative to ITS OWN size (a mean of 25 must not hide a wrong sigma of 1)
+        assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4, (tag, float(np.abs(m[:, 1] / m_ref[:, 1] - 1).max()))
+        # identical to what vl_nnbnorm computes from Y itself, to fp32 round-off
+        _, m2 = vl.vl_nnbnorm(y, vl.from_numpy(O.F(np.ones((K, 1)))), vl.from_numpy(O.F(np.zeros((K, 1)))))
+        assert np.abs(m / vl.to_numpy(m2) - 1)[:, 1].max() <= 2e-5, tag
+    try:
+        for cfg in range(L.xm_debug_num_conv_cfgs()):
+            L.xm_debug_force_conv_cfg(cfg)
+            check("cfg%d" % cfg)
+        L.xm_debug_force_conv_cfg(-1)
+        check("auto")
+        old = L.xm_debug_force_conv_splits(3)
+        try:
+            check("split-K")
+        finally:
+            L.xm_debug_force_conv_splits(old)
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+
+
 def test_conv_fused_epilogue(gpu):
     from mcncrossmodalemotions_amd import vl
     rng = np.random.default_rng(11)
