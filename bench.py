@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = scaled to the host: ~cores/4, "
                     "at least 16)")
-    ap.add_argument("--parserv", default="torch", choices=["torch", "rccl-capi"])
+    ap.add_argument("--parserv", default="auto", choices=["auto", "torch", "rccl-capi"],
+                    help="gradient exchange: the library's own communicator behind the C ABI (xm_parserv_push / sync -- "
+                         "what a MATLAB host binds; the default whenever an exchange happens) or torch.distributed")
     ap.add_argument("--teacher", default="resnet50", choices=["resnet50", "senet50"],
                     help="frozen teacher of the distill workload (BASELINE config 4 names resnet50)")
     ap.add_argument("--teacher-lanes", type=int, default=2,
@@ -150,8 +152,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    force_dist = os.environ.get("XM_DEBUG_DIST") in ("1", "2")   # exercise the RCCL path with a single rank
-    if world > 1 or force_dist:
+    force_dist = os.environ.get("XM_DEBUG_DIST") in ("1", "2", "3")   # exercise the RCCL path with a single rank
+    # "3": the library's own communicator only, no torch process group next to it
+    if world > 1 or (force_dist and os.environ.get("XM_DEBUG_DIST") != "3"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if shared_gpu:
@@ -165,6 +168,33 @@ def main():
     W = args.width
     seed = 4 + rank
 
+    # ParameterServer FIRST -- before any network, buffer or side stream exists.  A communicator created after the
+    # operator streams were in use cost 12 % of the step on this stack (3365 vs 3842 pairs/s at one rank, the whole
+    # backward phase 0.8 ms longer even when no collective was ever issued; moving xm_comm_init here removed it).
+    if args.parserv == "auto":
+        args.parserv = "torch" if shared_gpu else "rccl-capi"      # gloo debug runs have no RCCL communicator
+    parserv = train.ParameterServer(args.parserv)
+    if force_dist and os.environ.get("XM_DEBUG_DIST") in ("1", "3"):
+        parserv.force = True
+    if not os.environ.get("XM_PS_LATE"):
+        try:
+            parserv.start()
+            ok = 1
+        except Exception as e:   # noqa: BLE001 -- report, agree with the other ranks, fall back to torch.distributed
+            print("bench: rccl-capi ParameterServer failed to start (%s); using torch.distributed" % e, file=sys.stderr)
+            ok = 0
+        if world > 1 and args.parserv == "rccl-capi":
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not ok:
+            try:
+                parserv.stop()
+            except Exception:    # noqa: BLE001
+                pass
+            args.parserv = "torch"
+            parserv = train.ParameterServer("torch")
+            parserv.start()
     # ---- networks ------------------------------------------------------------------------
     teacher = student = None
     if wl in ("distill", "teacher", "joint"):
@@ -181,9 +211,6 @@ def main():
         student = zoo.emoVoxZoo("emovoxceleb-student", scratch=1, lossType="hot-cross-ent",
                                 numSeconds=W / 100.0, numOutputs=8, seed=200)
         student.pack_params()
-    parserv = train.ParameterServer(args.parserv)
-    if force_dist and os.environ.get("XM_DEBUG_DIST") == "1":
-        parserv.force = True
     parserv.start()
     parserv.overlap = bool(args.overlap_allreduce)
     opts = train.TrainOpts(batchSize=nb * world)
@@ -341,8 +368,13 @@ def main():
     # at most two steps in flight costs nothing and makes the step time reproducible.
     inflight = []
 
+    host_t = [0.0, 0]
+
     def throttled_step(it):
+        th = time.perf_counter()
         step(it)
+        host_t[0] += time.perf_counter() - th
+        host_t[1] += 1
         ev = torch.cuda.Event()
         ev.record()
         inflight.append(ev)
@@ -430,7 +462,8 @@ def main():
         for (la, ea), (lb, eb) in zip(seq, seq[1:]):
             k = "%s->%s" % (la, lb)
             acc.setdefault(k, []).append(ea.elapsed_time(eb))
-        print("[marks] " + "  ".join("%s %.3f ms" % (k, float(np.mean(v))) for k, v in acc.items()), file=sys.stderr)
+        print("[marks] " + "  ".join("%s %.3f ms" % (k, float(np.mean(v))) for k, v in acc.items()) +
+              "  host enqueue %.3f ms/step" % (host_t[0] / max(1, host_t[1]) * 1e3), file=sys.stderr)
     units = nb * world
     value = units * args.steps / dt
     windows = None

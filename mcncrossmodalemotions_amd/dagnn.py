@@ -457,6 +457,7 @@ class DagNN:
         self.accumulateParamDers = False
         self.fuse = True  # MI355X peephole fusion (results identical)
         self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
+        self.wgradAfterDgrad = os.environ.get("XM_WGRAD_AFTER_DGRAD") is not None
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
@@ -826,6 +827,13 @@ class _Step:
                 # dzdw / dzdb are off the critical path of the backward pass: they run on the side
                 # stream next to the (HBM-bound) bnorm / pooling derivatives of the layers below
                 main = torch.cuda.current_stream()
+                defer = net.wgradAfterDgrad
+                if defer:
+                    # the dgrad of this layer first, alone on the chip; its wgrad starts when it has finished and
+                    # then runs next to the HBM-bound bnorm / pooling derivatives of the layers below (two
+                    # MFMA-bound kernels side by side only slow each other down)
+                    dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False,
+                                               dx_accum=accum)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     _, dpar = r.block.backward(ins, self._params(net), douts, need_dx=False,
@@ -833,9 +841,11 @@ class _Step:
                     if net.gradHook is not None:
                         net.gradHook(r.name)
                 douts[0].record_stream(side)
+                ins[0].record_stream(side)
                 net._side_pending = True
-                dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False,
-                                           dx_accum=accum)
+                if not defer:
+                    dins, _ = r.block.backward(ins, self._params(net), douts, need_dx=True, need_df=False,
+                                               dx_accum=accum)
             if skip_db:
                 dpar = [dpar[0], net.params[r.params[1]].der]
         elif isinstance(r.block, BatchNorm):

@@ -41,6 +41,16 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
     expDir = os.path.join(dataDir, expName)
     if lossType == "hot-cross-ent":
         expDir += "-temp%d" % temperature
+    # ParameterServer before the first device allocation / kernel of the process (xmodal.h "CALL ORDER": a communicator
+    # created later slows every step); 'tmove' (run_distillation.m:88) = the library's communicator when there is
+    # more than one worker and RCCL can carry it, torch.distributed otherwise (gloo test groups)
+    import torch.distributed as dist
+    if parameterServer == "tmove":
+        parameterServer = "rccl-capi" if (dist.is_available() and dist.is_initialized() and
+                                          dist.get_backend() == "nccl" and dist.get_world_size() > 1) else "torch"
+    parserv = parameterServer if isinstance(parameterServer, train.ParameterServer) else \
+        train.ParameterServer(parameterServer)
+    parserv.start()
     net = zoo.emoVoxZoo(student, scratch=1 if fromScratch else 0, lossType=lossType, numSeconds=numSeconds,
                         numOutputs=numPredEmotions, width_mult=widthMult)             # :125-129
     net.meta.setdefault("augmentation", {})["transformation"] = "I"                  # :130
@@ -63,5 +73,5 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
     return train.cnn_train_dag(net, imdb, getBatch, learningRate=learningRate, batchSize=batchSize,
                                numEpochs=numEpochs, train=trainSamples, val=valSamples, cont=cont,
                                expDir=expDir, epochSize=epochSize,
-                               parameterServer=train.ParameterServer("torch" if parameterServer == "tmove" else parameterServer),
+                               parameterServer=parserv,
                                extractStatsFn=train.extractStats, verbose=verbose)

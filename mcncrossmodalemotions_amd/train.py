@@ -51,6 +51,8 @@ class ParameterServer:
         self._handles = []
 
     def start(self):
+        if self._started:
+            return
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
@@ -112,9 +114,14 @@ class ParameterServer:
         return dist.get_world_size() if dist.is_initialized() else 1
 
     def stop(self):
+        if not self._started:
+            if self.backend == "rccl-capi":
+                _lib.load().xm_comm_destroy()     # a half-initialised communicator (failed start)
+            return
         self.sync()
         if self.backend == "rccl-capi" and self.active:
             _lib.check(_lib.load().xm_comm_destroy())
+        self._started = False
 
 
 class GradBuckets:
