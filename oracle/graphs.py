@@ -246,11 +246,62 @@ def forward(graph, inputs, P, mode="normal", acc64=True, keep=None):
     return V
 
 
-def backward(graph, V, der_outputs, P, mode="normal", acc64=True):
+def pool_window_geometry(in_shape, pool, stride, pad):
+    H, W = int(in_shape[0]), int(in_shape[1])
+    ph, pw = int(pool[0]), int(pool[1])
+    sy, sx = (stride, stride) if np.isscalar(stride) else (int(stride[0]), int(stride[1]))
+    pt, pb, pl, pr = (pad,) * 4 if np.isscalar(pad) else [int(q) for q in pad]
+    return H, W, ph, pw, sy, sx, pt, pl, O.conv_out_size(H, pt, pb, ph, 1, sy), O.conv_out_size(W, pl, pr, pw, 1, sx)
+
+
+def pool_argmax_codes(x, pool, stride, pad):
+    """routing table of a max pooling: per output the window offset of its FIRST maximum in column-major scan
+    order, code = dh + ph * dw (the convention of xm_nnpool_forward_argmax); padding counts as -inf."""
+    H, W, ph, pw, sy, sx, pt, pl, Ho, Wo = pool_window_geometry(x.shape, pool, stride, pad)
+    best = np.full((Ho, Wo) + tuple(x.shape[2:]), -np.inf, np.float32)
+    code = np.zeros(best.shape, np.uint8)
+    ho, wo = np.arange(Ho), np.arange(Wo)
+    for dw in range(pw):
+        for dh in range(ph):
+            h, w = ho * sy - pt + dh, wo * sx - pl + dw
+            okh, okw = (h >= 0) & (h < H), (w >= 0) & (w < W)
+            cand = np.full(best.shape, -np.inf, np.float32)
+            cand[np.ix_(okh, okw)] = x[np.ix_(h[okh], w[okw])]
+            take = cand > best                      # strict: the first maximum wins
+            best = np.where(take, cand, best)
+            code[take] = dh + ph * dw
+    return code
+
+
+def pool_positions(code, in_shape, pool, stride, pad):
+    """flat (column-major) input index every pooled output is routed to"""
+    H, W, ph, pw, sy, sx, pt, pl, Ho, Wo = pool_window_geometry(in_shape, pool, stride, pad)
+    code = np.asarray(code).reshape((Ho, Wo) + tuple(in_shape[2:]), order="F").astype(np.int64)
+    dh, dw = code % ph, code // ph
+    h = np.arange(Ho).reshape(Ho, 1, 1, 1) * sy - pt + dh
+    w = np.arange(Wo).reshape(1, Wo, 1, 1) * sx - pl + dw
+    plane = (np.arange(in_shape[2]).reshape(1, 1, -1, 1) + in_shape[2] * np.arange(in_shape[3]).reshape(1, 1, 1, -1))
+    return np.clip(h, 0, H - 1) + H * (np.clip(w, 0, W - 1) + W * plane)
+
+
+def pool_route(dz, code, in_shape, pool, stride, pad):
+    """backward of a max pooling through a GIVEN routing table (derivatives add where windows share a maximum)"""
+    pos = pool_positions(code, in_shape, pool, stride, pad)
+    flat = np.bincount(pos.ravel(order="F"), weights=np.asarray(dz, np.float64).ravel(order="F"),
+                       minlength=int(np.prod(in_shape)))
+    return np.asfortranarray(flat.astype(np.float32).reshape(in_shape, order="F"))
+
+
+def backward(graph, V, der_outputs, P, mode="normal", acc64=True, gates=None):
     """(variable derivatives, parameter derivatives) -- dagnn semantics: derivatives add at forks; a BatchNorm's
-    third parameter derivative is the batch moments."""
+    third parameter derivative is the batch moments.
+    `gates` (tests only): the DISCRETE decisions of another arithmetic's forward pass, used instead of the ones this
+    pass's own values imply -- {relu layer: boolean open-gate mask, or True = pass everything through;
+    max-pool layer: (routing table as pool_argmax_codes, boolean mask of the outputs whose derivative flows)}.
+    Everything continuous (values, moments, sums) stays this pass's own."""
     D = dict(der_outputs)
     DP = {}
+    gates = gates or {}
 
     def add(name, d):
         if d is not None:
@@ -276,14 +327,23 @@ def backward(graph, V, der_outputs, P, mode="normal", acc64=True):
             add(l.inputs[0], dx)
             DP[l.params[0]], DP[l.params[1]], DP[l.params[2]] = dg, db, mom
         elif l.type == "relu":
-            add(l.inputs[0], O.vl_nnrelu(ins[0], dz))
+            if l.name in gates:
+                gm = gates[l.name]
+                add(l.inputs[0], dz if gm is True else np.asfortranarray(dz * np.asarray(gm, np.float32)))
+            else:
+                add(l.inputs[0], O.vl_nnrelu(ins[0], dz))
         elif l.type == "sigmoid":
             add(l.inputs[0], O.vl_nnsigmoid(ins[0], dz))
         elif l.type == "gpool":
             add(l.inputs[0], O.vl_nnpool(ins[0], ins[0].shape[:2], dz, method=a["method"]))
         elif l.type == "pool":
-            add(l.inputs[0], O.vl_nnpool(ins[0], a["poolSize"], dz, stride=a["stride"], pad=a["pad"],
-                                         method=a["method"]))
+            if l.name in gates:
+                code, flows = gates[l.name]
+                add(l.inputs[0], pool_route(np.asarray(dz) * np.asarray(flows, np.float32), code, ins[0].shape,
+                                            a["poolSize"], a["stride"], a["pad"]))
+            else:
+                add(l.inputs[0], O.vl_nnpool(ins[0], a["poolSize"], dz, stride=a["stride"], pad=a["pad"],
+                                             method=a["method"]))
         elif l.type == "sum":
             add(l.inputs[0], dz)
             add(l.inputs[1], dz)

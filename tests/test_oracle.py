@@ -268,3 +268,40 @@ def test_golden_extra_fixtures():
     assert np.array_equal(O.crop_resize_face(E["face_src"], (131.0912, 103.8827, 91.4953), (56, 56)), E["face_out"])
     for k, (a, b) in enumerate(zip(E["agg_first"], E["agg_last"])):
         assert np.array_equal(O.aggregate_logits(E["agg_logits"], int(a), int(b), "max"), E["agg_max_%d" % k])
+
+
+def test_injected_gates_reproduce_the_oracles_own_backward():
+    """oracle.graphs.backward(gates=...) -- the hook the full-size GPU tests use to re-run the oracle's backward pass
+    with ANOTHER arithmetic's discrete decisions -- must be a no-op when it is handed the oracle's own decisions:
+    routing tables from pool_argmax_codes (first maximum in column-major scan order, padding = -inf) and ReLU masks
+    x > 0 give the derivatives of the plain backward pass, ties at exact zeros included."""
+    from oracle import graphs as G
+    rng = np.random.default_rng(3)
+    for shape, pool, stride, pad in [((13, 11, 3, 2), (3, 3), (2, 2), (0, 0, 0, 0)),
+                                     ((12, 12, 4, 2), (3, 3), (2, 2), (0, 1, 0, 1)),
+                                     ((9, 8, 6, 2), (5, 3), (3, 2), (0, 0, 0, 0))]:
+        x = O.F(np.maximum(rng.standard_normal(shape), 0))          # rectified: many exact ties at 0
+        y = O.vl_nnpool(x, pool, stride=stride, pad=pad)
+        dz = O.F(rng.standard_normal(y.shape))
+        ref = O.vl_nnpool(x, pool, dz, stride=stride, pad=pad)
+        code = G.pool_argmax_codes(x, pool, stride, pad)
+        assert np.abs(G.pool_route(dz, code, x.shape, pool, stride, pad) - ref).max() < 1e-6
+        pos = G.pool_positions(code, x.shape, pool, stride, pad)
+        assert np.array_equal(x.ravel(order="F")[pos], y)
+    # a whole (tiny) student: own gates injected == plain backward
+    g = G.vggvox_student(100)
+    if g is not None:
+        P = G.make_params(g, 1)
+        data, lgo, lab = G.spectrogram_batch(2, 100, 5)
+        V = G.forward(g, {"data": data, "logitTarget": lgo, "maxLabel": lab}, P, mode="normal", acc64=True)
+        gates = {}
+        for l in g:
+            if l.type == "relu":
+                gates[l.name] = V[l.inputs[0]] > 0
+            elif l.type == "pool" and l.attrs["method"] == "max":
+                gates[l.name] = (G.pool_argmax_codes(V[l.inputs[0]], l.attrs["poolSize"], l.attrs["stride"],
+                                                     l.attrs["pad"]), np.ones(V[l.outputs[0]].shape, bool))
+        _, D0 = G.backward(g, V, {"objective": np.float32(1)}, P, mode="normal", acc64=True)
+        _, D1 = G.backward(g, V, {"objective": np.float32(1)}, P, mode="normal", acc64=True, gates=gates)
+        for k in D0:
+            assert np.abs(D0[k] - D1[k]).max() <= 1e-6 * max(1.0, np.abs(D0[k]).max()), k
