@@ -73,6 +73,37 @@ prep_dgrad_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int
   }
 }
 
+// The FC-shaped layers' dgrad operand is a plain matrix transpose: At[r][k] = F[k][r] for a 1 x 1 filter (r = c) and for
+// an H-collapsing FH x 1 filter folded into the GEMM rows (r = u + FH c) -- 110 of the 130 MB the student's filter
+// preparation moves per step (fc6: 4096 x 2304, fc7: 1024 x 4096).  64 x 64 tiles through LDS, 16-byte accesses on both
+// sides (the generic kernel above walks T-float runs element by element: ~1 TB/s).
+__global__ void __launch_bounds__(256)
+transpose_filter_kernel(const float *__restrict__ f, float *__restrict__ o, int K, int R, int ldo) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 float4 columns x 16 rows per pass
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int k = k0 + ty + 16 * p, r = r0 + 4 * tx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K && r < R) v = *reinterpret_cast<const float4 *>(f + (size_t)k * R + r);   // R % 4 == 0
+    tile[ty + 16 * p][4 * tx + 0] = v.x;
+    tile[ty + 16 * p][4 * tx + 1] = v.y;
+    tile[ty + 16 * p][4 * tx + 2] = v.z;
+    tile[ty + 16 * p][4 * tx + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = r0 + ty + 16 * p, k = k0 + 4 * tx;
+    if (r < R && k < K) {                                                                // K % 4 == 0
+      float4 v = make_float4(tile[4 * tx + 0][ty + 16 * p], tile[4 * tx + 1][ty + 16 * p],
+                             tile[4 * tx + 2][ty + 16 * p], tile[4 * tx + 3][ty + 16 * p]);
+      *reinterpret_cast<float4 *>(o + (size_t)r * ldo + k) = v;
+    }
+  }
+}
+
 // out[i] = sum_z part[z][i] in a FIXED order (deterministic): ZL "z-lanes" per output each sum a
 // strided subset of the splits with four independent accumulators (loads in flight instead of one
 // dependent chain), then the lanes are combined through LDS in lane order.
@@ -1070,7 +1101,16 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     float *At = (float *)(abase + c.aoff);
     for (int grp = 0; grp < g.G; ++grp) {
       float *Ag = At + (size_t)grp * g.FC * (foldH ? g.FH : 1) * c.Rp;
-      if (!have_prepared) {
+      // pure transpose (see transpose_filter_kernel): 1 x 1 filters, or an FH x 1 filter folded into the GEMM rows
+      const int Rrows = g.FC * (foldH ? g.FH : 1);
+      const bool pure_t = g.FW == 1 && ((foldH && c.nU == g.FH && c.nV == 1) || (g.FH == 1 && !foldH)) &&
+                          c.Rp == g.Kg && (Rrows & 3) == 0 && (g.Kg & 3) == 0 && g.G == 1 &&
+                          (((uintptr_t)f | (uintptr_t)Ag) & 15) == 0 && getenv("XM_NO_FAST_TRANSPOSE") == nullptr;
+      if (!have_prepared && pure_t) {
+        hipLaunchKernelGGL(transpose_filter_kernel, dim3((Rrows + 63) / 64, (g.Kg + 63) / 64), dim3(256), 0, st, f, Ag,
+                           g.Kg, Rrows, c.Rp);
+        XM_LAUNCH_CHECK();
+      } else if (!have_prepared) {
         const int T = g.FH * g.FW;
         const int TS = T <= 14 ? 32 : (T <= 56 ? 16 : 8);
         size_t lds = sizeof(float) * (size_t)TS * (TS * T + 1);

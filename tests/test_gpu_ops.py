@@ -40,6 +40,9 @@ CONV_CASES = [
     (10, 9, 8, 2, 3, 3, 4, 6, (1, 1), (1, 1, 1, 1), (1, 1)),       # 2 filter groups
     (10, 11, 6, 2, 3, 3, 6, 5, (3, 2), (1, 0, 0, 1), (1, 1)),      # stride 3x2
     (40, 33, 20, 3, 3, 3, 20, 150, (1, 1), (1, 1, 1, 1), (1, 1)),  # multi-tile M and pixels
+    (9, 8, 24, 4, 9, 1, 24, 80, (1, 1), (0, 0, 0, 0), (1, 1)),     # fc6 shape, K % 16 == 0: dgrad operand = plain transpose
+    (1, 1, 100, 5, 1, 1, 100, 96, (1, 1), (0, 0, 0, 0), (1, 1)),   # fc7 shape, K % 16 == 0 (transpose_filter_kernel)
+    (6, 6, 72, 2, 1, 1, 72, 64, (2, 2), (0, 0, 0, 0), (1, 1)),     # 1x1 stride 2, transposed operand + untouched pixels
 ]
 
 
