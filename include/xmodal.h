@@ -169,6 +169,15 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
                               const float *moments_in, float *dx_out, float *dg_out, float *db_out,
                               float *moments_out, int flags, void *stream);
 
+/* Extension: xm_nnbnorm_backward_fused that also returns dxsum_out (C x 1) = sum of DX over H x W x N per channel.  When
+ * X is the output of a vl_nnconv with biases, that sum IS the convolution's DZDB (vl_nnconv: dzdb = sum of dzdy), so the
+ * host skips the bias half of xm_nnconv_backward (db_out = NULL) -- one pass over DX and three launches less per layer
+ * (emoVoxZoo.m:118-123: conv -> bnorm -> relu for every layer of the student).  dx_out must not be NULL. */
+int xm_nnbnorm_backward_dxsum(const float *x, const float *y, int H, int W, int C, int N,
+                              const float *g, const float *b, const float *dzdy, float epsilon,
+                              const float *moments_in, float *dx_out, float *dg_out, float *db_out,
+                              float *moments_out, float *dxsum_out, int flags, void *stream);
+
 /* Extension: vl_nnbnorm -> vl_nnrelu -> vl_nnpool('max') as one fused operator pair.  The
  * normalised / rectified tensor is never materialised: forward = moments (train mode) + one pass
  * that normalises, rectifies and pools while recording the argmax table; backward = two passes

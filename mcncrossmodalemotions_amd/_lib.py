@@ -57,6 +57,8 @@ SIGNATURES = {
                                                _vp],
     "xm_nnbnorm_backward_fused": [c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp,
                                                              c_fp, c_fp, _i, _vp],
+    "xm_nnbnorm_backward_dxsum": [c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp,
+                                                             c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnbnorm_relu_pool_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp] + [_i] * 8 +
                                     [c_fp, c_fp, c_fp, _vp],
     "xm_nnbnorm_relu_pool_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _i] + [_i] * 8 +

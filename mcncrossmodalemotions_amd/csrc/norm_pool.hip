@@ -231,6 +231,68 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
   }
 }
 
+// Per-channel variant of bn_bwd_apply_kernel (grid (C, S2), the layout of the reduction kernels): the block first adds
+// the Sp partial sums of ITS channel (bn_bwd_partial_kernel's output -- no separate finalize launch; block s == 0
+// also writes dg / db), applies the derivative to its share of the channel, and leaves sum(dx) of that share in
+// part2[c][s]: summed over s this is dzdb of the convolution that produced x (vl_nnconv: dzdb = sum of dzdy), so the
+// bias derivative costs no pass of its own over dx.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_ch_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ yfwd,
+                       float *__restrict__ dx, const float *__restrict__ g, const float *__restrict__ mom,
+                       const double *__restrict__ part, int Sp, float *__restrict__ dg, float *__restrict__ db,
+                       double *__restrict__ part2, int HW, int C, int N, int S2, FastDiv divRun, double m, int train) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  double sa = 0.0, sb = 0.0;
+  for (int i = 0; i < Sp; ++i) {      // fixed order, the same in every block of the channel
+    sa += part[2 * ((size_t)c * Sp + i)];
+    sb += part[2 * ((size_t)c * Sp + i) + 1];
+  }
+  const double sg = mom[C + c], mu = mom[c];
+  if (s == 0 && threadIdx.x == 0) {
+    if (dg) dg[c] = (float)(sb / sg);
+    if (db) db[c] = (float)sa;
+  }
+  const double gs = (double)g[c] / sg;
+  const double c1 = train ? sa / m : 0.0;
+  const double c2 = train ? sb / (m * sg * sg) : 0.0;
+  double acc = 0.0;
+  const int nper = (N - s + S2 - 1) / S2;
+  const int run = VEC ? HW >> 2 : HW;
+  for (int j = threadIdx.x; j < nper * run; j += 256) {
+    const int nn = (int)xm_div((uint32_t)j, divRun), i = j - nn * run;
+    const size_t off = (size_t)HW * (c + (size_t)C * (s + nn * S2));
+    if (VEC) {
+      float4 xv = reinterpret_cast<const float4 *>(x + off)[i], dv = reinterpret_cast<const float4 *>(dy + off)[i];
+      if (yfwd) {
+        float4 yv = reinterpret_cast<const float4 *>(yfwd + off)[i];
+        dv.x = yv.x > 0.f ? dv.x : 0.f;
+        dv.y = yv.y > 0.f ? dv.y : 0.f;
+        dv.z = yv.z > 0.f ? dv.z : 0.f;
+        dv.w = yv.w > 0.f ? dv.w : 0.f;
+      }
+      float4 o;
+      o.x = (float)(gs * ((double)dv.x - c1 - ((double)xv.x - mu) * c2));
+      o.y = (float)(gs * ((double)dv.y - c1 - ((double)xv.y - mu) * c2));
+      o.z = (float)(gs * ((double)dv.z - c1 - ((double)xv.z - mu) * c2));
+      o.w = (float)(gs * ((double)dv.w - c1 - ((double)xv.w - mu) * c2));
+      reinterpret_cast<float4 *>(dx + off)[i] = o;
+      acc += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
+    } else {
+      float d = dy[off + i];
+      if (yfwd && !(yfwd[off + i] > 0.f)) d = 0.f;
+      const float o = (float)(gs * ((double)d - c1 - ((double)x[off + i] - mu) * c2));
+      dx[off + i] = o;
+      acc += (double)o;
+    }
+  }
+  acc = xm_wave_sum_d(acc);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part2[(size_t)c * S2 + s] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // run length of one sample inside the flat (sample, position) index of the reduction kernels
 static FastDiv bn_run_div(int HW) { return make_fastdiv((uint32_t)((HW & 3) == 0 ? HW >> 2 : HW)); }
 static int bn_splits(int C, int N) {
@@ -305,22 +367,29 @@ static int bnorm_forward(const float *x, int H, int W, int C, int N, const float
   return XM_OK;
 }
 
+__global__ void sum_partials_kernel(const double *__restrict__ part, float *__restrict__ out, int C, int S);
+
+// dxsum_out != NULL (needs dx_out): also sum(dx) per channel = the bias derivative of the producing convolution
 static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C, int N,
                           const float *g, const float *dzdy, float eps, const float *moments_in,
                           float *dx_out, float *dg_out, float *db_out, float *moments_out,
-                          hipStream_t st, bool batch_moments = false) {
+                          hipStream_t st, bool batch_moments = false, float *dxsum_out = nullptr) {
   int rc = bn_check(H, W, C, N);
   if (rc) return rc;
   if (!x || !g || !dzdy) return fail(XM_EINVAL, "vl_nnbnorm: NULL tensor");
   if (batch_moments && !moments_in) return fail(XM_EINVAL, "vl_nnbnorm: XM_BN_BATCH_MOMENTS needs moments");
+  if (dxsum_out && !dx_out) return fail(XM_EINVAL, "vl_nnbnorm: dxsum needs dx");
   const int HW = H * W;
   const int S = bn_splits(C, N);
+  // apply blocks per channel of the dxsum path: enough blocks to fill the chip, at most one per sample
+  const int S2 = std::max(1, std::min(N, 4096 / std::max(1, C)));
   WsCarver ws;
   rc = ws.init(WsCarver::need((size_t)2 * C * S, 8) + WsCarver::need((size_t)2 * C, 8) +
-                   WsCarver::need((size_t)2 * C, 4), st);
+                   WsCarver::need((size_t)2 * C, 4) + WsCarver::need(dxsum_out ? (size_t)C * S2 : 0, 8), st);
   if (rc) return rc;
   double *part = ws.take<double>((size_t)2 * C * S);
   double *sums = ws.take<double>((size_t)2 * C);
+  double *part2 = dxsum_out ? ws.take<double>((size_t)C * S2) : nullptr;
   const float *mom = moments_in;
   if (!moments_in) {
     float *momw = moments_out ? moments_out : ws.take<float>((size_t)2 * C);
@@ -336,6 +405,22 @@ static int bnorm_backward(const float *x, const float *yfwd, int H, int W, int C
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, S), dim3(256), 0, st, x, dzdy, yfwd, mom, part, HW,
                      C, N, S, bn_run_div(HW));
   XM_LAUNCH_CHECK();
+  if (dxsum_out) {
+    // partial sums -> [finalize + apply + sum(dx) partials] -> dzdb of the producing convolution: three launches
+    const double m = (double)HW * N;
+    const int train = (moments_in && !batch_moments) ? 0 : 1;
+    const bool al = ((((uintptr_t)x | (uintptr_t)dzdy | (uintptr_t)dx_out | (uintptr_t)yfwd) & 15) == 0);
+    if ((HW & 3) == 0 && al)
+      hipLaunchKernelGGL(bn_bwd_apply_ch_kernel<true>, dim3(C, S2), dim3(256), 0, st, x, dzdy, yfwd, dx_out, g, mom,
+                         part, S, dg_out, db_out, part2, HW, C, N, S2, bn_run_div(HW), m, train);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_ch_kernel<false>, dim3(C, S2), dim3(256), 0, st, x, dzdy, yfwd, dx_out, g, mom,
+                         part, S, dg_out, db_out, part2, HW, C, N, S2, make_fastdiv((uint32_t)HW), m, train);
+    XM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part2, dxsum_out, C, S2);
+    XM_LAUNCH_CHECK();
+    return XM_OK;
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, mom, sums,
                      dg_out, db_out, C, S);
   XM_LAUNCH_CHECK();
@@ -1216,6 +1301,17 @@ int xm_nnbnorm_backward_fused(const float *x, const float *y, int H, int W, int 
   return bnorm_backward(x, (flags & XM_FUSE_RELU) ? y : nullptr, H, W, C, N, g, dzdy, epsilon,
                         moments_in, dx_out, dg_out, db_out, moments_out, (hipStream_t)stream,
                         (flags & XM_BN_BATCH_MOMENTS) != 0);
+}
+
+int xm_nnbnorm_backward_dxsum(const float *x, const float *y, int H, int W, int C, int N,
+                              const float *g, const float *b, const float *dzdy, float epsilon,
+                              const float *moments_in, float *dx_out, float *dg_out, float *db_out,
+                              float *moments_out, float *dxsum_out, int flags, void *stream) {
+  (void)b;
+  if ((flags & XM_FUSE_RELU) && !y) return fail(XM_EINVAL, "vl_nnbnorm(fused bwd): y is NULL");
+  return bnorm_backward(x, (flags & XM_FUSE_RELU) ? y : nullptr, H, W, C, N, g, dzdy, epsilon,
+                        moments_in, dx_out, dg_out, db_out, moments_out, (hipStream_t)stream,
+                        (flags & XM_BN_BATCH_MOMENTS) != 0, dxsum_out);
 }
 
 int xm_nnpool_forward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,

@@ -127,7 +127,7 @@ class BatchNorm(Layer):
         self.moments = None if test else mom
         return [y]
 
-    def backward(self, inputs, params, derOutputs, relu=False, y=None, der_out=None):
+    def backward(self, inputs, params, derOutputs, relu=False, y=None, der_out=None, dxsum_out=None):
         test = self.net is not None and self.net.mode == "test"
         do = der_out or [None, None, None]
         # train mode: the forward pass of this eval left the batch moments of this very input in
@@ -137,7 +137,7 @@ class BatchNorm(Layer):
                                         epsilon=self.epsilon,
                                         moments=params[2] if test else saved,
                                         relu=relu, y=y, dg_out=do[0], db_out=do[1], moments_out=do[2],
-                                        batch_moments=(not test) and saved is not None)
+                                        batch_moments=(not test) and saved is not None, dxsum_out=dxsum_out)
         # dagnn.BatchNorm: derParams{3} = the batch moments (consumed by trainMethod 'average')
         return [dx], [dg, db, mom]
 
@@ -458,6 +458,7 @@ class DagNN:
         self.fuse = True  # MI355X peephole fusion (results identical)
         self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
         self.wgradAfterDgrad = os.environ.get("XM_WGRAD_AFTER_DGRAD") is not None
+        self.fuseBiasDer = os.environ.get("XM_NO_FUSED_BIASDER") is None   # conv dzdb = sum(dx) from the bnorm backward
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
@@ -766,6 +767,25 @@ class _Step:
         self.rec = rec
         self.bias_from = None  # fused consumer step that already produced this conv's bias derivative
         self.moments_for = None  # _LayerRec of the train-mode BatchNorm this conv step computes the batch moments for
+        self.bias_conv = None    # bnorm steps: _Step of the biased Conv that produced the input (its dzdb = sum of our dx)
+        self.bias_conv_done = False
+
+    def _bias_der_slot(self, net):
+        """flat derivative slot of the producing convolution's bias when this bnorm step may fill it (sum of dx)"""
+        self.bias_conv_done = False
+        if self.bias_conv is None or net._flat is None or net.accumulateParamDers or not net.fuseBiasDer:
+            return None
+        if net.wgradStream is not None and type(self) is not _BnReluPoolStep:
+            # measured (default step, three A/B pairs): with a side stream the convolution's own dzdb pass runs there,
+            # next to the main stream's dgrad, for free; pulling it into the bnorm backward lengthens the main stream
+            # (the critical path) and cost 1 % -- although it removes 20 us of kernel time per layer.  One-stream hosts
+            # (the MEX binding) take the shorter chain.
+            return None
+        bp = net.params[self.bias_conv.rec.params[1]]
+        if bp.fanout == 1 and bp.der is not None:
+            self.bias_conv_done = True
+            return bp.der
+        return None
 
     def _params(self, net):
         return [net.params[p].value for p in self.rec.params]
@@ -849,7 +869,8 @@ class _Step:
             if skip_db:
                 dpar = [dpar[0], net.params[r.params[1]].der]
         elif isinstance(r.block, BatchNorm):
-            dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r))
+            dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r),
+                                          dxsum_out=self._bias_der_slot(net))
         elif isinstance(r.block, Pooling):
             outs = [net.vars[v].value for v in r.outputs]
             dins, dpar = r.block.backward(ins, self._params(net), douts,
@@ -886,7 +907,7 @@ class _BnReluStep(_Step):
             return
         ins = [net.vars[v].value for v in r.inputs]
         dins, dpar = r.block.backward(ins, self._params(net), [out.der], relu=True, y=out.value,
-                                      der_out=net._direct_der(r))
+                                      der_out=net._direct_der(r), dxsum_out=self._bias_der_slot(net))
         net._set_var_der(r.inputs[0], dins[0])
         for p, d in zip(r.params, dpar):
             net._set_param_der(p, d)
@@ -1044,6 +1065,18 @@ class _ConvFoldStep(_Step):
         raise RuntimeError("folded conv+bn steps exist only in forward-only test-mode plans")
 
 
+def _link_bias_conv(bn_step, steps, r, consumers, training):
+    """training plans: a biased Conv whose only consumer is this bnorm gets its dzdb from the bnorm backward (sum of
+    dx) instead of a pass of its own over dzdy"""
+    if not training:
+        return
+    prod = [q for q in steps if type(q) is _Step and r.inputs[0] in q.rec.outputs]
+    if prod and isinstance(prod[0].rec.block, Conv) and prod[0].rec.block.hasBias and \
+            len(consumers.get(r.inputs[0], [])) == 1:
+        bn_step.bias_conv = prod[0]
+        prod[0].bias_from = bn_step
+
+
 def build_plan(net, training):
     recs = net.layers
     if not net.fuse:
@@ -1115,9 +1148,15 @@ def build_plan(net, training):
                     steps.append(_BnReluPoolStep(r, rl, pl, bias_conv))
                     skip.update((id(rl), id(pl)))
                     continue
-                steps.append(_BnReluStep(r, rl))
+                st_ = _BnReluStep(r, rl)
+                _link_bias_conv(st_, steps, r, consumers, training)
+                steps.append(st_)
                 skip.add(id(rl))
                 continue
+            st_ = _Step(r)
+            _link_bias_conv(st_, steps, r, consumers, training)
+            steps.append(st_)
+            continue
         steps.append(_Step(r))
     # a fused step may now sit before the producer of one of its operands is scheduled; the
     # `ready` test above guarantees producers precede the conv, so plain order is still valid.

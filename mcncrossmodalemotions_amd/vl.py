@@ -261,13 +261,14 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, wa
 
 
 def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None, dg_out=None,
-               db_out=None, moments_out=None, batch_moments=False):
+               db_out=None, moments_out=None, batch_moments=False, dxsum_out=None):
     """forward:  Y, MOMENTS = VL_NNBNORM(X, G, B);  backward: DX, DG, DB, MOMENTS = (..., DZDY).
 
     MOMENTS is C x 2 = [mean, sqrt(var + epsilon)].  `relu=True` fuses vl_nnrelu (forward) /
     its mask (backward; pass the fused forward output as `y`).  `batch_moments=True` (backward,
     extension): `moments` are the batch moments the forward call returned for this X -- train-mode
-    derivative without recomputing them."""
+    derivative without recomputing them.  `dxsum_out` (backward, extension; C x 1): receives sum(DX) per channel =
+    the DZDB of the vl_nnconv that produced X (xm_nnbnorm_backward_dxsum)."""
     x, g, b = _chk(x, "X"), _chk(g, "G"), _chk(b, "B")
     H, W, Cc, N = _shape4(x)
     if g.numel() != Cc or b.numel() != Cc:
@@ -293,7 +294,16 @@ def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=Non
     db = db_out if db_out is not None else mat_empty(Cc, 1, device=x.device)
     if batch_moments and mi is None:
         raise ValueError("vl_nnbnorm: batch_moments needs the moments of the forward call")
-    if relu or batch_moments:
+    if dxsum_out is not None:
+        if relu and y is None:
+            raise ValueError("vl_nnbnorm: fused backward needs the forward output y")
+        if _chk(dxsum_out, "DXSUM").numel() != Cc:
+            raise ValueError("vl_nnbnorm: dxsum_out must have %d elements" % Cc)
+        _lib.check(L.xm_nnbnorm_backward_dxsum(_ptr(x), _ptr(_chk(y, "Y")) if relu else None, H, W, Cc, N,
+                                               _ptr(g), _ptr(b), _ptr(dzdy), float(epsilon), _ptr(mi),
+                                               _ptr(dxo), _ptr(dg), _ptr(db), _ptr(mo), _ptr(dxsum_out),
+                                               (1 if relu else 0) | (2 if batch_moments else 0), _stream()))
+    elif relu or batch_moments:
         if relu and y is None:
             raise ValueError("vl_nnbnorm: fused backward needs the forward output y")
         _lib.check(L.xm_nnbnorm_backward_fused(_ptr(x), _ptr(_chk(y, "Y")) if relu else None, H, W, Cc, N,

@@ -56,8 +56,8 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
 
 
 def vl_nnbnorm(x, g, b, dzdy=None, epsilon=1e-4, moments=None, relu=False, y=None, dg_out=None, db_out=None,
-               moments_out=None, batch_moments=False):
-    assert not relu, "stand-in: run the net with fuse=False"
+               moments_out=None, batch_moments=False, dxsum_out=None):
+    assert not relu and dxsum_out is None, "stand-in: run the net with fuse=False"
     if dzdy is None:
         yy, mom = O.vl_nnbnorm(_np(x), _np(g), _np(b), epsilon=epsilon, moments=_np(moments), acc64=True)
         return _mat(yy), _into(moments_out, mom)

@@ -348,6 +348,18 @@ def test_bnorm(gpu, shape, relu):
     close(vl.to_numpy(dg2), vl.to_numpy(dg), 0, "bn dg with forward moments")
     close(vl.to_numpy(db2), vl.to_numpy(db), 0, "bn db with forward moments")
     close(vl.to_numpy(m2), vl.to_numpy(m), 0, "moments passed through")
+    # xm_nnbnorm_backward_dxsum: same dx / dg / db from the per-channel apply kernel, plus sum(dx) per channel (= dzdb
+    # of a convolution that produced x; ~0 in train mode, so it is compared on the scale of |dx| * sqrt(count))
+    dxs = vl.mat_empty(C, 1, device=xd.device)
+    dx3, dg3, db3, _ = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), relu=relu, y=y if relu else None,
+                                     moments=m, batch_moments=True, dxsum_out=dxs)
+    close(vl.to_numpy(dx3), dx_ref, what="bn dx (dxsum path)")
+    close(vl.to_numpy(dg3).ravel(), dg_ref, what="bn dg (dxsum path)")
+    close(vl.to_numpy(db3).ravel(), db_ref, what="bn db (dxsum path)")
+    sref = dx_ref.astype(np.float64).sum(axis=(0, 1, 3))
+    got = vl.to_numpy(dxs).ravel().astype(np.float64)
+    assert np.abs(got - vl.to_numpy(dx3).astype(np.float64).sum(axis=(0, 1, 3))).max() <= 1e-6 * max(1.0, np.abs(dx_ref).max()) * np.sqrt(H * W * N)
+    assert np.abs(got - sref).max() <= 1e-5 * max(1.0, np.abs(dx_ref).max()) * np.sqrt(H * W * N)
     # test mode with stored moments
     mom = O.F(np.stack([rng.standard_normal(C), rng.uniform(0.5, 1.5, C)], 1))
     yt_ref, _ = O.vl_nnbnorm(x, g, b, moments=mom, acc64=True)
@@ -356,6 +368,10 @@ def test_bnorm(gpu, shape, relu):
     dxt_ref, dgt_ref, dbt_ref, _ = O.vl_nnbnorm(x, g, b, dzdy, moments=mom, acc64=True)
     dxt, dgt, dbt, _ = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), moments=vl.from_numpy(mom))
     close(vl.to_numpy(dxt), dxt_ref, what="bn test-mode dx")
+    dxs2 = vl.mat_empty(C, 1, device=xd.device)
+    dxt2, _, _, _ = vl.vl_nnbnorm(xd, gd, bd, vl.from_numpy(dzdy), moments=vl.from_numpy(mom), dxsum_out=dxs2)
+    close(vl.to_numpy(dxt2), dxt_ref, what="bn test-mode dx (dxsum path)")
+    close(vl.to_numpy(dxs2).ravel(), dxt_ref.astype(np.float64).sum(axis=(0, 1, 3)), 2e-5, "bn test-mode sum(dx)")
     close(vl.to_numpy(dgt).ravel(), dgt_ref, what="bn test-mode dg")
 
 
