@@ -86,6 +86,11 @@ def parse():
                          "attach it as `north_star_b256`.  -1 = on for the default single-GPU distill line only")
     ap.add_argument("--teacher-prefetch", type=int, default=1,
                     help="1: the teacher stream works one batch ahead of the student (needs --overlap-teacher 1)")
+    ap.add_argument("--teacher-gate", default="",
+                    help="distill + --teacher-prefetch: where in the student step the teacher pass of the NEXT step may "
+                         "start on its stream: '' = at the start of the step; a student layer name (bn1, conv2, ...) = when "
+                         "the backward pass reaches that layer -- the MFMA-bound teacher then runs next to the HBM-bound "
+                         "tail of this step (first layer's bnorm / pooling derivative, update) and head of the next")
     ap.add_argument("--overlap-teacher", type=int, default=1,
                     help="1: the frozen teacher runs on a second HIP stream next to the student forward (+2 %%)")
     return ap.parse_args()
@@ -308,10 +313,13 @@ def main():
             # still launches exactly one teacher forward and one student step.
             main = torch.cuda.current_stream()
 
-            def launch_teacher():
+            def launch_teacher(gate=None):
                 # prefetch: pipeline depth 1 -- the teacher of step i+1 starts no earlier than the
-                # student of step i (event recorded on the main stream at the start of this step)
-                if args.teacher_prefetch:
+                # student of step i (event recorded on the main stream at the start of this step, or -- `gate` --
+                # where its backward pass reached the --teacher-gate layer)
+                if gate is not None:
+                    tstream.wait_event(gate)
+                elif args.teacher_prefetch:
                     e0 = torch.cuda.Event()
                     e0.record(main)
                     tstream.wait_event(e0)
@@ -332,13 +340,28 @@ def main():
                 # step of slack is left, i.e. the teacher never runs more than one pass ahead
                 q = prefetched.setdefault("q", [])
 
-                def refill():
-                    tl_, ml_, ev_ = launch_teacher()
+                def refill(gate=None):
+                    tl_, ml_, ev_ = launch_teacher(gate)
                     for k in range(tmult):
                         q.append((tl_[..., k * nb:(k + 1) * nb], ml_[..., k * nb:(k + 1) * nb], ev_))
                 if not q:
                     refill()
                 tl, ml, ev = q.pop(0)
+                if args.teacher_gate and tmult == 1:
+                    # this step first (its backward records the gate event), then the next step's teacher pass behind it
+                    gate = {}
+
+                    def hook():
+                        gate["ev"] = torch.cuda.Event()
+                        gate["ev"].record(main)
+                    student.bwdHooks = {args.teacher_gate: hook}
+                    train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
+                                     parserv, nb * world, input_events={"logitTarget": ev, "maxLabel": ev})
+                    student.bwdHooks = {}
+                    if "ev" not in gate:
+                        raise SystemExit("--teacher-gate %r: no such layer in the student's backward pass" % args.teacher_gate)
+                    refill(gate["ev"])
+                    return
                 if len(q) == 0:
                     refill()
             else:

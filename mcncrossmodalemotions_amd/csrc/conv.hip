@@ -193,38 +193,57 @@ bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ d
   if (lane == 0) db[k] = (float)s;
 }
 
-// batch moments from the convolution epilogue's partial sums (ConvGemmArgs::statPart, [row][ncg] pairs of fp32
-// {sum, sum of squares} over <= 128 values each): fp64 accumulation over the column groups in a fixed order.
-// mom = [mean, sqrt(var + eps)] (C x 2).  One block per channel.
+// batch moments from the convolution epilogue's partial sums (ConvGemmArgs::statPart, [pixel tile][row] pairs of fp32
+// {sum, sum of squares} over <= 256 values each): fp64 accumulation over the pixel tiles in a fixed order.
+// mom = [mean, sqrt(var + eps)] (M x 2).  Block = 32 channels x 8 tile lanes (a wave reads two runs of 32 consecutive
+// pairs); grid (ceil(M / 32), S): S > 1 splits the tiles, the partial fp64 sums go to part2[s][M][2] and
+// conv_stats_finalize2_kernel adds them.
 __global__ void __launch_bounds__(256)
-conv_stats_finalize_kernel(const float *__restrict__ part, float *__restrict__ mom, int M, int ncg, double m,
-                           float eps) {
-  const int c = blockIdx.x;
-  const float2 *p = reinterpret_cast<const float2 *>(part) + (size_t)c * ncg;
+conv_stats_reduce_kernel(const float *__restrict__ part, float *__restrict__ mom, double *__restrict__ part2, int M,
+                         int ncg, int S, double m, float eps) {
+  const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, s = blockIdx.y;
+  const int chunk = (ncg + S - 1) / S, g0 = s * chunk, g1 = min(ncg, g0 + chunk);
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < ncg; i += 256) {
-    const float2 v = p[i];
-    a += (double)v.x;
-    b += (double)v.y;
-  }
-  a = xm_wave_sum_d(a);
-  b = xm_wave_sum_d(b);
-  __shared__ double red[8];
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    red[w] = a;
-    red[4 + w] = b;
-  }
+  if (c < M)
+    for (int g = g0 + j; g < g1; g += 8) {
+      const float2 v = *reinterpret_cast<const float2 *>(part + ((size_t)g * M + c) * 2);
+      a += (double)v.x;
+      b += (double)v.y;
+    }
+  __shared__ double ra[8][32], rb[8][32];
+  ra[j][cl] = a;
+  rb[j][cl] = b;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    a = (red[0] + red[1]) + (red[2] + red[3]);
-    b = (red[4] + red[5]) + (red[6] + red[7]);
-    const double mu = a / m;
-    double var = b / m - mu * mu;
-    var = var < 0.0 ? 0.0 : var;
-    mom[c] = (float)mu;
-    mom[M + c] = (float)sqrt(var + (double)eps);
+  if (j == 0 && c < M) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a += ra[k][cl], b += rb[k][cl];
+    if (S == 1) {
+      const double mu = a / m;
+      double var = b / m - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      mom[c] = (float)mu;
+      mom[M + c] = (float)sqrt(var + (double)eps);
+    } else {
+      part2[2 * ((size_t)s * M + c)] = a;
+      part2[2 * ((size_t)s * M + c) + 1] = b;
+    }
   }
+}
+__global__ void __launch_bounds__(256)
+conv_stats_finalize2_kernel(const double *__restrict__ part2, float *__restrict__ mom, int M, int S, double m, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= M) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < S; ++s) {
+    a += part2[2 * ((size_t)s * M + c)];
+    b += part2[2 * ((size_t)s * M + c) + 1];
+  }
+  const double mu = a / m;
+  double var = b / m - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  mom[c] = (float)mu;
+  mom[M + c] = (float)sqrt(var + (double)eps);
 }
 
 // ---- tile configuration ---------------------------------------------------------------------
@@ -820,11 +839,12 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
                       g.R % kBK == 0 && getenv("XM_NO_DMA") == nullptr;
   static const bool no_fstats = getenv("XM_NO_FUSED_STATS") != nullptr;
   const bool want_stats = moments_out != nullptr && g.G == 1 && !no_fstats;
-  // partial sums: one {sum, sum sq} pair per row and per 32-pixel column group at the finest (TN = 1)
+  // partial sums: one {sum, sum sq} pair per row and per pixel tile (>= 32 pixels), + 64 fp64 slabs for the reduction
   const size_t statf = want_stats ? (size_t)2 * g.K * ((proto.NP + 31) / 32) : 0;
+  const size_t stat2 = want_stats ? (size_t)2 * g.K * 64 : 0;
   WsCarver ws;
   int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4) +
-                       WsCarver::need(statf, 4), st);
+                       WsCarver::need(statf, 4) + WsCarver::need(stat2, 8), st);
   if (rc) return rc;
   const int2 *taps = fwd_taps2(g, Rp, bigTaps);
   if (!taps) return fail(XM_ENOMEM, "vl_nnconv: tap table allocation failed");
@@ -841,6 +861,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   }
   float *slab = slabf ? ws.take<float>(slabf) : nullptr;
   float *statp = statf ? ws.take<float>(statf) : nullptr;
+  double *statp2 = stat2 ? ws.take<double>(stat2) : nullptr;
   bool stats_done = false;
   const size_t xTotal = (size_t)g.H * g.W * g.C * g.N;
   for (int grp = 0; grp < g.G; ++grp) {
@@ -904,7 +925,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       stat_ncg = 0;
       if (stats_ok && sp == 1 && (g_force_splits <= 1)) {
         const Cfg &c = kCfgs[ci];
-        stat_ncg = ((a.NP + c.bn() - 1) / c.bn()) * c.wgn;
+        stat_ncg = (a.NP + c.bn() - 1) / c.bn();
         aa.statPart = statp;
         aa.statNcg = stat_ncg;
       }
@@ -915,9 +936,15 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     rc = run(ci);
     if (rc) return rc;
     if (stat_ncg > 0) {
-      hipLaunchKernelGGL(conv_stats_finalize_kernel, dim3(g.K), dim3(256), 0, st, statp, moments_out, g.K, stat_ncg,
-                         (double)a.NP, eps);
+      const int S = std::max(1, std::min(64, stat_ncg / 256));
+      hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((g.K + 31) / 32, S), dim3(256), 0, st, statp, moments_out,
+                         statp2, g.K, stat_ncg, S, (double)a.NP, eps);
       XM_LAUNCH_CHECK();
+      if (S > 1) {
+        hipLaunchKernelGGL(conv_stats_finalize2_kernel, dim3((g.K + 255) / 256), dim3(256), 0, st, statp2, moments_out,
+                           g.K, S, (double)a.NP, eps);
+        XM_LAUNCH_CHECK();
+      }
       stats_done = true;
     }
   }

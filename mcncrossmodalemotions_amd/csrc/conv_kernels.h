@@ -61,11 +61,11 @@ struct ConvGemmArgs {
   int vecStore;       // 1: 4 consecutive pixels are contiguous & 16-B friendly -> dwordx4 epilogue
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
-  // != NULL (vecStore, no split-K, not the LDS-DMA kernel): every wave also leaves {sum, sum of squares} of the values
-  // it stores, per row and per column group (the 32 * TN pixels of the wave): statPart[row][statNcg][2].  The batch
+  // != NULL (vecStore, no split-K, not the LDS-DMA kernel): every BLOCK also leaves {sum, sum of squares} of the
+  // values it stores, per row: statPart[pixel tile bn][row][2] (rows contiguous: one coalesced run per block).  The batch
   // moments of the train-mode bnorm that follows the convolution then cost no second pass over Y (conv_forward).
   float *statPart;
-  int statNcg;
+  int statNcg;        // number of pixel tiles (= nbn)
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
   unsigned long long *dbgCycles;  // debug (xm_debug_conv_cycles): per-block {first clock, last clock, HW_ID, XCC_ID}
 };
@@ -207,7 +207,8 @@ __device__ __forceinline__ void xm_st4(float *p, float v) {
 
 template <int TM, int TN, int WGM, int WGN, bool ASMST = false>
 __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16 (&acc)[TM][TN], int bm, int bn,
-                                                   int split, int wm, int wn, int half, int l31) {
+                                                   int split, int wm, int wn, int half, int l31,
+                                                   float *sred = nullptr /* LDS, >= 2 * WGN * BM floats (statPart) */) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
 #if defined(XM_VARIANT) && XM_VARIANT == 2
   {  // experiment: no stores (keeps the accumulators alive through an impossible condition)
@@ -297,6 +298,11 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
           for (int g4 = 0; g4 < 4; ++g4) radd[i][g4] += bi_[i][g4] * rmul[i][g4];
       }
     }
+    float st1[TM][4], st2[TM][4];   // a.statPart: this lane's share of {sum, sum of squares} per row it stores
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) st1[i][g4] = 0.f, st2[i][g4] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       int offs[4][TN];
@@ -317,7 +323,6 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
       // compiler's vmcnt(0) in front of its use wait for those stores as well (in-order counter).
       // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
       // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
-      float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // a.statPart: this lane's share per row
       f32x4 rv[ASMST ? 4 : 1][ASMST ? TN : 1];
       if (ASMST && a.resid) {
 #pragma unroll
@@ -346,8 +351,8 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
                 o += *reinterpret_cast<const f32x4 *>(a.resid + offs[g4][j]);
             }
             if (!ASMST && a.statPart) {
-              st1[g4] += (o.x + o.y) + (o.z + o.w);
-              st2[g4] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+              st1[i][g4] += (o.x + o.y) + (o.z + o.w);
+              st2[i][g4] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             }
             if (a.relu) {
               o.x = fmaxf(o.x, 0.f);
@@ -363,16 +368,32 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
           }
         }
       }
-      if (!ASMST && a.statPart) {
-        // lanes iq + 4 q of a half hold pixel quads of the SAME row: sum them, lanes q == 0 store the wave's partial
-        const int cg = bn * WGN + wn;
+    }
+    if (!ASMST && a.statPart) {
+      // lanes iq + 4 q of a half hold pixel quads of the SAME row: sum them (DPP), park the wave's 32 * TM row sums in
+      // LDS, add the WGN waves that share the rows in wave order, and store the block's rows as ONE contiguous run.
+      // (Per-wave partials stored straight from the lanes -- 8-byte writes, every lane a different row -- made the
+      // student's first layer 58 us slower: 3.6 M quarter-filled cache lines.)
+      __syncthreads();                       // every wave is past its last fragment read: the operand tiles are dead
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const float u = quad_class_sum8(st1[g4]), v = quad_class_sum8(st2[g4]);
-          const int row = wbase + i * 32 + 8 * g4 + 4 * half + iq;
-          if ((l31 >> 2) == 0 && row < a.M)
-            *reinterpret_cast<float2 *>(a.statPart + ((size_t)row * a.statNcg + cg) * 2) = make_float2(u, v);
+          const float u = quad_class_sum8(st1[i][g4]), v = quad_class_sum8(st2[i][g4]);
+          const int rl = (wm * TM + i) * 32 + 8 * g4 + 4 * half + iq;       // row inside the block tile
+          if ((l31 >> 2) == 0) *reinterpret_cast<float2 *>(sred + 2 * (wn * BM + rl)) = make_float2(u, v);
         }
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < BM && bm * BM + t < a.M) {
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGN; ++w) {
+          const float2 q = *reinterpret_cast<const float2 *>(sred + 2 * (w * BM + t));
+          u += q.x;
+          v += q.y;
+        }
+        *reinterpret_cast<float2 *>(a.statPart + ((size_t)bn * a.M + bm * BM + t) * 2) = make_float2(u, v);
       }
     }
     return;
@@ -642,7 +663,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 #undef XM_STAGE_LAST
 
   if (TM * TN == 1) acc[0][0] += accx;
-  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31);
+  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31, smem);
 }
 
 template <int TM, int TN, int WGM, int WGN, int MODE>

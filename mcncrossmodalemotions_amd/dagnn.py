@@ -463,6 +463,8 @@ class DagNN:
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
         self.markHook = None     # diagnostics: callable(label) at the phase boundaries of eval (bench.py XM_BENCH_MARKS)
+        self.bwdHooks = {}       # {layer name: callable()} run right before that layer's backward step is enqueued
+                                 # (a host can hang stream events there, e.g. to start a prefetch -- bench.py)
         self._side_pending = False
         self._training = False
         self.prepareBackward = os.environ.get("XM_NO_PREPARE") is None   # dgrad filter transposition during forward
@@ -694,7 +696,12 @@ class DagNN:
             for p in self.params.values():
                 p.der = None
         self._pending_param_ders = {}
+        hooks = self.bwdHooks
         for step in reversed(plan):
+            if hooks:
+                h = hooks.get(step.rec.name)
+                if h is not None:
+                    h()
             step.backward(self)
         mark("bwd1")
         if self._side_pending:
