@@ -20,6 +20,8 @@ int xm_prof_kernel_name(int key, char *buf, int len);
 /* test hooks: force one tile configuration for every convolution launch (-1 = automatic) */
 int xm_debug_force_conv_cfg(int cfg);
 int xm_debug_num_conv_cfgs(void);
+/* 1: the halo-patch kernel (3 x 3, unit stride) wherever it can run; 0: never; -1: measured choice (default) */
+int xm_debug_force_conv_halo(int on);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);
 /* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,

@@ -348,6 +348,7 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 }
 
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
+static int g_force_halo = -1; // test hook (xm_debug_force_conv_halo): 1 = halo-patch kernel wherever it can run, 0 = never
 static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
 // ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) --------
@@ -483,6 +484,82 @@ static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipS
   return XM_OK;
 }
 
+// ---- halo-patch kernel (conv_halo_kernel): 3 x 3 taps, unit stride ------------------------------------------------
+// fills the patch geometry of `a` (an implicit-GEMM problem already described by its tap / gather fields) and says
+// whether the kernel can run it: nine taps in a 3 x 3 arrangement, unit pixel stride, channels a multiple of 8, and the
+// zero-padded patch under any 128-pixel tile within 512 floats per channel.
+static const float kHaloMargin = getenv("XM_HALO_MARGIN") ? (float)atof(getenv("XM_HALO_MARGIN")) : 0.04f;
+static bool halo_setup(ConvGemmArgs &a, int nSamples) {
+  static const bool off = getenv("XM_NO_HALO") != nullptr;
+  if (off || a.nU != 3 || a.nV != 3 || a.gsy != 1 || a.gsx != 1) return false;
+  if (a.Rtrue % kHaloKS != 0 || a.Rtrue < kHaloKS || (a.lda & 3) || ((uintptr_t)a.A & 15)) return false;
+  if (std::abs(a.dus) != 1 || std::abs(a.dvs) != 1) return false;     // dilation 1 (taps are adjacent rows / columns)
+  const int rlo = a.gh0 + a.du0 + std::min(0, 2 * a.dus), clo = a.gw0 + a.dv0 + std::min(0, 2 * a.dvs);
+  a.hpRmin = rlo;
+  a.hpCmin = clo;
+  a.hpHP = a.PI + 2;
+  a.hpWP = a.PJ + 2;
+  a.hpN = nSamples;
+  for (int iv = 0; iv < 3; ++iv)
+    for (int iu = 0; iu < 3; ++iu) {
+      const int su = a.gh0 + a.du0 + iu * a.dus - rlo, sv = a.gw0 + a.dv0 + iv * a.dvs - clo;
+      a.hpSh[iu + 3 * iv] = (su + a.hpHP * sv) * 4;
+    }
+  a.hpDivHP = make_fastdiv((uint32_t)a.hpHP);
+  a.hpDivWP = make_fastdiv((uint32_t)a.hpWP);
+  // widest patch over all 128-pixel tiles: padded columns of the first and the last pixel of the tile + the taps
+  const int BN = 128, pij = a.PI * a.PJ;
+  int worst = 0;
+  for (long long p0 = 0; p0 < a.NP; p0 += BN) {
+    const long long p1 = std::min<long long>(p0 + BN - 1, a.NP - 1);
+    const long long c0 = (p0 / pij) * a.hpWP + (p0 % pij) / a.PI, c1 = (p1 / pij) * a.hpWP + (p1 % pij) / a.PI;
+    worst = std::max(worst, (int)(c1 - c0) + 3);
+  }
+  return worst * a.hpHP <= kHaloPS;
+}
+
+// split-K for the halo kernel: stages of 72 reduction steps; one round of 2 blocks per CU, >= 4 stages per split
+static int halo_splits(const ConvGemmArgs &a) {
+  const int tiles = ((a.M + 127) / 128) * ((a.NP + 127) / 128), nst = a.Rtrue / kHaloKS;
+  if (tiles >= 384 || nst < 8) return 1;
+  return std::max(1, std::min(std::min(512 / tiles, nst / 4), 16));
+}
+static size_t halo_slab_floats(const ConvGemmArgs &a) {
+  const int sp = halo_splits(a);
+  return sp > 1 ? (size_t)sp * a.M * ((a.NP + 3) & ~3) : 0;
+}
+
+static int launch_halo(ConvGemmArgs a, float *slab, hipStream_t st) {
+  a.nbm = (a.M + 127) / 128;
+  a.nbn = (a.NP + 127) / 128;
+  a.nkt = a.Rtrue / kHaloKS;                 // stages (the split-K bookkeeping of the kernel counts in these)
+  int splits = slab ? halo_splits(a) : 1;
+  a.tilesPerSplit = (a.nkt + splits - 1) / splits;
+  splits = (a.nkt + a.tilesPerSplit - 1) / a.tilesPerSplit;
+  a.NPs = (a.NP + 3) & ~3;
+  a.slab = splits > 1 ? slab : nullptr;
+  if (a.slab) a.statPart = nullptr;
+  a.dbgCycles = nullptr;
+  {
+    const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
+    ProfScope ps(3 * 100, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2>), dim3(a.nbm * a.nbn, splits), dim3(256), 0, st, a);
+  }
+  XM_LAUNCH_CHECK();
+  if (splits > 1) {
+    const bool vec = a.vecStore && (a.NP & 3) == 0 && ((uintptr_t)a.slab & 15) == 0;
+    const size_t n = (size_t)a.M * (vec ? a.NP / 4 : a.NP);
+    if (vec)
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         a, splits, make_fastdiv((uint32_t)(a.NP / 4)));
+    else
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         a, splits, make_fastdiv((uint32_t)a.NP));
+    XM_LAUNCH_CHECK();
+  }
+  return XM_OK;
+}
+
 static int choose_cfg(long long M, long long NP, int nkt) {
   return g_force_cfg >= 0 ? g_force_cfg : pick_cfg(M, NP, nkt);
 }
@@ -594,6 +671,40 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
     fprintf(stderr, "  -> [xm tune] kind %d M %d NP %d Rp %d (%d %d %d %d %d): cfg%d %.3f ms\n", key.kind, key.M,
             key.NP, key.Rp, key.mode, key.a, key.b, key.c, key.d, bi, best);
   return bi;
+}
+
+// Incumbent (0) against a challenger (1): the two are timed ALTERNATELY, four rounds, best-of each, and the challenger
+// has to win by `margin` -- a choice within the noise of two timed launches flipped between processes, and an
+// alternative that is only as fast in isolation loses when its blocks share the chip (larger LDS footprint).
+template <class F>
+static int tune_pair(const TuneKey &key, hipStream_t st, F &&launch, float margin) {
+  if (!autotune_enabled()) return 0;
+  tune_load_once();
+  auto it = g_tuned.find(key);
+  if (it != g_tuned.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
+  float tmin[2] = {1e30f, 1e30f};
+  for (int rep = 0; rep < 4; ++rep)
+    for (int ci = 0; ci < 2; ++ci) {
+      (void)hipEventRecord(e0, st);
+      if (launch(ci) != XM_OK) continue;
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) continue;
+      float ms = 0.f;
+      if (rep > 0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) tmin[ci] = std::min(tmin[ci], ms);
+    }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const int pick = tmin[1] < (1.f - margin) * tmin[0] ? 1 : 0;
+  g_tuned[key] = pick;
+  ++g_tune_new;
+  if (getenv("XM_TUNE_VERBOSE"))
+    fprintf(stderr, "[xm tune] kind %d M %d NP %d Rp %d: incumbent %.3f ms, challenger %.3f ms -> %d\n", key.kind, key.M,
+            key.NP, key.Rp, tmin[0], tmin[1], pick);
+  return pick;
 }
 
 template <int AV>
@@ -832,6 +943,11 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     int sp;
     slabf = std::max(slabf, gemm_slab_floats(proto, c, &sp));
   }
+  if (g.FH == 3 && g.FW == 3 && g.R % kHaloKS == 0) {   // the halo-patch kernel splits in stages of 72
+    ConvGemmArgs ph = proto;
+    ph.Rtrue = g.R;
+    slabf = std::max(slabf, halo_slab_floats(ph));
+  }
   // LDS-DMA eligibility: a plain GEMM in memory (1x1, unit stride, no padding), pixel quads inside one sample,
   // 16-byte aligned operands
   const bool dma_ok = !need_pad && mode == 0 && g.FH == 1 && g.FW == 1 && g.sy == 1 && g.sx == 1 && g.dy == 1 &&
@@ -933,7 +1049,27 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
-    rc = run(ci);
+    // 3 x 3 / unit stride: the halo-patch kernel against the best implicit-GEMM configuration (measured once per shape)
+    ConvGemmArgs ah = a;
+    bool use_halo = false;
+    if (g_force_cfg < 0 && g_force_splits == 0 && halo_setup(ah, g.N)) {
+      auto run2 = [&](int h) {
+        if (!h) return run(ci);
+        ConvGemmArgs aa = ah;
+        stat_ncg = 0;
+        if (stats_ok && halo_splits(aa) == 1) {
+          stat_ncg = (a.NP + 127) / 128;
+          aa.statPart = statp;
+          aa.statNcg = stat_ncg;
+        }
+        return launch_halo(aa, slab, st);
+      };
+      TuneKey hkey{4, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      use_halo = g_force_halo >= 0 ? g_force_halo != 0 : tune_pair(hkey, st, run2, kHaloMargin) != 0;
+      rc = run2(use_halo ? 1 : 0);
+    } else {
+      rc = run(ci);
+    }
     if (rc) return rc;
     if (stat_ncg > 0) {
       const int S = std::max(1, std::min(64, stat_ncg / 256));
@@ -1059,6 +1195,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     for (int ci = 0; ci < kNumBaseCfg; ++ci) {
       int sp;
       slab_max = std::max(slab_max, gemm_slab_floats(proto, ci, &sp));
+    }
+    if (c.nU == 3 && c.nV == 3 && c.Rc % kHaloKS == 0) {
+      proto.Rtrue = c.Rc;
+      slab_max = std::max(slab_max, halo_slab_floats(proto));
     }
   }
   // transposed filters: from the persistent cache when a current entry exists (or is being built now), else scratch
@@ -1215,7 +1355,15 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       };
       TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
       int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run);
-      rc = run(ci);
+      ConvGemmArgs ah = a;
+      if (g_force_cfg < 0 && g_force_splits == 0 && !foldH && halo_setup(ah, g.N)) {
+        auto run2 = [&](int h) { return h ? launch_halo(ah, slab, st) : run(ci); };
+        TuneKey hkey{5, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
+        const bool use_halo = g_force_halo >= 0 ? g_force_halo != 0 : tune_pair(hkey, st, run2, kHaloMargin) != 0;
+        rc = run2(use_halo ? 1 : 0);
+      } else {
+        rc = run(ci);
+      }
       if (rc) return rc;
     }
   }
@@ -1355,6 +1503,11 @@ int xm_debug_force_conv_cfg(int cfg) {
   return old;
 }
 int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
+int xm_debug_force_conv_halo(int on) {
+  int old = g_force_halo;
+  g_force_halo = on < 0 ? -1 : (on ? 1 : 0);
+  return old;
+}
 
 // ---- persistent tuning table (include/xmodal.h) ----------------------------------------------
 int xm_tune_load(const char *path) {
@@ -1477,6 +1630,10 @@ int xm_prof_collect_bytes(int cap, int *keys, double *total_bytes) {
 // human-readable kernel name of a profiler key, matching the rocprofv3 kernel-trace name
 int xm_prof_kernel_name(int key, char *buf, int len) {
   int kind = key / 100;
+  if (kind == 3) {
+    snprintf(buf, len, "conv_halo_kernel<2, 2, 2, 2>");
+    return XM_OK;
+  }
   int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;
   if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
   const Cfg &c = kCfgs[ci];

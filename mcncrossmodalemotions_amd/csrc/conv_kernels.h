@@ -66,6 +66,12 @@ struct ConvGemmArgs {
   // moments of the train-mode bnorm that follows the convolution then cost no second pass over Y (conv_forward).
   float *statPart;
   int statNcg;        // number of pixel tiles (= nbn)
+  // conv_halo_kernel (3 x 3 taps, unit stride): geometry of the zero-padded input patch a pixel tile works from.
+  // Patch row 0 / padded column 0 of a sample are source row hpRmin / source column hpCmin; a column has hpHP rows, a
+  // sample hpWP padded columns; tap t = iu + 3 iv sits hpSh[t] BYTES behind a pixel's own patch position.
+  int hpHP, hpWP, hpRmin, hpCmin, hpN;
+  int hpSh[9];
+  FastDiv hpDivHP, hpDivWP;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
   unsigned long long *dbgCycles;  // debug (xm_debug_conv_cycles): per-block {first clock, last clock, HW_ID, XCC_ID}
 };
@@ -920,6 +926,204 @@ conv_gemm_dma_kernel(const ConvGemmArgs a) {
 #undef XM_DREAD
 #undef XM_DMFMA
 #undef XM_DSCHED
+}
+
+// ------------------------------------------------------------------------------------------
+// Halo-patch variant for 3 x 3 convolutions with unit stride (student conv3-5, the sixteen 3 x 3 layers of the
+// ResNet-50 teachers, and their dgrads -- 45 % of the FLOPs of a distillation step).
+// conv_gemm_kernel fetches every input element once PER TAP (nine gathers through the texture path, each with its
+// own address arithmetic and padding mask) and meets at a barrier every 16 reduction steps.  Here a stage is 8 input
+// channels: the zero-padded input PATCH under the block's 128 output pixels (all taps of all its pixels: <= 512
+// floats per channel) goes global -> registers -> LDS ONCE, padding rows / columns and sample gaps as out-of-range
+// buffer loads (zeros); the nine taps then read their B operand straight from the patch -- `ds_read_b32` at the lane's
+// own patch position + a per-tap shift + a compile-time channel offset, no VALU, no masks -- for 72 reduction steps
+// (288 MFMAs per wave) between barriers.  The filter operand is reordered while it is parked in LDS so that MFMA e of
+// tap t multiplies channels e (lanes 0-31) / e + 4 (lanes 32-63):  k = 8 t + c.
+//   LDS  A [18 k-groups][128 rows][4]  37 KB   +   patch [8 channels][512]  16 KB   (one stage; the next stage's
+//   operands wait in registers while this one is multiplied -- two blocks per CU overlap the store phases)
+// Epilogue, accumulator map, split-free launch geometry: conv_gemm_kernel's.
+constexpr int kHaloT = 9, kHaloCB = 8, kHaloKS = kHaloT * kHaloCB, kHaloPS = 512;
+
+#ifndef XM_HALO_OCC
+#define XM_HALO_OCC 2
+#endif
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(256, XM_HALO_OCC)
+conv_halo_kernel(const ConvGemmArgs a) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  static_assert(BM == 128 && WGM * WGN == 4, "two staging threads per filter row, four waves");
+  constexpr int NGRP = kHaloKS / 4;            // 18 k-groups of four
+  constexpr int PLA = BM * 4 + 4;              // floats per k-group plane
+  constexpr int PS = kHaloPS;
+  __shared__ __attribute__((aligned(16))) float smem[NGRP * PLA + kHaloCB * PS];
+  float *sA = smem;
+  float *sP = smem + NGRP * PLA;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave % WGM, wn = wave / WGM;
+  const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+  const int bm = tile % a.nbm, bn = tile / a.nbm;
+  const int half = lane >> 5, l31 = lane & 31;
+  // stages = channels / 8; split-K (grid.y) hands every split a contiguous range of them
+  const int split = blockIdx.y;
+  const int st0 = split * a.tilesPerSplit;
+  const int nst = min(a.nkt, st0 + a.tilesPerSplit) - st0;
+
+  // ---- A staging: thread (row = t / 2, h = t % 2) moves 36 consecutive reduction indices of its row per stage ----
+#ifndef XM_HALO_VARIANT
+#define XM_HALO_VARIANT 0
+#endif
+#if XM_HALO_VARIANT == 6 || XM_HALO_VARIANT == 7
+  const float *arow = a.A + 36 * (t & 1) + (size_t)st0 * kHaloKS;     // experiment: every thread the same filter row
+#else
+  const float *arow = a.A + (size_t)min(bm * BM + (t >> 1), a.M - 1) * a.lda + 36 * (t & 1) + (size_t)st0 * kHaloKS;
+#endif
+  float *sAw = sA + (t & 1) * PLA + (t >> 1) * 4;
+
+  // ---- patch staging: thread owns patch positions 4 (t % 128) .. + 3 of channels 2 i + t / 128 (i = 0..3) ----
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  unsigned poff[4], pinv[4];
+  int jjp0;
+  {
+    const uint32_t p0 = (uint32_t)min(bn * BN, a.NP - 1);
+    const uint32_t n0 = xm_div(p0, a.divPIJ);
+    const uint32_t q0 = p0 - n0 * a.divPIJ.d;
+    jjp0 = (int)(n0 * (uint32_t)a.hpWP + xm_div(q0, a.divPI));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t pos = 4u * (uint32_t)(t & 127) + d;
+      const uint32_t col = xm_div(pos, a.hpDivHP), r = pos - col * (uint32_t)a.hpHP;
+      const uint32_t jjp = (uint32_t)jjp0 + col;
+      const uint32_t n = xm_div(jjp, a.hpDivWP), jl = jjp - n * (uint32_t)a.hpWP;
+      const int sr = (int)r + a.hpRmin, sc = (int)jl + a.hpCmin;
+      const bool ok = (unsigned)sr < (unsigned)a.LimH && (unsigned)sc < (unsigned)a.LimW && (int)n < a.hpN;
+      poff[d] = (unsigned)(sr + a.LimH * sc + (int)n * a.xSampleStride) * 4u;
+      pinv[d] = ok ? 0u : 0xFFFFFFFFu;
+#if XM_HALO_VARIANT == 5 || XM_HALO_VARIANT == 7
+      pinv[d] = 0xFFFFFFFFu;                   // experiment: every patch load out of range (no memory traffic)
+#endif
+    }
+  }
+  const unsigned chBytes = (unsigned)(a.LimH * a.LimW) * 4u;
+  const int chalf = wave >> 1;                 // t / 128, wave-uniform
+  float *sPw = sP + chalf * PS + 4 * (t & 127);
+
+  // ---- per-lane patch position of the wave's pixels ----
+  const float *pb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const uint32_t p = (uint32_t)min(bn * BN + (wn * TN + j) * 32 + l31, a.NP - 1);
+    const uint32_t n = xm_div(p, a.divPIJ);
+    const uint32_t q = p - n * a.divPIJ.d;
+    const uint32_t jj = xm_div(q, a.divPI), ii = q - jj * a.divPI.d;
+    pb[j] = sP + half * 4 * PS + (int)ii + a.hpHP * ((int)(n * (uint32_t)a.hpWP + jj) - jjp0);
+  }
+  const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
+
+  f32x4 ra[9], rb[4];
+#define XM_HLOAD(S)                                                            \
+  _Pragma("unroll") for (int i = 0; i < 9; ++i)                                \
+    ra[i] = *reinterpret_cast<const f32x4 *>(arow + (S) * kHaloKS + 4 * i);    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                              \
+    const unsigned cb_ = (unsigned)((st0 + (S)) * kHaloCB + 2 * i + chalf) * chBytes;  \
+    rb[i].x = buf_load(xrsrc, (poff[0] + cb_) | pinv[0]);                      \
+    rb[i].y = buf_load(xrsrc, (poff[1] + cb_) | pinv[1]);                      \
+    rb[i].z = buf_load(xrsrc, (poff[2] + cb_) | pinv[2]);                      \
+    rb[i].w = buf_load(xrsrc, (poff[3] + cb_) | pinv[3]);                      \
+  }
+  // element e of unit i is reduction index 36 h + 4 i + e of the stage: channel 4 h + (4 i + e) / 9, tap (4 i + e) % 9,
+  // i.e. k = 8 tap + channel -> k-group 2 tap + h, slot (4 i + e) / 9  (h is folded into sAw)
+#define XM_HSTORE                                                              \
+  _Pragma("unroll") for (int i = 0; i < 9; ++i)                                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                              \
+      sAw[2 * ((4 * i + e) % 9) * PLA + (4 * i + e) / 9] = ra[i][e];           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
+    *reinterpret_cast<f32x4 *>(sPw + 2 * i * PS) = rb[i];
+#define XM_HREAD(TAP, AF, BF)                                                  \
+  {                                                                            \
+    const int sh_ = a.hpSh[TAP] >> 2;                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
+      AF[i] = *reinterpret_cast<const f32x4 *>(sAr + 2 * (TAP) * PLA + i * 128); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                             \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                            \
+        BF[j][e] = pb[j][sh_ + e * PS];                                        \
+  }
+#define XM_HMFMA(AF, BF)                                                       \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[i][e], BF[j][e], acc[i][j], 0, 0, 0);
+#define XM_HSCHED                                                              \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, 1, 0);                  \
+  }                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 af0[TM], af1[TM];
+  float bf0[TN][4], bf1[TN][4];
+
+  // The global loads of stage s + 1 are spread over ALL nine taps of stage s (one filter quad + two patch dwords per
+  // tap, each behind a few MFMAs): a wave issues in order, and a burst of 25 wave-wide loads -- most of them touching
+  // 64 different cache lines -- holds its issue slot until the memory pipeline has taken them all.
+#ifndef XM_HALO_NLT
+#define XM_HALO_NLT 7
+#endif
+  // part P of XM_HALO_NLT: filter quads P, P + NLT, ... and patch dwords likewise
+#define XM_HLOAD_PART(S, P)                                                    \
+  if ((P) < XM_HALO_NLT) {                                                     \
+    _Pragma("unroll") for (int i_ = (P); i_ < 9; i_ += XM_HALO_NLT)            \
+      ra[i_] = *reinterpret_cast<const f32x4 *>(arow + (S) * kHaloKS + 4 * i_); \
+    _Pragma("unroll") for (int u_ = (P); u_ < 16; u_ += XM_HALO_NLT) {         \
+      const unsigned cb_ = (unsigned)((st0 + (S)) * kHaloCB + 2 * (u_ >> 2) + chalf) * chBytes; \
+      rb[u_ >> 2][u_ & 3] = buf_load(xrsrc, (poff[u_ & 3] + cb_) | pinv[u_ & 3]); \
+    }                                                                          \
+  }
+#define XM_HSCHED_LD                                                           \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, 1, 0);                  \
+    if (q_ % 2 == 1) {                                                         \
+      __builtin_amdgcn_sched_group_barrier(XM_SGB_VALU, 3, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(XM_SGB_VMEM_RD, 1, 0);              \
+    }                                                                          \
+  }                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+  XM_HLOAD(0)
+  for (int s = 0; s < nst; ++s) {
+    if (s > 0) __syncthreads();     // every wave has read the last fragments of stage s - 1
+    XM_HSTORE
+    __syncthreads();
+    XM_HREAD(0, af0, bf0)
+    __builtin_amdgcn_sched_barrier(0);
+    const int sn = min(s + 1, nst - 1);   // (the last stage re-requests itself: no branch inside the scheduling regions)
+    XM_HREAD(1, af1, bf1) XM_HLOAD_PART(sn, 0) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+    XM_HREAD(2, af0, bf0) XM_HLOAD_PART(sn, 1) XM_HMFMA(af1, bf1) XM_HSCHED_LD
+    XM_HREAD(3, af1, bf1) XM_HLOAD_PART(sn, 2) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+    XM_HREAD(4, af0, bf0) XM_HLOAD_PART(sn, 3) XM_HMFMA(af1, bf1) XM_HSCHED_LD
+    XM_HREAD(5, af1, bf1) XM_HLOAD_PART(sn, 4) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+    XM_HREAD(6, af0, bf0) XM_HLOAD_PART(sn, 5) XM_HMFMA(af1, bf1) XM_HSCHED_LD
+    XM_HREAD(7, af1, bf1) XM_HLOAD_PART(sn, 6) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+    XM_HREAD(8, af0, bf0) XM_HLOAD_PART(sn, 7) XM_HMFMA(af1, bf1) XM_HSCHED_LD
+    XM_HLOAD_PART(sn, 8) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+  }
+#undef XM_HLOAD_PART
+#undef XM_HSCHED_LD
+#undef XM_HLOAD
+#undef XM_HSTORE
+#undef XM_HREAD
+#undef XM_HMFMA
+#undef XM_HSCHED
+  __syncthreads();                  // the epilogue's statistics path reuses the operand tiles
+  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31, smem);
 }
 
 // Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity

@@ -252,6 +252,82 @@ def test_conv_forward_with_batch_moments(gpu, case):
         L.xm_debug_force_conv_cfg(-1)
 
 
+# (H, W, C, N, K, pad): 3 x 3, unit stride -> conv_halo_kernel (forward: C % 8 == 0; dgrad: K % 8 == 0)
+HALO_CASES = [(30, 17, 16, 3, 40, (1, 1, 1, 1)),      # student conv3-5 geometry, M tail
+              (14, 14, 8, 5, 136, (1, 1, 1, 1)),      # tiles straddle samples (196 pixels each)
+              (7, 7, 24, 9, 64, (1, 1, 1, 1)),        # a 128-pixel tile covers three samples
+              (56, 56, 8, 2, 64, (1, 1, 1, 1)),       # long columns
+              (12, 20, 16, 2, 24, (0, 0, 0, 0)),      # no padding: output smaller than the input
+              (13, 11, 8, 3, 16, (2, 0, 1, 2)),       # asymmetric padding
+              (9, 6, 32, 4, 8, (1, 1, 1, 1)),
+              (7, 7, 128, 9, 64, (1, 1, 1, 1)),       # few tiles, 16 stages: split-K slabs + combine kernel
+              (14, 14, 64, 3, 136, (1, 1, 1, 1))]
+
+
+def _kernels_run(L, fn):
+    """names of the convolution kernels `fn` launched (profiler hooks of the library)"""
+    import ctypes as C
+    import torch
+    L.xm_prof_enable(1)
+    out = fn()
+    torch.cuda.synchronize()
+    L.xm_prof_enable(0)
+    cap = 32
+    keys, ms, fl, cnt = (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), (C.c_longlong * cap)()
+    n = L.xm_prof_collect(cap, keys, ms, fl, cnt)
+    names = []
+    for i in range(min(n, cap)):
+        buf = C.create_string_buffer(128)
+        L.xm_prof_kernel_name(keys[i], buf, 128)
+        names.append(buf.value.decode())
+    return out, names
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_kernel(gpu, case):
+    """3 x 3 unit-stride convolutions through the halo-patch kernel (input patch of 8 channels staged once in LDS, the
+    nine taps read from it): forward incl. the fused epilogue and the batch moments, and dgrad, against the oracle; the
+    profiler hooks prove which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, K, pad = case
+    rng = np.random.default_rng(H * 7 + W * 3 + C + K)
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, 3, 3, C, K), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, pad=pad, acc64=True)
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, df_ref, _ = O.vl_nnconv(x, f, b, dzdy, pad=pad, acc64=True)
+    xd, fd, bd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), vl.from_numpy(dzdy)
+    old = L.xm_debug_force_conv_halo(1)
+    try:
+        y, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, pad=pad))
+        assert any("halo" in n for n in names), names
+        close(vl.to_numpy(y), y_ref, what="halo fwd")
+        (dx, df, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, dd, pad=pad))
+        assert any("halo" in n for n in names) == (K % 8 == 0), names
+        close(vl.to_numpy(dx), dx_ref, what="halo dgrad")
+        close(vl.to_numpy(df), df_ref, what="wgrad next to halo dgrad")
+        # accumulate-into-dx epilogue
+        acc = rnd(rng, H, W, C, N)
+        dx2, _, _ = vl.vl_nnconv(xd, fd, bd, dd, pad=pad, no_der_filters=True, dx_accum=vl.from_numpy(acc))
+        close(vl.to_numpy(dx2), dx_ref + acc, what="halo dgrad + accum")
+        # fused epilogue (test-mode bnorm fold + residual + relu) and batch moments
+        sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+        res = rnd(rng, *y_ref.shape)
+        ref = np.maximum(y_ref * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1) + res, 0)
+        yf = vl.vl_nnconv(xd, fd, bd, pad=pad, scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)),
+                          residual=vl.from_numpy(res), relu=True)
+        close(vl.to_numpy(yf), ref, what="halo fused epilogue")
+        mo = vl.mat_empty(K, 2, device=xd.device)
+        ym = vl.vl_nnconv(xd, fd, bd, pad=pad, moments_out=mo)
+        _, m_ref = O.vl_nnbnorm(y_ref, O.F(np.ones(K)), O.F(np.zeros(K)), acc64=True)
+        close(vl.to_numpy(ym), y_ref, what="halo fwd + moments")
+        m = vl.to_numpy(mo)
+        close(m[:, 0], m_ref[:, 0], what="halo mean")
+        assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4
+    finally:
+        L.xm_debug_force_conv_halo(old)
+
+
 def test_conv_fused_epilogue(gpu):
     from mcncrossmodalemotions_amd import vl
     rng = np.random.default_rng(11)
