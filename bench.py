@@ -131,10 +131,6 @@ def host_info():
 
 def main():
     args = parse()
-    # CPU baseline threads: one per physical core, pinned (must be in the environment before the first OpenMP
-    # runtime of the process -- torch's -- starts)
-    os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
     if args.workload == "cpu-teacher":
         return cpu_teacher_line(args)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
@@ -704,16 +700,18 @@ def _cpu_pass(wl, pairs, W):
 
 def cpu_baseline(wl, pairs, W, passes=3):
     """MatConvNet-CPU-equivalent restatement (oracle fp32 path: im2row + vectorised SGEMM, images in parallel,
-    OpenMP, one thread pinned to each physical core -- OMP_PLACES / OMP_PROC_BIND are set in main() before any
-    OpenMP runtime starts) on a bounded sample of the same workload: `passes` timed passes, the MEDIAN is the value,
+    OpenMP, one thread pinned to each physical core by oracle.pin_threads) on a bounded sample of the same workload: `passes` timed passes, the MEDIAN is the value,
     min / max are in the line (a shared host moved single passes by 30 % between boxes).  Checker code used as a timed
     baseline only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv would be faster still
     (this SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an upper bound."""
     from oracle import oracle as O
-    cores = O.set_num_threads()          # one thread per physical core this process may use
+    cores, restore = O.pin_threads()     # one thread per physical core this process may use, pinned to it
     if pairs <= 0:
         pairs = max(16, cores // 8)
-    runs = [_cpu_pass(wl, pairs, W) for _ in range(max(1, passes))]
+    try:
+        runs = [_cpu_pass(wl, pairs, W) for _ in range(max(1, passes))]
+    finally:
+        restore()
     ts = sorted(t for t, _ in runs)
     med, gflop = ts[len(ts) // 2], runs[0][1]
     return {"value": round(pairs / med, 4), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",

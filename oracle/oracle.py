@@ -362,6 +362,45 @@ def physical_cores():
     return len(seen) or len(allowed)
 
 
+def physical_core_cpus():
+    """one logical CPU id per physical core this process may run on (the first SMT sibling)"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+    first, cur = {}, {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur and int(cur["processor"]) in allowed:
+                    first.setdefault((cur.get("physical id", "0"), cur.get("core id", cur["processor"])),
+                                     int(cur["processor"]))
+                cur = {}
+                continue
+            k, v = line.split(":", 1)
+            cur[k.strip()] = v.strip()
+    except OSError:
+        pass
+    return sorted(first.values()) or sorted(allowed)
+
+
 def set_num_threads(n=None):
     lib().orc_set_num_threads(int(n or physical_cores()))
     return num_threads()
+
+
+def pin_threads():
+    """one OpenMP thread per physical core, each pinned to its core (timed baselines); returns (threads, restore):
+    call restore() afterwards -- the calling thread is team member 0 and was pinned as well."""
+    cpus = physical_core_cpus()
+    try:
+        before = os.sched_getaffinity(0)
+    except AttributeError:
+        before = None
+    arr = (C.c_int * len(cpus))(*cpus)
+    lib().orc_pin_threads(arr, len(cpus))
+
+    def restore():
+        if before is not None:
+            os.sched_setaffinity(0, before)
+    return num_threads(), restore

@@ -34,6 +34,10 @@
  * algorithm shape (also the timed "MatConvNet-CPU-equivalent" baseline),
  * 1 = same maths with fp64 accumulators (error-budget ground truth).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
 #include <float.h>
 #include <math.h>
 #include <stddef.h>
@@ -52,6 +56,28 @@ void orc_set_num_threads(int n) {
 #else
   (void)n;
 #endif
+}
+
+/* one OpenMP thread per entry of `cpus`, thread i pinned to logical CPU cpus[i] (the timed CPU baseline of bench.py:
+ * one thread per physical core; unpinned teams on a shared host moved the figure by 30 % between boxes).  Returns the
+ * number of threads that could be pinned.  The calling thread is thread 0: the caller restores its affinity. */
+int orc_pin_threads(const int *cpus, int n) {
+  int pinned = 0;
+#ifdef _OPENMP
+  if (n <= 0) return 0;
+  omp_set_num_threads(n);
+#pragma omp parallel num_threads(n) reduction(+ : pinned)
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpus[omp_get_thread_num() % n], &set);
+    if (sched_setaffinity(0, sizeof set, &set) == 0) pinned += 1;
+  }
+#else
+  (void)cpus;
+  (void)n;
+#endif
+  return pinned;
 }
 
 int orc_num_threads(void) {

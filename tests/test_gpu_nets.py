@@ -1,5 +1,7 @@
 """GPU end-to-end parity: whole graphs (student step, teachers) through the dagnn mirror over the
 HIP C ABI vs the same graphs executed by the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -453,3 +455,39 @@ def test_bucketed_gradient_exchange(gpu):
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+def test_shipped_tuning_table_covers_the_bench_step(gpu):
+    """Every convolution shape of the default bench step (full ResNet-50 teacher forward on 32 faces, full-width student
+    step on 32 spectrograms 512x300, wgrad side stream as in bench.py) is in the shipped tile-configuration table: the
+    step adds no measured entry, so tile choices -- and with them the summation order / the bits of every result -- are
+    the same in every process (include/xmodal.h, xm_tune_load)."""
+    import ctypes as C
+    import torch
+    from mcncrossmodalemotions_amd import _lib, batch as xbatch, train, vl, zoo
+    L = _lib.load()
+    if os.environ.get("XM_TUNE_FILE") is not None or os.environ.get("XM_AUTOTUNE") == "0":
+        pytest.skip("non-default tuning table")
+    teacher = zoo.ferPlusZoo("resnet50-ferplus", seed=100)
+    zoo.strip_losses(teacher)
+    teacher.move("gpu")
+    teacher.mode = "test"
+    teacher.vars["prediction"].precious = True
+    student = zoo.emoVoxZoo("emovoxceleb-student", scratch=1, lossType="hot-cross-ent", numSeconds=3, numOutputs=8, seed=200)
+    student.pack_params()
+    student.wgradStream = torch.cuda.Stream()
+    faces = xbatch.getImageBatch(32, seed=4)
+    raw = torch.randn((32, 1, 300, 512), device="cuda").abs_()
+    spec = vl.spec_rownorm(raw.permute(3, 2, 1, 0))
+    tot, new0, new1 = C.c_int(), C.c_int(), C.c_int()
+    L.xm_tune_load(None)          # (an earlier test of this process may have pointed the loader at another file)
+    L.xm_tune_entries(C.byref(tot), C.byref(new0))
+    opts = train.TrainOpts(batchSize=32)
+    for it in range(2):
+        teacher.eval(["data", faces])
+        tl = teacher.vars["prediction"].value
+        train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", vl.max_label(tl)], opts, it, None, 32)
+    torch.cuda.synchronize()
+    L.xm_tune_entries(C.byref(tot), C.byref(new1))
+    assert new1.value == new0.value, "the bench step measured %d tile configurations that the shipped table lacks" % (
+        new1.value - new0.value)
