@@ -20,7 +20,8 @@ int xm_prof_kernel_name(int key, char *buf, int len);
 /* test hooks: force one tile configuration for every convolution launch (-1 = automatic) */
 int xm_debug_force_conv_cfg(int cfg);
 int xm_debug_num_conv_cfgs(void);
-/* 1: the halo-patch kernel (3 x 3, unit stride) wherever it can run; 0: never; -1: measured choice (default) */
+/* 1 + v: halo-patch kernel variant v (0: 128-row tiles, 1: 96-row tiles, 2: 96-row tiles / tall patch) wherever it can
+ * run, another runnable variant otherwise; 0: never; -1: measured choice (default) */
 int xm_debug_force_conv_halo(int on);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);

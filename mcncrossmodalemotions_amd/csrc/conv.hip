@@ -484,26 +484,36 @@ static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipS
   return XM_OK;
 }
 
-// ---- halo-patch kernel (conv_halo_kernel): 3 x 3 taps, unit stride ------------------------------------------------
-// fills the patch geometry of `a` (an implicit-GEMM problem already described by its tap / gather fields) and says
-// whether the kernel can run it: nine taps in a 3 x 3 arrangement, unit pixel stride, channels a multiple of 8, and the
-// zero-padded patch under any 128-pixel tile within 512 floats per channel.
+// ---- halo-patch kernels (conv_halo_kernel / conv_halo_multi_kernel): <= 3 x 3 taps, unit pixel stride ---------------
+// Variants: 0 = 128-row tiles (2 x 2 wave tiles), patch 512;  1 = 96-row tiles (3 x 1), patch 512;
+//           2 = 96-row tiles, patch 1024 (tall columns: the student's conv2 dgrad classes have 65-row patch columns)
+struct HaloVar {
+  int bm, ps;
+};
+static const HaloVar kHaloVars[] = {{128, 512}, {96, 512}, {96, 1024}};
 static const float kHaloMargin = getenv("XM_HALO_MARGIN") ? (float)atof(getenv("XM_HALO_MARGIN")) : 0.04f;
-static bool halo_setup(ConvGemmArgs &a, int nSamples) {
+
+// fills the patch geometry of `a` (an implicit-GEMM problem already described by its tap / gather fields) and returns
+// the patch floats per channel the widest 128-pixel tile needs (0: the kernel cannot run this problem): taps in an
+// nU x nV <= 3 x 3 arrangement of 9 / 6 / 4, adjacent rows / columns, unit pixel stride, channels a multiple of 8.
+static int halo_setup(ConvGemmArgs &a, int nSamples) {
   static const bool off = getenv("XM_NO_HALO") != nullptr;
-  if (off || a.nU != 3 || a.nV != 3 || a.gsy != 1 || a.gsx != 1) return false;
-  if (a.Rtrue % kHaloKS != 0 || a.Rtrue < kHaloKS || (a.lda & 3) || ((uintptr_t)a.A & 15)) return false;
-  if (std::abs(a.dus) != 1 || std::abs(a.dvs) != 1) return false;     // dilation 1 (taps are adjacent rows / columns)
-  const int rlo = a.gh0 + a.du0 + std::min(0, 2 * a.dus), clo = a.gw0 + a.dv0 + std::min(0, 2 * a.dvs);
+  const int T = a.nU * a.nV;
+  if (off || a.nU < 1 || a.nU > 3 || a.nV < 1 || a.nV > 3 || (T != 9 && T != 6 && T != 4)) return 0;
+  if (a.gsy != 1 || a.gsx != 1 || std::abs(a.dus) != 1 || std::abs(a.dvs) != 1) return 0;
+  const int KS = kHaloCB * T;
+  if (a.Rtrue % KS != 0 || a.Rtrue < KS || (a.lda & 3) || ((uintptr_t)a.A & 15)) return 0;
+  if (a.divMU.d != 1) return 0;
+  const int rlo = a.gh0 + a.du0 + std::min(0, (a.nU - 1) * a.dus), clo = a.gw0 + a.dv0 + std::min(0, (a.nV - 1) * a.dvs);
   a.hpRmin = rlo;
   a.hpCmin = clo;
-  a.hpHP = a.PI + 2;
-  a.hpWP = a.PJ + 2;
+  a.hpHP = a.PI + a.nU - 1;
+  a.hpWP = a.PJ + a.nV - 1;
   a.hpN = nSamples;
-  for (int iv = 0; iv < 3; ++iv)
-    for (int iu = 0; iu < 3; ++iu) {
+  for (int iv = 0; iv < a.nV; ++iv)
+    for (int iu = 0; iu < a.nU; ++iu) {
       const int su = a.gh0 + a.du0 + iu * a.dus - rlo, sv = a.gw0 + a.dv0 + iv * a.dvs - clo;
-      a.hpSh[iu + 3 * iv] = (su + a.hpHP * sv) * 4;
+      a.hpSh[iu + a.nU * iv] = (su + a.hpHP * sv) * 4;
     }
   a.hpDivHP = make_fastdiv((uint32_t)a.hpHP);
   a.hpDivWP = make_fastdiv((uint32_t)a.hpWP);
@@ -513,37 +523,85 @@ static bool halo_setup(ConvGemmArgs &a, int nSamples) {
   for (long long p0 = 0; p0 < a.NP; p0 += BN) {
     const long long p1 = std::min<long long>(p0 + BN - 1, a.NP - 1);
     const long long c0 = (p0 / pij) * a.hpWP + (p0 % pij) / a.PI, c1 = (p1 / pij) * a.hpWP + (p1 % pij) / a.PI;
-    worst = std::max(worst, (int)(c1 - c0) + 3);
+    worst = std::max(worst, (int)(c1 - c0) + a.nV);
   }
-  return worst * a.hpHP <= kHaloPS;
+  return worst * a.hpHP;
+}
+// Tall pixel grids (the student's conv2 dgrad classes: 63 / 62 rows) put 3-4 columns + taps + a sample gap under a
+// 128-pixel tile -- more than 512 patch floats.  Enumerating the pixels with PI rounded up to a multiple of 32 makes a tile
+// a whole number of columns (2 of 64): the patch shrinks below 512 floats and the 96-row / 512 variant (3 blocks per CU,
+// half the patch loads) applies; the non-existent rows (1.6 %) are computed and dropped in the epilogue (piReal).
+// Only for scalar-store problems whose padding waste stays under 4 %.
+static int halo_setup_padded(ConvGemmArgs &a, int nSamples) {
+  int need = halo_setup(a, nSamples);
+  if (need <= 512 || a.vecStore || a.slab) return need;
+  const int piv = (a.PI + 31) / 32 * 32;
+  if (piv == a.PI || (piv - a.PI) * 25 > piv || (long long)piv * a.PJ * nSamples >= (1LL << 31)) return need;
+  ConvGemmArgs b = a;
+  b.piReal = a.PI;
+  b.PI = piv;
+  b.NP = piv * a.PJ * nSamples;
+  b.divPI = make_fastdiv((uint32_t)piv);
+  b.divPIJ = make_fastdiv((uint32_t)(piv * a.PJ));
+  const int need2 = halo_setup(b, nSamples);
+  if (need2 > 0 && need2 <= 512) {
+    a = b;
+    return need2;
+  }
+  return need;
 }
 
-// split-K for the halo kernel: stages of 72 reduction steps; one round of 2 blocks per CU, >= 4 stages per split
-static int halo_splits(const ConvGemmArgs &a) {
-  const int tiles = ((a.M + 127) / 128) * ((a.NP + 127) / 128), nst = a.Rtrue / kHaloKS;
+static bool halo_var_ok(const ConvGemmArgs &a, int need, int v) {
+  if (need <= 0 || need > kHaloVars[v].ps) return false;
+  if (v == 2 && need <= 512) return false;                       // variant 1 covers it with half the patch loads
+  if (kHaloVars[v].bm == 96 && (a.M % 96 != 0)) return false;    // 96-row tiles only where they waste nothing
+  return true;
+}
+
+// split-K: stages of 8 T reduction steps; one round of 2 blocks per CU, >= 4 stages per split
+static int halo_splits(const ConvGemmArgs &a, int v) {
+  const int bm = kHaloVars[v].bm;
+  const int tiles = ((a.M + bm - 1) / bm) * ((a.NP + 127) / 128), nst = a.Rtrue / (kHaloCB * a.nU * a.nV);
   if (tiles >= 384 || nst < 8) return 1;
   return std::max(1, std::min(std::min(512 / tiles, nst / 4), 16));
 }
 static size_t halo_slab_floats(const ConvGemmArgs &a) {
-  const int sp = halo_splits(a);
+  int sp = 1;
+  for (int v = 0; v < 3; ++v) sp = std::max(sp, halo_splits(a, v));
   return sp > 1 ? (size_t)sp * a.M * ((a.NP + 3) & ~3) : 0;
 }
 
-static int launch_halo(ConvGemmArgs a, float *slab, hipStream_t st) {
-  a.nbm = (a.M + 127) / 128;
+static void halo_prepare(ConvGemmArgs &a, int v) {
+  const int bm = kHaloVars[v].bm;
+  a.nbm = (a.M + bm - 1) / bm;
   a.nbn = (a.NP + 127) / 128;
-  a.nkt = a.Rtrue / kHaloKS;                 // stages (the split-K bookkeeping of the kernel counts in these)
-  int splits = slab ? halo_splits(a) : 1;
+  a.nkt = a.Rtrue / (kHaloCB * a.nU * a.nV);   // stages (the split-K bookkeeping of the kernel counts in these)
+  a.tilesPerSplit = a.nkt;
+  a.NPs = (a.NP + 3) & ~3;
+  a.slab = nullptr;
+  a.dbgCycles = nullptr;
+}
+
+// test hook: xm_debug_force_conv_halo(1 + v) asks for variant v, any other runnable one if v cannot take the problem
+static int forced_halo_variant(const bool *hok) {
+  if (g_force_halo >= 1 && g_force_halo <= 3 && hok[g_force_halo]) return g_force_halo;
+  return hok[2] ? 2 : (hok[1] ? 1 : 3);
+}
+
+static int launch_halo(ConvGemmArgs a, int v, float *slab, hipStream_t st) {
+  halo_prepare(a, v);
+  int splits = slab ? halo_splits(a, v) : 1;
   a.tilesPerSplit = (a.nkt + splits - 1) / splits;
   splits = (a.nkt + a.tilesPerSplit - 1) / a.tilesPerSplit;
-  a.NPs = (a.NP + 3) & ~3;
   a.slab = splits > 1 ? slab : nullptr;
   if (a.slab) a.statPart = nullptr;
-  a.dbgCycles = nullptr;
   {
     const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
-    ProfScope ps(3 * 100, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
-    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2>), dim3(a.nbm * a.nbn, splits), dim3(256), 0, st, a);
+    ProfScope ps(3 * 100 + v, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
+    const dim3 grid(a.nbm * a.nbn, splits), block(256);
+    if (v == 0) hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 512>), grid, block, 0, st, a);
+    else if (v == 1) hipLaunchKernelGGL((conv_halo_kernel<3, 1, 1, 4, 512>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_halo_kernel<3, 1, 1, 4, 1024>), grid, block, 0, st, a);
   }
   XM_LAUNCH_CHECK();
   if (splits > 1) {
@@ -557,6 +615,30 @@ static int launch_halo(ConvGemmArgs a, float *slab, hipStream_t st) {
                          a, splits, make_fastdiv((uint32_t)a.NP));
     XM_LAUNCH_CHECK();
   }
+  return XM_OK;
+}
+
+// the stride-parity classes of a strided dgrad in one launch (no split-K), all through halo variant v
+static int launch_halo_multi(const std::vector<ConvGemmArgs> &args, int v, hipStream_t st) {
+  ConvGemmMulti m{};
+  int maxTiles = 0;
+  double flops = 0, abytes = args.empty() ? 0.0 : (double)args[0].xBytes;
+  for (size_t i = 0; i < args.size(); ++i) {
+    ConvGemmArgs a = args[i];
+    halo_prepare(a, v);
+    maxTiles = std::max(maxTiles, a.nbm * a.nbn);
+    flops += a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue;
+    abytes += 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
+    m.c[i] = a;
+  }
+  {
+    ProfScope ps(4 * 100 + v, flops, st, abytes);
+    const dim3 grid(maxTiles, 1, (unsigned)args.size()), block(256);
+    if (v == 0) hipLaunchKernelGGL((conv_halo_multi_kernel<2, 2, 2, 2, 512>), grid, block, 0, st, m);
+    else if (v == 1) hipLaunchKernelGGL((conv_halo_multi_kernel<3, 1, 1, 4, 512>), grid, block, 0, st, m);
+    else hipLaunchKernelGGL((conv_halo_multi_kernel<3, 1, 1, 4, 1024>), grid, block, 0, st, m);
+  }
+  XM_LAUNCH_CHECK();
   return XM_OK;
 }
 
@@ -673,22 +755,25 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   return bi;
 }
 
-// Incumbent (0) against a challenger (1): the two are timed ALTERNATELY, four rounds, best-of each, and the challenger
-// has to win by `margin` -- a choice within the noise of two timed launches flipped between processes, and an
-// alternative that is only as fast in isolation loses when its blocks share the chip (larger LDS footprint).
+// Incumbent (0) against challengers (1 .. n - 1): all are timed ALTERNATELY, four rounds, best-of each (the first round
+// is a warm-up), and the best challenger has to win by `margin` -- a choice within the noise of two timed launches
+// flipped between processes, and an alternative that is only as fast in isolation loses when its blocks share the chip
+// (larger LDS footprint).  `ok[i]` = false skips a challenger.
 template <class F>
-static int tune_pair(const TuneKey &key, hipStream_t st, F &&launch, float margin) {
+static int tune_challengers(const TuneKey &key, hipStream_t st, F &&launch, int n, const bool *ok, float margin) {
   if (!autotune_enabled()) return 0;
   tune_load_once();
   auto it = g_tuned.find(key);
-  if (it != g_tuned.end()) return it->second;
+  if (it != g_tuned.end()) return (it->second < n && (it->second == 0 || ok[it->second])) ? it->second : 0;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
-  float tmin[2] = {1e30f, 1e30f};
+  float tmin[8];
+  for (int i = 0; i < 8; ++i) tmin[i] = 1e30f;
   for (int rep = 0; rep < 4; ++rep)
-    for (int ci = 0; ci < 2; ++ci) {
+    for (int ci = 0; ci < n && ci < 8; ++ci) {
+      if (ci > 0 && !ok[ci]) continue;
       (void)hipEventRecord(e0, st);
       if (launch(ci) != XM_OK) continue;
       (void)hipEventRecord(e1, st);
@@ -698,12 +783,15 @@ static int tune_pair(const TuneKey &key, hipStream_t st, F &&launch, float margi
     }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  const int pick = tmin[1] < (1.f - margin) * tmin[0] ? 1 : 0;
+  int pick = 0;
+  float best = (1.f - margin) * tmin[0];
+  for (int ci = 1; ci < n && ci < 8; ++ci)
+    if (tmin[ci] < best) best = tmin[ci], pick = ci;
   g_tuned[key] = pick;
   ++g_tune_new;
   if (getenv("XM_TUNE_VERBOSE"))
-    fprintf(stderr, "[xm tune] kind %d M %d NP %d Rp %d: incumbent %.3f ms, challenger %.3f ms -> %d\n", key.kind, key.M,
-            key.NP, key.Rp, tmin[0], tmin[1], pick);
+    fprintf(stderr, "[xm tune] kind %d M %d NP %d Rp %d: incumbent %.3f ms, challengers %.3f %.3f %.3f -> %d\n", key.kind,
+            key.M, key.NP, key.Rp, tmin[0], tmin[1], tmin[2], tmin[3], pick);
   return pick;
 }
 
@@ -943,9 +1031,11 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     int sp;
     slabf = std::max(slabf, gemm_slab_floats(proto, c, &sp));
   }
-  if (g.FH == 3 && g.FW == 3 && g.R % kHaloKS == 0) {   // the halo-patch kernel splits in stages of 72
+  if (g.FH <= 3 && g.FW <= 3 && g.FH * g.FW >= 4 && g.R % (kHaloCB * g.FH * g.FW) == 0) {   // halo-patch kernel splits
     ConvGemmArgs ph = proto;
     ph.Rtrue = g.R;
+    ph.nU = g.FH;
+    ph.nV = g.FW;
     slabf = std::max(slabf, halo_slab_floats(ph));
   }
   // LDS-DMA eligibility: a plain GEMM in memory (1x1, unit stride, no padding), pixel quads inside one sample,
@@ -1049,24 +1139,29 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
-    // 3 x 3 / unit stride: the halo-patch kernel against the best implicit-GEMM configuration (measured once per shape)
+    // <= 3 x 3 taps / unit stride: the halo-patch kernel variants against the best implicit-GEMM configuration
+    // (measured once per shape, alternating launches, the challenger must win by a margin)
     ConvGemmArgs ah = a;
-    bool use_halo = false;
-    if (g_force_cfg < 0 && g_force_splits == 0 && halo_setup(ah, g.N)) {
+    const int hneed = (g_force_cfg < 0 && g_force_splits == 0) ? halo_setup(ah, g.N) : 0;
+    bool hok[4] = {true, halo_var_ok(ah, hneed, 0), halo_var_ok(ah, hneed, 1), halo_var_ok(ah, hneed, 2)};
+    if (hok[1] || hok[2] || hok[3]) {
       auto run2 = [&](int h) {
         if (!h) return run(ci);
         ConvGemmArgs aa = ah;
         stat_ncg = 0;
-        if (stats_ok && halo_splits(aa) == 1) {
+        if (stats_ok && halo_splits(aa, h - 1) == 1) {
           stat_ncg = (a.NP + 127) / 128;
           aa.statPart = statp;
           aa.statNcg = stat_ncg;
         }
-        return launch_halo(aa, slab, st);
+        return launch_halo(aa, h - 1, slab, st);
       };
       TuneKey hkey{4, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-      use_halo = g_force_halo >= 0 ? g_force_halo != 0 : tune_pair(hkey, st, run2, kHaloMargin) != 0;
-      rc = run2(use_halo ? 1 : 0);
+      int pick;
+      if (g_force_halo == 0) pick = 0;
+      else if (g_force_halo > 0) pick = forced_halo_variant(hok);
+      else pick = tune_challengers(hkey, st, run2, 4, hok, kHaloMargin);
+      rc = run2(pick);
     } else {
       rc = run(ci);
     }
@@ -1196,8 +1291,10 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       int sp;
       slab_max = std::max(slab_max, gemm_slab_floats(proto, ci, &sp));
     }
-    if (c.nU == 3 && c.nV == 3 && c.Rc % kHaloKS == 0) {
+    if (!foldH && c.nU <= 3 && c.nV <= 3 && c.nU * c.nV >= 4 && c.Rc % (kHaloCB * c.nU * c.nV) == 0) {
       proto.Rtrue = c.Rc;
+      proto.nU = c.nU;
+      proto.nV = c.nV;
       slab_max = std::max(slab_max, halo_slab_floats(proto));
     }
   }
@@ -1356,11 +1453,16 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
       int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run);
       ConvGemmArgs ah = a;
-      if (g_force_cfg < 0 && g_force_splits == 0 && !foldH && halo_setup(ah, g.N)) {
-        auto run2 = [&](int h) { return h ? launch_halo(ah, slab, st) : run(ci); };
+      const int hneed = (g_force_cfg < 0 && g_force_splits == 0 && !foldH) ? halo_setup_padded(ah, g.N) : 0;
+      bool hok[4] = {true, halo_var_ok(ah, hneed, 0), halo_var_ok(ah, hneed, 1), halo_var_ok(ah, hneed, 2)};
+      if (hok[1] || hok[2] || hok[3]) {
+        auto run2 = [&](int h) { return h ? launch_halo(ah, h - 1, slab, st) : run(ci); };
         TuneKey hkey{5, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
-        const bool use_halo = g_force_halo >= 0 ? g_force_halo != 0 : tune_pair(hkey, st, run2, kHaloMargin) != 0;
-        rc = run2(use_halo ? 1 : 0);
+        int pick;
+        if (g_force_halo == 0) pick = 0;
+        else if (g_force_halo > 0) pick = forced_halo_variant(hok);
+        else pick = tune_challengers(hkey, st, run2, 4, hok, kHaloMargin);
+        rc = run2(pick);
       } else {
         rc = run(ci);
       }
@@ -1385,7 +1487,36 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     TuneKey key{3, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
                 g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(merged[0].M, npSum, rpMax / kBK), st, run);
-    rc = run(ci);
+    // every class a halo-patch problem (unit-stride gathers of <= 3 x 3 taps in dY space)?  Then the same variant for all
+    std::vector<ConvGemmArgs> mh = merged;
+    bool hok[4] = {true, g_force_cfg < 0, g_force_cfg < 0, g_force_cfg < 0};
+    for (ConvGemmArgs &a : mh) {
+      const int need = hok[1] || hok[2] || hok[3] ? halo_setup_padded(a, g.N) : 0;
+      for (int v = 0; v < 3; ++v) hok[v + 1] = hok[v + 1] && halo_var_ok(a, need, v);
+    }
+    if (hok[3] && !hok[2])      // the tall-patch variant may serve classes that would also fit the short one
+      ;
+    else if (!hok[3]) {         // classes of mixed patch height: let the tall variant take them all if each fits 1024
+      bool all = g_force_cfg < 0;
+      for (ConvGemmArgs &a : mh) {
+        ConvGemmArgs t = a;
+        const int need = all ? halo_setup_padded(t, g.N) : 0;
+        all = all && need > 0 && need <= 1024 && t.M % 96 == 0;
+      }
+      hok[3] = all && !hok[2];
+    }
+    if (hok[1] || hok[2] || hok[3]) {
+      auto run2 = [&](int h) { return h ? launch_halo_multi(mh, h - 1, st) : run(ci); };
+      TuneKey hkey{6, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
+                   g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      int pick;
+      if (g_force_halo == 0) pick = 0;
+      else if (g_force_halo > 0) pick = forced_halo_variant(hok);
+      else pick = tune_challengers(hkey, st, run2, 4, hok, kHaloMargin);
+      rc = run2(pick);
+    } else {
+      rc = run(ci);
+    }
     if (rc) return rc;
   }
   return XM_OK;
@@ -1505,7 +1636,7 @@ int xm_debug_force_conv_cfg(int cfg) {
 int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
 int xm_debug_force_conv_halo(int on) {
   int old = g_force_halo;
-  g_force_halo = on < 0 ? -1 : (on ? 1 : 0);
+  g_force_halo = on < 0 ? -1 : std::min(on, 3);
   return old;
 }
 
@@ -1630,8 +1761,10 @@ int xm_prof_collect_bytes(int cap, int *keys, double *total_bytes) {
 // human-readable kernel name of a profiler key, matching the rocprofv3 kernel-trace name
 int xm_prof_kernel_name(int key, char *buf, int len) {
   int kind = key / 100;
-  if (kind == 3) {
-    snprintf(buf, len, "conv_halo_kernel<2, 2, 2, 2>");
+  if (kind == 3 || kind == 4) {
+    const int v = key % 100;
+    snprintf(buf, len, "%s<%s, %d>", kind == 3 ? "conv_halo_kernel" : "conv_halo_multi_kernel",
+             v == 0 ? "2, 2, 2, 2" : "3, 1, 1, 4", v == 2 ? 1024 : 512);
     return XM_OK;
   }
   int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;

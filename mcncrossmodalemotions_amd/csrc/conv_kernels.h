@@ -70,6 +70,9 @@ struct ConvGemmArgs {
   // Patch row 0 / padded column 0 of a sample are source row hpRmin / source column hpCmin; a column has hpHP rows, a
   // sample hpWP padded columns; tap t = iu + 3 iv sits hpSh[t] BYTES behind a pixel's own patch position.
   int hpHP, hpWP, hpRmin, hpCmin, hpN;
+  // != 0: the pixel grid is enumerated with PI rounded UP (PI, divPI, divPIJ, NP describe the padded grid) so that a
+  // 128-pixel tile is a whole number of columns; rows >= piReal of every column do not exist and are never stored
+  int piReal;
   int hpSh[9];
   FastDiv hpDivHP, hpDivWP;
   double algoFlops;   // profiler only: algorithmic FLOPs of this launch (0 = 2*M*NP*Rtrue)
@@ -259,6 +262,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     uint32_t jj = xm_div(q, a.divPI);
     uint32_t ii = q - jj * a.divPI.d;
     obase[j] = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride;
+    if (a.piReal) pok[j] = pok[j] && (int)ii < a.piReal;
   }
   if (a.vecStore) {
     // Wide path (dword stores are issue-bound at ~2.5 TB/s on this chip): each group of 4
@@ -929,33 +933,38 @@ conv_gemm_dma_kernel(const ConvGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Halo-patch variant for 3 x 3 convolutions with unit stride (student conv3-5, the sixteen 3 x 3 layers of the
-// ResNet-50 teachers, and their dgrads -- 45 % of the FLOPs of a distillation step).
-// conv_gemm_kernel fetches every input element once PER TAP (nine gathers through the texture path, each with its
-// own address arithmetic and padding mask) and meets at a barrier every 16 reduction steps.  Here a stage is 8 input
-// channels: the zero-padded input PATCH under the block's 128 output pixels (all taps of all its pixels: <= 512
-// floats per channel) goes global -> registers -> LDS ONCE, padding rows / columns and sample gaps as out-of-range
-// buffer loads (zeros); the nine taps then read their B operand straight from the patch -- `ds_read_b32` at the lane's
-// own patch position + a per-tap shift + a compile-time channel offset, no VALU, no masks -- for 72 reduction steps
-// (288 MFMAs per wave) between barriers.  The filter operand is reordered while it is parked in LDS so that MFMA e of
-// tap t multiplies channels e (lanes 0-31) / e + 4 (lanes 32-63):  k = 8 t + c.
-//   LDS  A [18 k-groups][128 rows][4]  37 KB   +   patch [8 channels][512]  16 KB   (one stage; the next stage's
-//   operands wait in registers while this one is multiplied -- two blocks per CU overlap the store phases)
-// Epilogue, accumulator map, split-free launch geometry: conv_gemm_kernel's.
-constexpr int kHaloT = 9, kHaloCB = 8, kHaloKS = kHaloT * kHaloCB, kHaloPS = 512;
+// Halo-patch variant for unit-stride gathers with T = nU x nV <= 3 x 3 taps: the 3 x 3 convolutions (student conv3-5,
+// the sixteen 3 x 3 layers of the ResNet-50 teachers) and their dgrads, and the stride-parity classes of a strided
+// dgrad (the student's 5 x 5 / 2 conv2: classes of 3x3, 3x2, 2x3 and 2x2 taps) -- half of the FLOPs of a step.
+// conv_gemm_kernel fetches every input element once PER TAP (T gathers through the texture path, each with its own
+// address arithmetic and padding mask) and meets at a barrier every 16 reduction steps.  Here a stage is 8 input
+// channels: the zero-padded input PATCH under the block's 128 output pixels (all taps of all its pixels: PS floats per
+// channel) goes global -> registers -> LDS ONCE, padding rows / columns and sample gaps as out-of-range buffer loads
+// (zeros); the taps then read their B operand straight from the patch -- `ds_read_b32` at the lane's own patch position
+// + a per-tap shift + a compile-time channel offset, no VALU, no masks -- for 8 T reduction steps (16 T MFMAs per wave
+// tile) between barriers.  The filter operand is reordered while it is parked in LDS so that MFMA e of tap t multiplies
+// channels e (lanes 0-31) / e + 4 (lanes 32-63):  k = 8 t + c.
+//   LDS  A [2 T k-groups][BM rows][4]  +  patch [8 channels][PS]   (T = 9, BM = 128, PS = 512: 37 + 16 KB; one stage --
+//   the next stage's operands wait in registers while this one is multiplied, two blocks per CU overlap the store phases)
+// Measured on the way (x_fill3x3, TFLOP/s): multiply from LDS only 151; + store phase / barriers 142; + the loads in one
+// burst behind the barrier 119 (a wave issues in order: 25 wave-wide loads, most touching 64 cache lines, hold its
+// issue slot); loads spread over the taps of the stage 129-135.  The filter quads of a wave-wide load sit in 64
+// different cache lines (two threads per row, compile-time reorder): 5 % -- a pre-ordered filter copy would remove it.
+// Epilogue, accumulator map, split-K slabs: conv_gemm_kernel's.
+constexpr int kHaloCB = 8;
 
-#ifndef XM_HALO_OCC
-#define XM_HALO_OCC 2
-#endif
-template <int TM, int TN, int WGM, int WGN>
-__global__ void __launch_bounds__(256, XM_HALO_OCC)
-conv_halo_kernel(const ConvGemmArgs a) {
+template <int T, int TM, int TN, int WGM, int WGN, int PS>
+__device__ __forceinline__ void conv_halo_body(const ConvGemmArgs &a, float *smem) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  static_assert(BM == 128 && WGM * WGN == 4, "two staging threads per filter row, four waves");
-  constexpr int NGRP = kHaloKS / 4;            // 18 k-groups of four
+  static_assert(WGM * WGN == 4 && BN == 128 && 2 * BM <= 256, "four waves, 128 pixels, two staging threads per row");
+  static_assert(PS == 512 || PS == 1024, "patch positions map to threads as 4 (t % (PS / 4))");
+  constexpr int KS = kHaloCB * T;              // reduction steps per stage
+  constexpr int NGRP = 2 * T;                  // k-groups of four
   constexpr int PLA = BM * 4 + 4;              // floats per k-group plane
-  constexpr int PS = kHaloPS;
-  __shared__ __attribute__((aligned(16))) float smem[NGRP * PLA + kHaloCB * PS];
+  constexpr int UC = PS / 4;                   // staging threads per channel
+  constexpr int CPP = 256 / UC;                // channels per staging pass (2 / 1)
+  constexpr int NI = kHaloCB / CPP;            // patch units (float4) per thread and stage (4 / 8)
+  constexpr int NLT = T < 7 ? T : 7;           // the stage's global loads are spread over this many taps
   float *sA = smem;
   float *sP = smem + NGRP * PLA;
 
@@ -970,18 +979,12 @@ conv_halo_kernel(const ConvGemmArgs a) {
   const int st0 = split * a.tilesPerSplit;
   const int nst = min(a.nkt, st0 + a.tilesPerSplit) - st0;
 
-  // ---- A staging: thread (row = t / 2, h = t % 2) moves 36 consecutive reduction indices of its row per stage ----
-#ifndef XM_HALO_VARIANT
-#define XM_HALO_VARIANT 0
-#endif
-#if XM_HALO_VARIANT == 6 || XM_HALO_VARIANT == 7
-  const float *arow = a.A + 36 * (t & 1) + (size_t)st0 * kHaloKS;     // experiment: every thread the same filter row
-#else
-  const float *arow = a.A + (size_t)min(bm * BM + (t >> 1), a.M - 1) * a.lda + 36 * (t & 1) + (size_t)st0 * kHaloKS;
-#endif
-  float *sAw = sA + (t & 1) * PLA + (t >> 1) * 4;
+  // ---- A staging: thread (row = t / 2, h = t % 2) moves 4 T consecutive reduction indices of its row per stage ----
+  const bool arowOk = t < 2 * BM;
+  const float *arow = a.A + (size_t)min(bm * BM + min(t >> 1, BM - 1), a.M - 1) * a.lda + 4 * T * (t & 1) + (size_t)st0 * KS;
+  float *sAw = sA + (t & 1) * PLA + min(t >> 1, BM - 1) * 4;
 
-  // ---- patch staging: thread owns patch positions 4 (t % 128) .. + 3 of channels 2 i + t / 128 (i = 0..3) ----
+  // ---- patch staging: thread owns patch positions 4 (t % UC) .. + 3 of channels CPP i + t / UC ----
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
   unsigned poff[4], pinv[4];
   int jjp0;
@@ -992,7 +995,7 @@ conv_halo_kernel(const ConvGemmArgs a) {
     jjp0 = (int)(n0 * (uint32_t)a.hpWP + xm_div(q0, a.divPI));
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const uint32_t pos = 4u * (uint32_t)(t & 127) + d;
+      const uint32_t pos = 4u * (uint32_t)(t % UC) + d;
       const uint32_t col = xm_div(pos, a.hpDivHP), r = pos - col * (uint32_t)a.hpHP;
       const uint32_t jjp = (uint32_t)jjp0 + col;
       const uint32_t n = xm_div(jjp, a.hpDivWP), jl = jjp - n * (uint32_t)a.hpWP;
@@ -1000,14 +1003,11 @@ conv_halo_kernel(const ConvGemmArgs a) {
       const bool ok = (unsigned)sr < (unsigned)a.LimH && (unsigned)sc < (unsigned)a.LimW && (int)n < a.hpN;
       poff[d] = (unsigned)(sr + a.LimH * sc + (int)n * a.xSampleStride) * 4u;
       pinv[d] = ok ? 0u : 0xFFFFFFFFu;
-#if XM_HALO_VARIANT == 5 || XM_HALO_VARIANT == 7
-      pinv[d] = 0xFFFFFFFFu;                   // experiment: every patch load out of range (no memory traffic)
-#endif
     }
   }
   const unsigned chBytes = (unsigned)(a.LimH * a.LimW) * 4u;
-  const int chalf = wave >> 1;                 // t / 128, wave-uniform
-  float *sPw = sP + chalf * PS + 4 * (t & 127);
+  const int chalf = __builtin_amdgcn_readfirstlane(t / UC);      // wave-uniform (UC is a multiple of 64)
+  float *sPw = sP + chalf * PS + 4 * (t % UC);
 
   // ---- per-lane patch position of the wave's pixels ----
   const float *pb[TN];
@@ -1021,25 +1021,28 @@ conv_halo_kernel(const ConvGemmArgs a) {
   }
   const float *sAr = sA + half * PLA + (wm * TM * 32 + l31) * 4;
 
-  f32x4 ra[9], rb[4];
-#define XM_HLOAD(S)                                                            \
-  _Pragma("unroll") for (int i = 0; i < 9; ++i)                                \
-    ra[i] = *reinterpret_cast<const f32x4 *>(arow + (S) * kHaloKS + 4 * i);    \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                              \
-    const unsigned cb_ = (unsigned)((st0 + (S)) * kHaloCB + 2 * i + chalf) * chBytes;  \
-    rb[i].x = buf_load(xrsrc, (poff[0] + cb_) | pinv[0]);                      \
-    rb[i].y = buf_load(xrsrc, (poff[1] + cb_) | pinv[1]);                      \
-    rb[i].z = buf_load(xrsrc, (poff[2] + cb_) | pinv[2]);                      \
-    rb[i].w = buf_load(xrsrc, (poff[3] + cb_) | pinv[3]);                      \
+  f32x4 ra[T], rb[NI];
+  // part P of NLT of the loads of stage S: filter quads P, P + NLT, ... and patch dwords likewise.  (The loads of
+  // stage s + 1 are spread over the taps of stage s, each behind a few MFMAs -- see the header.)
+#define XM_HLOAD_PART(S, P)                                                    \
+  if ((P) < NLT) {                                                             \
+    _Pragma("unroll") for (int i_ = (P); i_ < T; i_ += NLT)                    \
+      ra[i_] = *reinterpret_cast<const f32x4 *>(arow + (S) * KS + 4 * i_);     \
+    _Pragma("unroll") for (int u_ = (P); u_ < 4 * NI; u_ += NLT) {             \
+      const unsigned cb_ = (unsigned)((st0 + (S)) * kHaloCB + CPP * (u_ >> 2) + chalf) * chBytes; \
+      rb[u_ >> 2][u_ & 3] = buf_load(xrsrc, (poff[u_ & 3] + cb_) | pinv[u_ & 3]); \
+    }                                                                          \
   }
-  // element e of unit i is reduction index 36 h + 4 i + e of the stage: channel 4 h + (4 i + e) / 9, tap (4 i + e) % 9,
-  // i.e. k = 8 tap + channel -> k-group 2 tap + h, slot (4 i + e) / 9  (h is folded into sAw)
+  // element e of unit i is reduction index 4 T h + 4 i + e of the stage: channel 4 h + (4 i + e) / T, tap (4 i + e) % T,
+  // i.e. k = 8 tap + channel -> k-group 2 tap + h, slot (4 i + e) / T  (h is folded into sAw)
 #define XM_HSTORE                                                              \
-  _Pragma("unroll") for (int i = 0; i < 9; ++i)                                \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                              \
-      sAw[2 * ((4 * i + e) % 9) * PLA + (4 * i + e) / 9] = ra[i][e];           \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
-    *reinterpret_cast<f32x4 *>(sPw + 2 * i * PS) = rb[i];
+  if (arowOk) {                                                                \
+    _Pragma("unroll") for (int i = 0; i < T; ++i)                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                            \
+        sAw[2 * ((4 * i + e) % T) * PLA + (4 * i + e) / T] = ra[i][e];         \
+  }                                                                            \
+  _Pragma("unroll") for (int i = 0; i < NI; ++i)                               \
+    *reinterpret_cast<f32x4 *>(sPw + CPP * i * PS) = rb[i];
 #define XM_HREAD(TAP, AF, BF)                                                  \
   {                                                                            \
     const int sh_ = a.hpSh[TAP] >> 2;                                          \
@@ -1054,39 +1057,6 @@ conv_halo_kernel(const ConvGemmArgs a) {
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                             \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                           \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AF[i][e], BF[j][e], acc[i][j], 0, 0, 0);
-#define XM_HSCHED                                                              \
-  _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
-    __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
-    __builtin_amdgcn_sched_group_barrier(XM_SGB_DS_RD, 1, 0);                  \
-  }                                                                            \
-  __builtin_amdgcn_sched_barrier(0);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f32x4 af0[TM], af1[TM];
-  float bf0[TN][4], bf1[TN][4];
-
-  // The global loads of stage s + 1 are spread over ALL nine taps of stage s (one filter quad + two patch dwords per
-  // tap, each behind a few MFMAs): a wave issues in order, and a burst of 25 wave-wide loads -- most of them touching
-  // 64 different cache lines -- holds its issue slot until the memory pipeline has taken them all.
-#ifndef XM_HALO_NLT
-#define XM_HALO_NLT 7
-#endif
-  // part P of XM_HALO_NLT: filter quads P, P + NLT, ... and patch dwords likewise
-#define XM_HLOAD_PART(S, P)                                                    \
-  if ((P) < XM_HALO_NLT) {                                                     \
-    _Pragma("unroll") for (int i_ = (P); i_ < 9; i_ += XM_HALO_NLT)            \
-      ra[i_] = *reinterpret_cast<const f32x4 *>(arow + (S) * kHaloKS + 4 * i_); \
-    _Pragma("unroll") for (int u_ = (P); u_ < 16; u_ += XM_HALO_NLT) {         \
-      const unsigned cb_ = (unsigned)((st0 + (S)) * kHaloCB + 2 * (u_ >> 2) + chalf) * chBytes; \
-      rb[u_ >> 2][u_ & 3] = buf_load(xrsrc, (poff[u_ & 3] + cb_) | pinv[u_ & 3]); \
-    }                                                                          \
-  }
 #define XM_HSCHED_LD                                                           \
   _Pragma("unroll") for (int q_ = 0; q_ < 4 * TM * TN; ++q_) {                 \
     __builtin_amdgcn_sched_group_barrier(XM_SGB_MFMA, 1, 0);                   \
@@ -1097,33 +1067,61 @@ conv_halo_kernel(const ConvGemmArgs a) {
     }                                                                          \
   }                                                                            \
   __builtin_amdgcn_sched_barrier(0);
-  XM_HLOAD(0)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 af[2][TM];
+  float bf[2][TN][4];
+
+#pragma unroll
+  for (int P = 0; P < NLT; ++P) {
+    XM_HLOAD_PART(0, P)
+  }
   for (int s = 0; s < nst; ++s) {
     if (s > 0) __syncthreads();     // every wave has read the last fragments of stage s - 1
     XM_HSTORE
     __syncthreads();
-    XM_HREAD(0, af0, bf0)
+    XM_HREAD(0, af[0], bf[0])
     __builtin_amdgcn_sched_barrier(0);
     const int sn = min(s + 1, nst - 1);   // (the last stage re-requests itself: no branch inside the scheduling regions)
-    XM_HREAD(1, af1, bf1) XM_HLOAD_PART(sn, 0) XM_HMFMA(af0, bf0) XM_HSCHED_LD
-    XM_HREAD(2, af0, bf0) XM_HLOAD_PART(sn, 1) XM_HMFMA(af1, bf1) XM_HSCHED_LD
-    XM_HREAD(3, af1, bf1) XM_HLOAD_PART(sn, 2) XM_HMFMA(af0, bf0) XM_HSCHED_LD
-    XM_HREAD(4, af0, bf0) XM_HLOAD_PART(sn, 3) XM_HMFMA(af1, bf1) XM_HSCHED_LD
-    XM_HREAD(5, af1, bf1) XM_HLOAD_PART(sn, 4) XM_HMFMA(af0, bf0) XM_HSCHED_LD
-    XM_HREAD(6, af0, bf0) XM_HLOAD_PART(sn, 5) XM_HMFMA(af1, bf1) XM_HSCHED_LD
-    XM_HREAD(7, af1, bf1) XM_HLOAD_PART(sn, 6) XM_HMFMA(af0, bf0) XM_HSCHED_LD
-    XM_HREAD(8, af0, bf0) XM_HLOAD_PART(sn, 7) XM_HMFMA(af1, bf1) XM_HSCHED_LD
-    XM_HLOAD_PART(sn, 8) XM_HMFMA(af0, bf0) XM_HSCHED_LD
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      if (tap + 1 < T) {
+        XM_HREAD(tap + 1, af[(tap + 1) & 1], bf[(tap + 1) & 1])
+      }
+      XM_HLOAD_PART(sn, tap)
+      XM_HMFMA(af[tap & 1], bf[tap & 1])
+      XM_HSCHED_LD
+    }
   }
 #undef XM_HLOAD_PART
-#undef XM_HSCHED_LD
-#undef XM_HLOAD
 #undef XM_HSTORE
 #undef XM_HREAD
 #undef XM_HMFMA
-#undef XM_HSCHED
+#undef XM_HSCHED_LD
   __syncthreads();                  // the epilogue's statistics path reuses the operand tiles
   conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31, smem);
+}
+
+template <int TM, int WGM, int PS>
+constexpr int halo_smem_floats() {
+  return 2 * 9 * (32 * TM * WGM * 4 + 4) + kHaloCB * PS;   // sized for T = 9
+}
+
+// one problem per launch; T = a.nU * a.nV (9 / 6 / 4)
+template <int TM, int TN, int WGM, int WGN, int PS>
+__global__ void __launch_bounds__(256, 2)
+conv_halo_kernel(const ConvGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[halo_smem_floats<TM, WGM, PS>()];
+  const int T = a.nU * a.nV;
+  if (T == 9) conv_halo_body<9, TM, TN, WGM, WGN, PS>(a, smem);
+  else if (T == 6) conv_halo_body<6, TM, TN, WGM, WGN, PS>(a, smem);
+  else conv_halo_body<4, TM, TN, WGM, WGN, PS>(a, smem);
 }
 
 // Several independent implicit GEMMs in ONE launch (blockIdx.z picks the problem): the stride-parity
@@ -1138,6 +1136,19 @@ conv_gemm_multi_kernel(const ConvGemmMulti m) {
   const ConvGemmArgs &a = m.c[blockIdx.z];
   if ((int)blockIdx.x >= a.nbm * a.nbn) return;
   conv_gemm_body<TM, TN, WGM, WGN, 1>(a);
+}
+
+// the stride-parity classes of a strided dgrad through the halo-patch body, one launch (blockIdx.z = class)
+template <int TM, int TN, int WGM, int WGN, int PS>
+__global__ void __launch_bounds__(256, 2)
+conv_halo_multi_kernel(const ConvGemmMulti m) {
+  __shared__ __attribute__((aligned(16))) float smem[halo_smem_floats<TM, WGM, PS>()];
+  const ConvGemmArgs &a = m.c[blockIdx.z];
+  if ((int)blockIdx.x >= a.nbm * a.nbn) return;
+  const int T = a.nU * a.nV;
+  if (T == 9) conv_halo_body<9, TM, TN, WGM, WGN, PS>(a, smem);
+  else if (T == 6) conv_halo_body<6, TM, TN, WGM, WGN, PS>(a, smem);
+  else conv_halo_body<4, TM, TN, WGM, WGN, PS>(a, smem);
 }
 
 // combine split-K slabs in split order and apply the fused epilogue.  VEC (vecStore destinations, slab pitch and

@@ -261,7 +261,9 @@ HALO_CASES = [(30, 17, 16, 3, 40, (1, 1, 1, 1)),      # student conv3-5 geometry
               (13, 11, 8, 3, 16, (2, 0, 1, 2)),       # asymmetric padding
               (9, 6, 32, 4, 8, (1, 1, 1, 1)),
               (7, 7, 128, 9, 64, (1, 1, 1, 1)),       # few tiles, 16 stages: split-K slabs + combine kernel
-              (14, 14, 64, 3, 136, (1, 1, 1, 1))]
+              (14, 14, 64, 3, 136, (1, 1, 1, 1)),
+              (30, 17, 96, 2, 96, (1, 1, 1, 1)),      # 96 rows both ways: the 3 x 1 wave-tile variant
+              (15, 9, 192, 3, 192, (1, 1, 1, 1))]
 
 
 def _kernels_run(L, fn):
@@ -297,7 +299,7 @@ def test_conv_halo_kernel(gpu, case):
     dzdy = rnd(rng, *y_ref.shape)
     dx_ref, df_ref, _ = O.vl_nnconv(x, f, b, dzdy, pad=pad, acc64=True)
     xd, fd, bd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), vl.from_numpy(dzdy)
-    old = L.xm_debug_force_conv_halo(1)
+    old = L.xm_debug_force_conv_halo(1 + (H + K) % 2)      # 128-row / 96-row variant (the latter only where M % 96 == 0)
     try:
         y, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, pad=pad))
         assert any("halo" in n for n in names), names
@@ -324,6 +326,30 @@ def test_conv_halo_kernel(gpu, case):
         m = vl.to_numpy(mo)
         close(m[:, 0], m_ref[:, 0], what="halo mean")
         assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4
+    finally:
+        L.xm_debug_force_conv_halo(old)
+
+
+@pytest.mark.parametrize("N,variant", [(3, 1), (3, 3), (16, 3), (16, 1)])
+def test_conv_halo_strided_dgrad(gpu, N, variant):
+    """dgrad of a 5 x 5 / stride-2 convolution (the student's conv2): four stride-parity classes with 3x3, 3x2, 2x3 and
+    2x2 taps, each a unit-stride gather in dY space -> the halo-patch kernel with T = 9 / 6 / 4 taps, per class (few
+    tiles) or all classes in one launch (conv_halo_multi_kernel), 128-row and 96-row / tall-patch variants."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, K = 126, 73, 96, 8
+    rng = np.random.default_rng(N * 10 + variant)
+    x, f = rnd(rng, H, W, C, N), rnd(rng, 5, 5, C, K)
+    y_ref = O.vl_nnconv(x, f, None, stride=2, pad=1, acc64=True)
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, _, _ = O.vl_nnconv(x, f, None, dzdy, stride=2, pad=1, acc64=True, no_der_filters=True)
+    xd, fd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(dzdy)
+    old = L.xm_debug_force_conv_halo(variant)
+    try:
+        (dx, _, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, None, dd, stride=2, pad=1, no_der_filters=True))
+        assert any("halo" in n for n in names), names
+        assert any("multi" in n for n in names) == (N == 16), names
+        close(vl.to_numpy(dx), dx_ref, what="strided dgrad through the halo-patch kernel")
     finally:
         L.xm_debug_force_conv_halo(old)
 
