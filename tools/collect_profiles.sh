@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence for profiles/<round>/ : run on the GPU box (gpurun), writes gpurun_out/<round>/.
 # usage: tools/collect_profiles.sh r02 [commit]
-R=${1:-r02}
+R=${1:-r03}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -20,7 +20,25 @@ $B --teacher senet50 --per-gpu-batch 256 --no-cpu-baseline  | tail -1 > $O/bench
 $B --per-gpu-batch 256 --no-cpu-baseline                    | tail -1 > $O/bench_distill_b256_n1.json
 $B --frames 13 --no-cpu-baseline --teacher senet50          | tail -1 > $O/bench_distill_13frames_senet50_n1.json
 $B --workload cpu-teacher                                   | tail -1 > $O/bench_cpu_teacher.json                  # BASELINE config 1 (host cores only)
-XM_DEBUG_DIST=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline | tail -1 > $O/bench_distill_capi_1rank.json
+XM_DEBUG_DIST=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_capi_1rank.json
+XM_DEBUG_DIST=1 $B --parserv torch --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_torch_1rank.json
+XM_DEBUG_DIST=1 XM_PS_LATE=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_capi_late_init.json   # communicator created AFTER the nets: the 12 % trap (xmodal.h CALL ORDER)
+# round-3 experiments behind DESIGN.md 2.3b: where the main stream spends its time; scheduling variants that moved nothing
+NS="--no-cpu-baseline --no-roofline --north-star 0"
+{
+  for f in "" "--wgrad-stream 0" "--overlap-teacher 0" "--serial" "--workload student --per-gpu-batch 32" "--workload student --per-gpu-batch 32 --wgrad-stream 0"; do
+    echo "== bench.py $f"; XM_BENCH_MARKS=1 $B $NS $f 2>&1 | grep -E "marks|\"value\"" | sed -e "s/, \"unit.*//"; done
+} > $O/phase_marks.txt
+{
+  for tb in 0 64 128 256; do echo -n "--teacher-batch $tb: "; $B $NS --teacher-batch $tb 2>/dev/null | tail -1 | cut -c60-112; done
+  for g in "" loss conv5 conv3 conv2 bn1; do echo -n "--teacher-gate '$g': "; $B $NS --teacher-gate "$g" 2>/dev/null | tail -1 | cut -c60-112; done
+  for e in "XM_X=1" "XM_WGRAD_AFTER_DGRAD=1" "XM_SIDE_PRIO=0 XM_MAIN_PRIO=-1" "XM_NO_FUSED_STATS=1" "XM_NO_FUSED_BIASDER=1" "XM_NO_FAST_TRANSPOSE=1" "XM_NO_HALO=1"; do
+    echo -n "$e: "; env $e $B $NS 2>/dev/null | tail -1 | cut -c60-112; done
+  for e in "XM_X=1" "XM_NO_HALO=1" "XM_NO_FUSED_STATS=1"; do echo -n "student batch 64, $e: "; env $e $B $NS --workload student 2>/dev/null | tail -1 | cut -c50-100; done
+} > $O/schedule_experiments.txt
+for n in 32 64 256; do python tools/halo_bench.py $n 2>&1 | grep -v amdgpu; done > $O/halo_bench.txt
+python tools/stats_bench.py 32 2>&1 | grep -v amdgpu > $O/stats_bench.txt
+python tools/bnbwd_bench.py 32 2>&1 | grep -v amdgpu > $O/bnbwd_bench.txt
 # per-kernel durations of the serial pass (what roofline.avg_launch_ms is compared with)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o run -- $B --serial --no-cpu-baseline --steps 60 --warmup 10 \
     > $O/bench_under_rocprof.json 2> $O/rocprof_kt.log
@@ -49,6 +67,7 @@ if [ -z "$XM_PROFILE_SKIP_EXTRA" ]; then
   kstats joint --workload joint
   kstats senet50 --teacher senet50
   kstats b256 --per-gpu-batch 256
+  kstats senet50_b256 --teacher senet50 --per-gpu-batch 256
 fi
 # PMC passes, each on its own (no tracing domains besides the kernel trace)
 P="--serial --steps 3 --warmup 3 --no-cpu-baseline --no-roofline"

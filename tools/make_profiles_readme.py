@@ -2,7 +2,7 @@
 """Regenerates profiles/README.md from the JSON / text evidence under profiles/<round>/.
 usage: python tools/make_profiles_readme.py r02"""
 import json, os, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(root, "profiles", R)
 def L(n): return json.loads(open(os.path.join(P, n + ".json")).read().strip().splitlines()[-1])
@@ -11,6 +11,8 @@ d, dd, ds, st, te, jo, mf = (L("bench_distill_n1"), L("bench_distill_driver_flag
                              L("bench_distill_13frames_senet50_n1"))
 se, se256, r256, c1, capi = (L("bench_distill_senet50_n1"), L("bench_distill_senet50_b256_n1"), L("bench_distill_b256_n1"),
                              L("bench_cpu_teacher"), L("bench_distill_capi_1rank"))
+tor1, late = L("bench_distill_torch_1rank"), L("bench_distill_capi_late_init")
+ns = d.get("north_star_b256") or {}
 r, c = d["roofline"], d["cpu_baseline"]
 tests = open(os.path.join(P, "pytest_gpu.txt")).read().strip().splitlines()[-1]
 ks = open(os.path.join(P, "kernel_stats.txt")).read()
@@ -26,7 +28,7 @@ txt = f"""# profiles/ — measured evidence, round {int(R[1:])} (MI355X, 1 GPU, 
 
 Everything under `{R}/` comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
 `bash tools/collect_profiles.sh {R} <commit>` (the script lists every command); this file is generated from
-those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous round's evidence, unchanged.
+those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the previous rounds' evidence, unchanged.
 
 | file | what |
 |---|---|
@@ -42,6 +44,11 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
 | `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
 | `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only) |
 | `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
+| `{R}/bench_distill_torch_1rank.json`, `bench_distill_capi_late_init.json` | the same single-rank run through `torch.distributed` ({tor1['value']} pairs/s), and with the library's communicator created AFTER the networks (`XM_PS_LATE=1`: {late['value']} pairs/s -- the call-order trap of `include/xmodal.h`) |
+| `{R}/phase_marks.txt` | `XM_BENCH_MARKS=1`: timing events on the main stream at the phase boundaries of the student step (forward / backward / join / update / gap to the next step) for the default line and its one-stream / no-side-stream / no-teacher-overlap variants |
+| `{R}/schedule_experiments.txt` | A/B lines behind DESIGN.md 2.3b: teacher pass over 64 / 128 / 256 faces, `--teacher-gate`, wgrad deferred behind dgrad, stream priorities, and every round-3 kernel change switched off by its environment variable |
+| `{R}/halo_bench.txt`, `stats_bench.txt`, `bnbwd_bench.txt` | `tools/halo_bench.py` (halo-patch variants vs the best implicit-GEMM configuration, 32 / 64 / 256 samples), `tools/stats_bench.py` (conv with / without fused batch moments), `tools/bnbwd_bench.py` (bnorm backward chains) |
+| `{R}/kernel_stats_senet50_b256.txt` | rocprofv3 per-kernel summary of north_star's configuration (SE-ResNet50 teacher, 256 pairs, serial mode) |
 | `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` (+ the commit) from the JSON |
 
 ## Headline (default bench line)
@@ -57,6 +64,8 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
   launch stream, serial pass); `kernel_stats.txt` (rocprofv3, same command) has it at {rocavg:.1f} us average.
   All convolution kernels together: {r['all_conv_kernels']['achieved']} TFLOP/s over {r['all_conv_kernels']['ms_per_step']} ms per step.
   HBM traffic of that kernel from the PMC passes (commit `{r.get('traffic_profile_commit')}`): {(r.get('traffic') or 0)/1e6:.0f} MB per launch.
+* north_star's own configuration inside the same invocation (`north_star_b256`: SE-ResNet50 teacher + student, 256 pairs on
+  this GPU, 12 timed steps): **{ns.get('value')} pairs/s = {pct(ns.get('model_frac') or 0)}** of the fp32-MFMA peak for the whole step.
 * CPU baseline (oracle fp32 path = MatConvNet-CPU-equivalent restatement): {c['value']} pairs/s = {c.get('gflops')} GFLOP/s on {c['cores']} cores
   of {c.get('cpu')} ({c['sample']}).  Config 1 by itself: {c1['value']} images/s ({c1['cpu_baseline'].get('gflops')} GFLOP/s).
 * `{tot}` (serial mode under rocprofv3).
@@ -78,13 +87,12 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` is the previous roun
 | 8f-1: 13 frames/pair, SE-ResNet50 teacher + student step | 32 pairs (416 faces) | {mf['value']} pairs/s | {mf['ms_per_step']} | {pct(mf['model_frac_of_fp32_mfma_peak'])} |
 | 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
-Round 1 -> round 2 on the default line: 3502 -> {d['value']} pairs/s (+{round(100 * (d['value'] / 3502 - 1), 1)} %).  Where it came from:
-conv epilogue constants as per-lane loads (+2.4 %); the student's pooling layers rewritten (LDS-staged forward, per-channel
-backward sums from the pooled tensors, patch-per-thread apply: +3.8 %); reduction / finalize / filter-transpose kernels that were
-bound by index arithmetic or idle lanes (+1.8 %); the LDS-DMA kernel's epilogue stores made invisible to the compiler's
-wait-count pass, whose `s_waitcnt vmcnt(0)` at the k-loop header drained the DMA ring every stage (+1.0 % here, the 1x1 layers'
-ceiling 106 -> 134 TFLOP/s on a long-K fill case).  SE-ResNet50 teacher: 3197 -> {se['value']} pairs/s (skinny FC kernel for the gates).
-Serial non-convolution time: 2.1 -> see `kernel_stats.txt`.
+Round 2 -> round 3 on the default line: 3812 -> {d['value']} pairs/s; student batch 64: 5373 -> {st['value']} samples/s; north_star batch 256
+(SE-ResNet50): 3903 -> {se256['value']} pairs/s; one stream: 3415 -> {ds['value']}.  Where it came from: bnorm batch
+moments from the convolution epilogue (no second pass over the conv output; +0.9 % / +3.5 % at 64); the FC-shaped dgrad
+filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32).
+What did NOT move the step is in `schedule_experiments.txt`: the step is work-conserving (serial sum 9.2 ms -> {d['ms_per_step']} ms overlapped),
+its main stream never waits (`phase_marks.txt`), and only work removed from the main stream shows up one to one.
 
 ## How the numbers were taken
 ```
