@@ -47,7 +47,7 @@ enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
- * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments (additions never change the revision's meaning
+ * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated (additions never change the revision's meaning
  * for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
@@ -94,6 +94,18 @@ int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const fl
                             int FW, int FC, int K, const float *b, float *y, int sy, int sx,
                             int pt, int pb, int pl, int pr, int dy, int dx, const float *scale,
                             const float *shift, const float *residual, int flags, void *stream);
+/* Extension: xm_nnconv_forward_fused with a per-(channel, sample) multiplier between the scale / shift and the residual:
+ *   y = act( ((conv + b) .* scale_k + shift_k) .* gate(k, n) + residual ),   gate = 1 x 1 x K x N.
+ * The SE block of senet50-ferplus (mcnExtraLayers dagnn.Axpy: out = a .* x + shortcut, teacher/ferPlusZoo.m:86-112;
+ * fetch_emovoxceleb_imdb.m:98-136 runs it in test mode): x is the output of a bias-free 1 x 1 projection + test-mode
+ * bnorm, i.e. affine in its input u, so the squeeze mean(x) = scale .* (F * mean(u)) + shift can be taken from the 4 x
+ * narrower u BEFORE the projection runs; the gate a is then known when the projection's epilogue writes, and
+ * relu(a .* x + shortcut) leaves the kernel directly -- x is never written, re-read for the squeeze, re-read and
+ * re-written for the excite (three passes over the widest tensors of the network per block). */
+int xm_nnconv_forward_gated(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                            int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                            int pl, int pr, int dy, int dx, const float *scale, const float *shift,
+                            const float *gate, const float *residual, int flags, void *stream);
 /* Extension: Y = vl_nnconv(X, F, B, ...) AND the batch moments of Y that a train-mode vl_nnbnorm(Y, G, B) would
  * compute first -- moments_out (K x 2, column-major) = [mean_k, sqrt(var_k + epsilon)] over H x W x N, biased
  * variance (emoVoxZoo.m:118-123: every dagnn.Conv of the student is followed by dagnn.BatchNorm).  Hand them to

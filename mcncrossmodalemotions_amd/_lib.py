@@ -39,6 +39,8 @@ SIGNATURES = {
     "xm_out_size": [_i] * 6,
     "xm_nnconv_forward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 + [_vp],
     "xm_nnconv_forward_moments": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 + [_f, c_fp, _vp],
+    "xm_nnconv_forward_gated": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 +
+                               [c_fp, c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnconv_forward_fused": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp] + [_i] * 8 +
                                [c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnconv_backward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +

@@ -1010,7 +1010,7 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
 // (16-byte-store epilogue, no split-K, no filter groups), else by a pass over Y.
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
-                        hipStream_t st, float *moments_out = nullptr, float eps = 0.f) {
+                        hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
   // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
   // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
   const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
@@ -1082,6 +1082,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     a.scale = scale ? scale + grp * g.Kg : nullptr;
     a.shift = shift ? shift + grp * g.Kg : nullptr;
     a.resid = resid ? resid + (size_t)grp * g.Kg * g.Ho * g.Wo : nullptr;
+    a.gate = gate ? gate + (size_t)grp * g.Kg : nullptr;
+    a.gateStride = g.K;
     a.relu = relu;
     a.lda = lda;
     a.M = g.Kg;
@@ -1815,6 +1817,21 @@ int xm_nnconv_forward_moments(const float *x, int H, int W, int C, int N, const 
     return rc ? rc : bn_batch_moments(y, g.Ho, g.Wo, g.K, g.N, epsilon, moments_out, st);
   }
   return conv_forward(x, f, b, y, g, nullptr, nullptr, nullptr, 0, st, moments_out, epsilon);
+}
+
+int xm_nnconv_forward_gated(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                            int FC, int K, const float *b, float *y, int sy, int sx, int pt, int pb,
+                            int pl, int pr, int dy, int dx, const float *scale, const float *shift,
+                            const float *gate, const float *residual, int flags, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!x || !f || !y || !gate) return fail(XM_EINVAL, "vl_nnconv(gated): NULL tensor");
+  if ((scale == nullptr) != (shift == nullptr))
+    return fail(XM_EINVAL, "vl_nnconv(gated): scale and shift must be given together");
+  if (flags & XM_FUSE_SIGMOID) return fail(XM_ENOTSUP, "vl_nnconv(gated): sigmoid epilogue is not built");
+  return conv_forward(x, f, b, y, g, scale, shift, residual, (flags & XM_FUSE_RELU) ? 1 : 0, (hipStream_t)stream,
+                      nullptr, 0.f, gate);
 }
 
 int xm_nnconv_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -41,6 +41,10 @@ struct ConvGemmArgs {
   float *slab;        // splits > 1: [splits][M][NPs] raw partial sums
   const int2 *taps;   // Rp + 3*kBK entries {byte offset, (u,v) index}; padding entries use index 63
   const float *bias, *scale, *shift, *resid;
+  // != NULL: per-(row, sample) multiplier applied after scale / shift and before the residual: gate[row + gateStride *
+  // sample] -- the SE excite a .* x folded into the 1 x 1 projection that produces x (xm_nnconv_forward_gated)
+  const float *gate;
+  int gateStride;
   int relu;
   unsigned xBytes;    // size of the gather source in bytes (buffer bounds check)
   unsigned aBytes;    // size of A in bytes (LDS-DMA variant: A is read through a buffer descriptor too)
@@ -250,7 +254,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
   // ---- epilogue: y = act((acc + bias) * scale + shift + residual) ----
   // Per-row constants: per-lane loads of the rows the lane stores, all in flight together (both paths below).
   const int wbase = __builtin_amdgcn_readfirstlane(bm * BM + wm * TM * 32);
-  int obase[TN];
+  int obase[TN], gbase[TN];   // gbase: gateStride * sample of the lane's pixel (a.gate)
   bool pok[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -258,6 +262,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
     pok[j] = p < a.NP;
     uint32_t pc = pok[j] ? p : a.NP - 1;
     uint32_t n = xm_div(pc, a.divPIJ);
+    gbase[j] = (int)n * a.gateStride;
     uint32_t q = pc - n * a.divPIJ.d;
     uint32_t jj = xm_div(q, a.divPI);
     uint32_t ii = q - jj * a.divPI.d;
@@ -333,6 +338,15 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
       // compiler's vmcnt(0) in front of its use wait for those stores as well (in-order counter).
       // explicit 16-byte accesses: written element by element the compiler keeps four dword loads / stores
       // (it cannot prove the alignment), i.e. 4x the VMEM instructions and quarter-filled cache lines
+      float gv[4][TN];   // a.gate: multiplier of (row this lane stores, sample of its pixel quad)
+      if (a.gate) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int rowc_ = min(wbase + i * 32 + 8 * g4 + 4 * half + iq, a.M - 1);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) gv[g4][j] = a.gate[rowc_ + gbase[j]];
+        }
+      }
       f32x4 rv[ASMST ? 4 : 1][ASMST ? TN : 1];
       if (ASMST && a.resid) {
 #pragma unroll
@@ -354,6 +368,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
           if (ok[g4][j]) {
             f32x4 o = {v[0] * rmul[i][g4] + radd[i][g4], v[1] * rmul[i][g4] + radd[i][g4],
                        v[2] * rmul[i][g4] + radd[i][g4], v[3] * rmul[i][g4] + radd[i][g4]};
+            if (a.gate) o *= gv[g4][j];
             if (a.resid) {
               if constexpr (ASMST)
                 o += rv[g4 % (ASMST ? 4 : 1)][j % (ASMST ? TN : 1)];
@@ -436,6 +451,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
         if (m < a.M && pok[j]) {
           int off = obase[j] + moff;
           float v = acc[i][j][r] * rmul[r] + radd[r];
+          if (a.gate) v *= a.gate[min(m, a.M - 1) + gbase[j]];
           if (a.resid) v += a.resid[off];
           if (a.relu) v = fmaxf(v, 0.f);
           xm_st4<ASMST>(a.Y + off, v);
@@ -1174,6 +1190,7 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
     for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(a.slab + ((size_t)z * a.M + m) * a.NPs + p);
     if (a.bias) v += a.bias[m];
     if (a.scale) v = v * a.scale[m] + a.shift[m];
+    if (a.gate) v *= a.gate[m + (int)n * a.gateStride];
     if (a.resid) v += *reinterpret_cast<const f32x4 *>(a.resid + off);
     if (a.relu) {
       v.x = fmaxf(v.x, 0.f);
@@ -1187,6 +1204,7 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
     for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + p];
     if (a.bias) v += a.bias[m];
     if (a.scale) v = v * a.scale[m] + a.shift[m];
+    if (a.gate) v *= a.gate[m + (int)n * a.gateStride];
     if (a.resid) v += a.resid[off];
     if (a.relu) v = fmaxf(v, 0.f);
     a.Y[off] = v;

@@ -459,6 +459,7 @@ class DagNN:
         self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
         self.wgradAfterDgrad = os.environ.get("XM_WGRAD_AFTER_DGRAD") is not None
         self.fuseBiasDer = os.environ.get("XM_NO_FUSED_BIASDER") is None   # conv dzdb = sum(dx) from the bnorm backward
+        self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
@@ -1072,6 +1073,82 @@ class _ConvFoldStep(_Step):
         raise RuntimeError("folded conv+bn steps exist only in forward-only test-mode plans")
 
 
+class _SEFoldStep(_ConvFoldStep):
+    """test mode only: the whole SE tail of a bottleneck as TWO passes over narrow tensors + ONE over the wide one.
+
+        x  = bnorm(conv1x1(u))                 (projection C/4 -> C, frozen moments: affine in u)
+        a  = sigmoid(fc2(relu(fc1(mean_hw(x)))))
+        y  = relu(a .* x + shortcut)           (mcnExtraLayers dagnn.Axpy + ReLU)
+
+    mean_hw(x) = scale .* (F * mean_hw(u) + b) + shift by linearity, so the gate a is computed from the 4 x narrower u
+    BEFORE the projection runs, and the projection's epilogue writes relu(a .* x + shortcut) directly
+    (vl_nnconv(..., gate=a, residual=shortcut)): x is never materialised -- no write, no squeeze read, no excite
+    read / write of the widest tensors of the network."""
+
+    def __init__(self, conv_rec, bn_rec, se):
+        super().__init__(conv_rec, bn_rec, None, se["relu"], se["out"])
+        self.se = se
+
+    def forward(self, net):
+        r, blk, se = self.rec, self.rec.block, self.se
+        u = net.vars[r.inputs[0]].value
+        prm = self._params(net)
+        bias = prm[1] if blk.hasBias else None
+        sc, sh = self._fold(net)
+        ubar = vl.vl_nnpool(u, [int(u.shape[0]), int(u.shape[1])], method="avg")
+        z = vl.vl_nnconv(ubar, prm[0], bias, scale=sc, shift=sh)
+        f1 = [net.params[p].value for p in se["fc1"].params]
+        f2 = [net.params[p].value for p in se["fc2"].params]
+        h = vl.vl_nnconv(z, f1[0], f1[1] if se["fc1"].block.hasBias else None, relu=True)
+        a = vl.vl_nnconv(h, f2[0], f2[1] if se["fc2"].block.hasBias else None, sigmoid=True)
+        y = vl.vl_nnconv(u, prm[0], bias, stride=blk.stride, pad=blk.pad, dilate=blk.dilate, scale=sc, shift=sh,
+                         gate=a, residual=net.vars[se["shortcut"]].value, relu=se["relu"] is not None)
+        net.vars[self.out_name].value = y
+
+
+def _match_se_tail(net, recs, consumers, order, conv_rec, bn_rec):
+    """the SE tail behind a 1 x 1 / stride-1 projection + bnorm: {GlobalPooling('avg') -> Conv -> ReLU -> Conv -> Sigmoid}
+    and Axpy(gate, x, shortcut) [-> ReLU] as the only consumers of x, nothing precious in between"""
+    blk = conv_rec.block
+    if blk.size[0] != 1 or blk.size[1] != 1 or tuple(vl._pair(blk.stride, "STRIDE")) != (1, 1) or any(vl._pad4(blk.pad)):
+        return None
+    x = bn_rec.outputs[0]
+    cs = consumers.get(x, [])
+    if len(cs) != 2 or net.vars[x].precious:
+        return None
+    gp = [c for c in cs if isinstance(c.block, GlobalPooling) and c.block.method == "avg"]
+    ax = [c for c in cs if isinstance(c.block, Axpy)]
+    if len(gp) != 1 or len(ax) != 1:
+        return None
+    gp, ax = gp[0], ax[0]
+
+    def only(var, cls):
+        c = consumers.get(var, [])
+        return c[0] if len(c) == 1 and isinstance(c[0].block, cls) and not net.vars[var].precious else None
+    fc1 = only(gp.outputs[0], Conv)
+    r1 = only(fc1.outputs[0], ReLU) if fc1 else None
+    fc2 = only(r1.outputs[0], Conv) if r1 else None
+    sg = only(fc2.outputs[0], Sigmoid) if fc2 else None
+    if sg is None or r1.block.leak != 0.0 or only(sg.outputs[0], Axpy) is not ax:
+        return None
+    for fc in (fc1, fc2):
+        b = fc.block
+        if b.size[0] != 1 or b.size[1] != 1 or tuple(vl._pair(b.stride, "STRIDE")) != (1, 1) or any(vl._pad4(b.pad)):
+            return None
+    if len(ax.inputs) != 3 or ax.inputs[0] != sg.outputs[0] or ax.inputs[1] != x:
+        return None
+    shortcut = ax.inputs[2]
+    prod = [q for q in recs if shortcut in q.outputs]
+    if prod and not all(order[id(q)] < order[id(conv_rec)] for q in prod):
+        return None
+    out, relu = ax.outputs[0], None
+    rl = only(out, ReLU)
+    if rl is not None and rl.block.leak == 0.0:
+        relu, out = rl, rl.outputs[0]
+    return {"gp": gp, "fc1": fc1, "relu1": r1, "fc2": fc2, "sig": sg, "axpy": ax, "relu": relu, "out": out,
+            "shortcut": shortcut}
+
+
 def _link_bias_conv(bn_step, steps, r, consumers, training):
     """training plans: a biased Conv whose only consumer is this bnorm gets its dzdb from the bnorm backward (sum of
     dx) instead of a pass of its own over dzdy"""
@@ -1108,6 +1185,12 @@ def build_plan(net, training):
             continue
         if fold_ok and isinstance(r.block, Conv):
             bn = sole_consumer(r.outputs[0], BatchNorm)
+            se = _match_se_tail(net, recs, consumers, order, r, bn) if (bn is not None and net.fuseSE) else None
+            if se is not None:
+                steps.append(_SEFoldStep(r, bn, se))
+                skip.update(id(q) for q in (bn, se["gp"], se["fc1"], se["relu1"], se["fc2"], se["sig"], se["axpy"],
+                                            se["relu"]) if q is not None)
+                continue
             if bn is not None:
                 out = bn.outputs[0]
                 sm = sole_consumer(out, Sum)

@@ -135,9 +135,12 @@ def out_size(n, pa, pb, f, d, s):
 
 def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=False,
               no_der_filters=False, no_der_biases=False, scale=None, shift=None, residual=None,
-              relu=False, df_out=None, db_out=None, dx_accum=None, sigmoid=False, moments_out=None, epsilon=1e-4):
+              relu=False, df_out=None, db_out=None, dx_accum=None, sigmoid=False, moments_out=None, epsilon=1e-4,
+              gate=None):
     """Y = VL_NNCONV(X, F, B) / [DX, DF, DB] = VL_NNCONV(X, F, B, DZDY).
 
+    `gate` (forward, extension; 1 x 1 x K x N): per-(channel, sample) multiplier between scale / shift and the residual --
+    the SE excite folded into the projection that produces its operand (xm_nnconv_forward_gated).
     `moments_out` (forward, extension; a K x 2 device matrix): also receives the batch moments [mean, sqrt(var +
     epsilon)] of Y -- the statistics pass of the train-mode vl_nnbnorm that follows (xm_nnconv_forward_moments).
     `scale/shift/residual/relu/sigmoid` select the fused forward epilogue (extension; see xmodal.h);
@@ -159,7 +162,16 @@ def vl_nnconv(x, f, b=None, dzdy=None, stride=1, pad=0, dilate=1, no_der_data=Fa
     if dzdy is None:
         y = mat_empty(max(Ho, 0), max(Wo, 0), K, N, device=x.device)
         fused = scale is not None or residual is not None or relu or sigmoid
-        if moments_out is not None:
+        if gate is not None:
+            gt = _chk(gate, "GATE")
+            if gt.numel() != K * N:
+                raise ValueError("vl_nnconv: GATE must be 1 x 1 x %d x %d" % (K, N))
+            if residual is not None and _shape4(_chk(residual, "RESIDUAL")) != [Ho, Wo, K, N]:
+                raise ValueError("vl_nnconv: residual shape mismatch")
+            _lib.check(L.xm_nnconv_forward_gated(
+                _ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(bb), _ptr(y), sy, sx, pt, pb, pl, pr, dy, dx,
+                _ptr(scale), _ptr(shift), _ptr(gt), _ptr(residual), (1 if relu else 0) | (4 if sigmoid else 0), _stream()))
+        elif moments_out is not None:
             if fused:
                 raise ValueError("vl_nnconv: moments_out cannot be combined with a fused epilogue")
             mo = _chk(moments_out, "MOMENTS")

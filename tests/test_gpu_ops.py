@@ -369,6 +369,38 @@ def test_conv_fused_epilogue(gpu):
     close(vl.to_numpy(y), ref, what="fused conv")
 
 
+@pytest.mark.parametrize("case", [(8, 8, 16, 5, 40), (7, 7, 24, 9, 70), (14, 14, 64, 3, 256), (2, 2, 512, 6, 128)])
+def test_conv_gated_epilogue(gpu, case):
+    """xm_nnconv_forward_gated: y = relu(((conv + b) .* scale + shift) .* gate(k, n) + residual) for every tile
+    configuration (vector and scalar stores, LDS-DMA kernel, split-K combine) -- the SE excite folded into the 1 x 1
+    projection (mcnExtraLayers dagnn.Axpy: out = a .* x + shortcut)."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, K = case
+    rng = np.random.default_rng(H + C + K)
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, 1, 1, C, K), rnd(rng, K)
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    gate = O.F(rng.uniform(0.0, 1.0, (1, 1, K, N)))
+    res = rnd(rng, H, W, K, N)
+    y0 = O.vl_nnconv(x, f, b, acc64=True)
+    ref = np.maximum((y0 * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1)) * gate + res, 0)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+    kw = dict(scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)), gate=vl.from_numpy(gate),
+              residual=vl.from_numpy(res), relu=True)
+    try:
+        for cfg in list(range(L.xm_debug_num_conv_cfgs())) + [-1]:
+            L.xm_debug_force_conv_cfg(cfg)
+            close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, **kw)), ref, what="gated cfg %d" % cfg)
+        L.xm_debug_force_conv_cfg(-1)
+        old = L.xm_debug_force_conv_splits(2)
+        try:
+            close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, **kw)), ref, what="gated split-K")
+        finally:
+            L.xm_debug_force_conv_splits(old)
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+
+
 def test_conv_no_der_flags_and_errors(gpu):
     from mcncrossmodalemotions_amd import vl, _lib
     rng = np.random.default_rng(3)
