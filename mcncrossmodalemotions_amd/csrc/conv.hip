@@ -392,12 +392,45 @@ struct ProfScope {
   }
 };
 
+
+// co-resident blocks per CU of the register-staged configurations (VGPR-limited: 222 / 232 / 186 / 140 / 116 / 134 / 122)
+static const int kCfgOcc[kNumBaseCfg] = {2, 2, 2, 3, 4, 3, 4};
+
+// Hybrid schedule (ConvGemmArgs::hyS): a launch of more than one round of the chip whose LAST round is partly filled
+// computes the full rounds tile by tile and splits the remaining tiles along the reduction so that they fill the last
+// round with short blocks -- 3.06 rounds cost 3.06 + 1/S instead of 4.  Returns the split count of the remainder (1: plain).
+static int hybrid_plan(const ConvGemmArgs &a, int ci, int *full_out) {
+  static const bool off = getenv("XM_NO_HYBRID") != nullptr;
+  *full_out = 0;
+  if (off || is_dma_cfg(ci) || a.statPart || g_force_splits > 0) return 1;
+  const int tiles = a.nbm * a.nbn, slots = 256 * kCfgOcc[ci];
+  if (tiles <= slots || a.nkt < 16) return 1;
+  int full = tiles / slots * slots;
+  full -= full % a.nbm;                       // the remainder is a whole range of pixel tiles
+  const int rem = tiles - full;
+  if (rem <= 0 || rem * 5 > slots * 4) return 1;     // a last round that is > 80 % full is left alone
+  const int S = std::min(std::min(slots / rem, a.nkt / 8), 16);
+  if (S < 2) return 1;
+  *full_out = full;
+  return S;
+}
+
 static size_t gemm_slab_floats(const ConvGemmArgs &a, int ci, int *splits_out) {
   const Cfg &c = kCfgs[ci];
   int nbm = (a.M + c.bm() - 1) / c.bm(), nbn = (a.NP + c.bn() - 1) / c.bn();
   int splits = pick_splits(nbm * nbn, a.Rp / kBK);
   *splits_out = splits;
-  return splits > 1 ? (size_t)splits * a.M * ((a.NP + 3) & ~3) : 0;
+  size_t need = splits > 1 ? (size_t)splits * a.M * ((a.NP + 3) & ~3) : 0;
+  if (splits == 1 && !is_dma_cfg(ci)) {
+    // hybrid remainder: at most one round of tiles, up to 16 partial copies of each
+    ConvGemmArgs t = a;
+    t.nbm = nbm, t.nbn = nbn, t.nkt = a.Rp / kBK;
+    t.statPart = nullptr;
+    int full;
+    const int S = hybrid_plan(t, ci, &full);
+    if (S > 1) need = std::max(need, (size_t)S * a.M * ((size_t)(nbm * nbn - full) / nbm * c.bn() + 4));
+  }
+  return need;
 }
 
 static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *slab, hipStream_t st) {
@@ -411,7 +444,23 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
   a.NPs = (a.NP + 3) & ~3;
   a.slab = splits > 1 ? slab : nullptr;
   a.dbgCycles = g_dbg_cycles;
+  a.hyS = 1, a.hyFull = 0, a.hyTps = 0, a.hyP0 = 0;
   dim3 grid(a.nbm * a.nbn, splits);
+  int hyS = 1;
+  if (splits == 1 && slab) {
+    int full;
+    hyS = hybrid_plan(a, ci, &full);
+    if (hyS > 1) {
+      a.hyFull = full;
+      a.hyTps = (a.nkt + hyS - 1) / hyS;
+      hyS = (a.nkt + a.hyTps - 1) / a.hyTps;
+      a.hyS = hyS;
+      a.hyP0 = full / a.nbm * c.bn();
+      a.NPs = (a.NP - a.hyP0 + 3) & ~3;
+      a.slab = slab;
+      grid = dim3(full + (a.nbm * a.nbn - full) * hyS, 1);
+    }
+  }
   {
     const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP * (a.resid ? 2 : 1);
     ProfScope ps(0 * 100 + ci * 2 + mode, a.algoFlops > 0 ? a.algoFlops : 2.0 * a.M * (double)a.NP * a.Rtrue, st,
@@ -429,15 +478,17 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
       launch_gemm_cfg<0>(ci, a, grid, st);
   }
   XM_LAUNCH_CHECK();
-  if (splits > 1) {
-    const bool vec = a.vecStore && (a.NP & 3) == 0 && (a.NPs & 3) == 0 && ((uintptr_t)a.slab & 15) == 0;
-    const size_t n = (size_t)a.M * (vec ? a.NP / 4 : a.NP);
+  if (splits > 1 || hyS > 1) {
+    const int z = splits > 1 ? splits : hyS;
+    const int np = a.NP - a.hyP0;                       // pixels the slabs cover
+    const bool vec = a.vecStore && (np & 3) == 0 && (a.hyP0 & 3) == 0 && (a.NPs & 3) == 0 && ((uintptr_t)a.slab & 15) == 0;
+    const size_t n = (size_t)a.M * (vec ? np / 4 : np);
     if (vec)
       hipLaunchKernelGGL(conv_splitk_epilogue_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                         a, splits, make_fastdiv((uint32_t)(a.NP / 4)));
+                         a, z, make_fastdiv((uint32_t)(np / 4)));
     else
       hipLaunchKernelGGL(conv_splitk_epilogue_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                         a, splits, make_fastdiv((uint32_t)a.NP));
+                         a, z, make_fastdiv((uint32_t)np));
     XM_LAUNCH_CHECK();
   }
   return XM_OK;
@@ -663,7 +714,7 @@ static std::map<TuneKey, int> g_tuned;
 // are then the same in every process, and shapes already in the table pay no timed launches on the caller's
 // stream.  Shapes that are not in the table are still measured once per process (and written back by
 // xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
-constexpr int XM_TUNE_REV = 4;
+constexpr int XM_TUNE_REV = 5;   // 5: hybrid schedule (partly filled last round split along the reduction)
 static bool g_tune_loaded = false;
 static int g_tune_new = 0;  // entries measured in this process (not yet saved)
 
@@ -895,7 +946,8 @@ static const int4 *fwd_taps(const Geo &g, int count) {
 template <int ACT, bool VEC>
 __global__ void __launch_bounds__(256)
 fc_skinny_kernel(const float *__restrict__ x, const float *__restrict__ f, const float *__restrict__ b,
-                 float *__restrict__ y, int K, int M, int HW, int NP, int chunks, FastDiv divChunks, FastDiv divHW) {
+                 float *__restrict__ y, int K, int M, int HW, int NP, int chunks, FastDiv divChunks, FastDiv divHW,
+                 const float *__restrict__ scale, const float *__restrict__ shift) {
   __shared__ float red[4][32];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int m = (int)xm_div(blockIdx.x, divChunks);
@@ -967,6 +1019,7 @@ fc_skinny_kernel(const float *__restrict__ x, const float *__restrict__ f, const
     v = red[0][threadIdx.x];
     for (int w = 1; w < nw; ++w) v += red[w][threadIdx.x];
     if (b) v += b[m];
+    if (scale) v = v * scale[m] + shift[m];     // folded test-mode bnorm: (conv + b) .* scale + shift
     if (ACT == 1) v = fmaxf(v, 0.f);
     if (ACT == 2) v = 1.f / (1.f + expf(-v));
     const int n = (int)xm_div((uint32_t)p, divHW);
@@ -982,7 +1035,7 @@ static bool fc_skinny_ok(const Geo &g) {
   return (long long)g.K * ((NP + 31) / 32) <= 65535 && (long long)g.H * g.W * g.C * g.N < (1ll << 31);
 }
 static int fc_skinny_forward(const float *x, const float *f, const float *b, float *y, const Geo &g, int act,
-                             hipStream_t st) {
+                             hipStream_t st, const float *scale = nullptr, const float *shift = nullptr) {
   const int HW = g.H * g.W, NP = HW * g.N, chunks = (NP + 31) / 32;
   const bool vec = HW == 1 && (g.C & 3) == 0 && (((uintptr_t)x | (uintptr_t)f) & 15) == 0;
   const int units = vec ? g.C / 4 : g.C;   // k positions handed out per lane step
@@ -990,7 +1043,7 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
   dim3 grid(g.K * chunks), block(64 * nw);
   FastDiv dc = make_fastdiv((uint32_t)chunks), dh = make_fastdiv((uint32_t)HW);
 #define XM_FC_LAUNCH(A, V) \
-  hipLaunchKernelGGL((fc_skinny_kernel<A, V>), grid, block, 0, st, x, f, b, y, g.C, g.K, HW, NP, chunks, dc, dh)
+  hipLaunchKernelGGL((fc_skinny_kernel<A, V>), grid, block, 0, st, x, f, b, y, g.C, g.K, HW, NP, chunks, dc, dh, scale, shift)
   if (vec) {
     if (act == 2) XM_FC_LAUNCH(2, true);
     else if (act == 1) XM_FC_LAUNCH(1, true);
@@ -1797,8 +1850,9 @@ int xm_nnconv_forward_fused(const float *x, int H, int W, int C, int N, const fl
   if ((flags & XM_FUSE_RELU) && (flags & XM_FUSE_SIGMOID))
     return fail(XM_EINVAL, "vl_nnconv(fused): relu and sigmoid are exclusive");
   hipStream_t st = (hipStream_t)stream;
-  if (!scale && !residual && fc_skinny_ok(g))
-    return fc_skinny_forward(x, f, b, y, g, (flags & XM_FUSE_SIGMOID) ? 2 : ((flags & XM_FUSE_RELU) ? 1 : 0), st);
+  if (!residual && fc_skinny_ok(g))
+    return fc_skinny_forward(x, f, b, y, g, (flags & XM_FUSE_SIGMOID) ? 2 : ((flags & XM_FUSE_RELU) ? 1 : 0), st, scale,
+                             shift);
   rc = conv_forward(x, f, b, y, g, scale, shift, residual, (flags & XM_FUSE_RELU) ? 1 : 0, st);
   if (rc || !(flags & XM_FUSE_SIGMOID)) return rc;
   return xm_nnsigmoid(y, (size_t)g.Ho * g.Wo * g.K * g.N, nullptr, y, stream);  // in place (elementwise)

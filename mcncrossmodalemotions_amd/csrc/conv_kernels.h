@@ -65,6 +65,11 @@ struct ConvGemmArgs {
   int vecStore;       // 1: 4 consecutive pixels are contiguous & 16-B friendly -> dwordx4 epilogue
   int nbm, nbn;       // tile counts
   int tilesPerSplit, nkt;
+  // Hybrid schedule of conv_gemm_kernel (hyS > 1): the first hyFull tiles (whole rounds of the chip) are computed by one
+  // block each; each of the remaining tiles -- the partly filled last round -- is split hyS ways along the reduction
+  // (hyTps stages per split), its partial sums go to the slab ([split][M][NPs], pixel index relative to hyP0) and
+  // conv_splitk_epilogue_kernel combines them over the pixel range [hyP0, NP).  grid.x = hyFull + (tiles - hyFull) * hyS.
+  int hyFull, hyS, hyTps, hyP0;
   // != NULL (vecStore, no split-K, not the LDS-DMA kernel): every BLOCK also leaves {sum, sum of squares} of the
   // values it stores, per row: statPart[pixel tile bn][row][2] (rows contiguous: one coalesced run per block).  The batch
   // moments of the train-mode bnorm that follows the convolution then cost no second pass over Y (conv_forward).
@@ -221,7 +226,8 @@ __device__ __forceinline__ void xm_st4(float *p, float v) {
 template <int TM, int TN, int WGM, int WGN, bool ASMST = false>
 __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16 (&acc)[TM][TN], int bm, int bn,
                                                    int split, int wm, int wn, int half, int l31,
-                                                   float *sred = nullptr /* LDS, >= 2 * WGN * BM floats (statPart) */) {
+                                                   float *sred = nullptr /* LDS, >= 2 * WGN * BM floats (statPart) */,
+                                                   bool toSlab = true /* a.slab != NULL: this block writes partials */) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
 #if defined(XM_VARIANT) && XM_VARIANT == 2
   {  // experiment: no stores (keeps the accumulators alive through an impossible condition)
@@ -234,9 +240,9 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
   }
 #endif
   // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  if (a.slab) {
-    // split-K: raw partial sums, [split][m][p] with p contiguous
-    float *out = a.slab + (size_t)split * a.M * a.NPs;
+  if (a.slab && toSlab) {
+    // split-K: raw partial sums, [split][m][p] with p contiguous (hybrid schedule: p relative to hyP0)
+    float *out = a.slab + (size_t)split * a.M * a.NPs - a.hyP0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       int p = bn * BN + (wn * TN + j) * 32 + l31;
@@ -477,11 +483,29 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave % WGM, wn = wave / WGM;
-  const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+  int tile, split, kt0, kt1;
+  bool toSlab = true;
+  if (a.hyS > 1) {
+    // hybrid: whole tiles for the full rounds, the remainder tiles split along the reduction (see ConvGemmArgs)
+    const int b = (int)blockIdx.x;
+    if (b < a.hyFull) {
+      tile = xcd_remap(b, a.hyFull);
+      split = 0, kt0 = 0, kt1 = a.nkt;
+      toSlab = false;
+    } else {
+      const int r = b - a.hyFull;
+      tile = a.hyFull + r / a.hyS;
+      split = r - (r / a.hyS) * a.hyS;
+      kt0 = split * a.hyTps;
+      kt1 = min(a.nkt, kt0 + a.hyTps);
+    }
+  } else {
+    tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+    split = blockIdx.y;
+    kt0 = split * a.tilesPerSplit;
+    kt1 = min(a.nkt, kt0 + a.tilesPerSplit);
+  }
   const int bm = tile % a.nbm, bn = tile / a.nbm;
-  const int split = blockIdx.y;
-  const int kt0 = split * a.tilesPerSplit;
-  const int kt1 = min(a.nkt, kt0 + a.tilesPerSplit);
 
   // ---- per-thread gather geometry (fixed for the whole reduction) ----
   const int pl = t % BN, gB0 = t / BN;
@@ -689,7 +713,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 #undef XM_STAGE_LAST
 
   if (TM * TN == 1) acc[0][0] += accx;
-  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31, smem);
+  conv_gemm_epilogue<TM, TN, WGM, WGN>(a, acc, bm, bn, split, wm, wn, half, l31, smem, toSlab);
 }
 
 template <int TM, int TN, int WGM, int WGN, int MODE>
@@ -1177,7 +1201,8 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
   const uint32_t cols = divCols.d;
   if (idx >= (uint32_t)a.M * cols) return;
   const int m = (int)xm_div(idx, divCols);
-  const int p = (int)(idx - (uint32_t)m * cols) * (VEC ? 4 : 1);
+  const int pr = (int)(idx - (uint32_t)m * cols) * (VEC ? 4 : 1);   // relative to hyP0 (0 for a plain split-K launch)
+  const int p = pr + a.hyP0;
   uint32_t n = xm_div((uint32_t)p, a.divPIJ);
   uint32_t q = (uint32_t)p - n * a.divPIJ.d;
   uint32_t jj = xm_div(q, a.divPI);
@@ -1187,7 +1212,7 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
             (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
   if (VEC) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(a.slab + ((size_t)z * a.M + m) * a.NPs + p);
+    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(a.slab + ((size_t)z * a.M + m) * a.NPs + pr);
     if (a.bias) v += a.bias[m];
     if (a.scale) v = v * a.scale[m] + a.shift[m];
     if (a.gate) v *= a.gate[m + (int)n * a.gateStride];
@@ -1201,7 +1226,7 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
     *reinterpret_cast<f32x4 *>(a.Y + off) = v;
   } else {
     float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + p];
+    for (int z = 0; z < splits; ++z) v += a.slab[((size_t)z * a.M + m) * a.NPs + pr];
     if (a.bias) v += a.bias[m];
     if (a.scale) v = v * a.scale[m] + a.shift[m];
     if (a.gate) v *= a.gate[m + (int)n * a.gateStride];

@@ -122,7 +122,9 @@ def test_frozen_teacher_lanes_match_single_stream(gpu):
         for _ in range(2):  # second call reuses plans / replicas
             got = vl.to_numpy(ft.logits(xd))
         assert got.shape == one.shape
-        close(got, one, 1e-5, "%d lanes vs single" % lanes)
+        # (not bit-identical: the slices select other tile configurations / split-K factors, and the SE squeeze of a
+        # small slice takes the skinny-FC kernel instead of the GEMM -- other summation orders, fp32 round-off level)
+        close(got, one, 3e-5, "%d lanes vs single" % lanes)
         close(got, V["prediction"], 1e-4, "%d lanes vs oracle" % lanes)
     net.mode = "normal"
     with pytest.raises(ValueError):

@@ -94,6 +94,12 @@ def test_conv_skinny_fc(gpu, case):
     # no bias
     y0 = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), None)
     close(vl.to_numpy(y0), O.vl_nnconv(x, f, None, acc64=True), 2e-6, what="skinny fc, no bias")
+    # folded test-mode bnorm (scale / shift) on the skinny path: the SE squeeze taken through the projection
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    ys = vl.vl_nnconv(vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)),
+                      scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)), relu=act == "relu")
+    ref = O.vl_nnconv(x, f, b, acc64=True) * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1)
+    close(vl.to_numpy(ys), np.maximum(ref, 0) if act == "relu" else ref, 3e-6, what="skinny fc, scale / shift")
 
 
 def test_conv_fused_sigmoid_general_path(gpu):
@@ -399,6 +405,38 @@ def test_conv_gated_epilogue(gpu, case):
             L.xm_debug_force_conv_splits(old)
     finally:
         L.xm_debug_force_conv_cfg(-1)
+
+
+@pytest.mark.parametrize("geom", [(40, 35, 256, 32, 256, 1), (15, 13, 32, 230, 128, 3)])
+def test_conv_hybrid_schedule(gpu, geom):
+    """launches of more than one round of the chip with a partly filled last round: whole tiles for the full rounds, the
+    remaining tiles split along the reduction and combined by conv_splitk_epilogue_kernel over their pixel range
+    (ConvGemmArgs::hyS) -- every register-staged tile configuration, plain and fused epilogue, vector and scalar stores."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, K, F = geom
+    rng = np.random.default_rng(H + K)
+    pad = F // 2
+    x, f, b = rnd(rng, H, W, C, N), O.F(rng.standard_normal((F, F, C, K)) / np.sqrt(F * F * C)), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, pad=pad, acc64=True)
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    res = rnd(rng, *y_ref.shape)
+    ref2 = np.maximum(y_ref * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1) + res, 0)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+    kw = dict(scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)), residual=vl.from_numpy(res), relu=True)
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, _, _ = O.vl_nnconv(x, f, b, dzdy, pad=pad, acc64=True, no_der_filters=True)
+    old = L.xm_debug_force_conv_halo(0)
+    try:
+        for cfg in range(7):
+            L.xm_debug_force_conv_cfg(cfg)
+            close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=pad)), y_ref, what="hybrid cfg %d" % cfg)
+            close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=pad, **kw)), ref2, what="hybrid cfg %d, fused epilogue" % cfg)
+            dx, _, _ = vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), pad=pad, no_der_filters=True)
+            close(vl.to_numpy(dx), dx_ref, what="hybrid cfg %d dgrad" % cfg)
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+        L.xm_debug_force_conv_halo(old)
 
 
 def test_conv_no_der_flags_and_errors(gpu):
