@@ -90,7 +90,9 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the prev
 Round 2 -> round 3 on the default line: 3812 -> {d['value']} pairs/s; student batch 64: 5373 -> {st['value']} samples/s; north_star batch 256
 (SE-ResNet50): 3903 -> {se256['value']} pairs/s; one stream: 3415 -> {ds['value']}.  Where it came from: bnorm batch
 moments from the convolution epilogue (no second pass over the conv output; +0.9 % / +3.5 % at 64); the FC-shaped dgrad
-filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32).
+filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32);
+the SE tail of the frozen teachers fused algebraically (2.2d: config 3 11044 -> {te['value']} img/s, every SE-ResNet50 line); the hybrid
+schedule for partly filled last rounds (+1 % on the teacher and batch-256 lines).
 What did NOT move the step is in `schedule_experiments.txt`: the step is work-conserving (serial sum 9.2 ms -> {d['ms_per_step']} ms overlapped),
 its main stream never waits (`phase_marks.txt`), and only work removed from the main stream shows up one to one.
 
