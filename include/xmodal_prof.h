@@ -23,6 +23,8 @@ int xm_debug_num_conv_cfgs(void);
 /* 1 + v: halo-patch kernel variant v (0: 128-row tiles, 1: 96-row tiles, 2: 96-row tiles / tall patch) wherever it can
  * run, another runnable variant otherwise; 0: never; -1: measured choice (default) */
 int xm_debug_force_conv_halo(int on);
+/* 1: the single-channel stem kernel (conv_stem_kernel) wherever it can run; 0: never; -1: measured choice (default) */
+int xm_debug_force_conv_stem(int on);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);
 /* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,

@@ -348,6 +348,7 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 }
 
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
+static int g_force_stem = -1; // test hook (xm_debug_force_conv_stem): 1 = conv_stem_kernel wherever it can run, 0 = never
 static int g_force_halo = -1; // test hook (xm_debug_force_conv_halo): 1 = halo-patch kernel wherever it can run, 0 = never
 static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
@@ -1061,6 +1062,44 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
 // moments_out != NULL: also the batch moments [mean, sqrt(var + eps)] of Y (the statistics half of the train-mode
 // vl_nnbnorm that follows the convolution), from per-wave partial sums of the GEMM epilogue when the launch allows it
 // (16-byte-store epilogue, no split-K, no filter groups), else by a pass over Y.
+// ---- single-channel stem (conv_stem_kernel) ----------------------------------------------------------------------
+// Forward convolutions over ONE input channel with <= 8 x 7 taps, stride 1 / 2 along H, <= 96 filters, source columns of
+// <= 512 rows (the student's conv1 over 512-bin spectrograms).  `f` is the caller's filter bank, unpadded.
+static bool stem_ok(const ConvGemmArgs &a, const Geo &g, const float *x, const float *f) {
+  static const bool off = getenv("XM_NO_STEM") != nullptr;
+  if (off || g_force_cfg >= 0 || g_force_splits > 0) return false;
+  if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
+  if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.Kg > 96) return false;
+  if (g.sy != 1 && g.sy != 2) return false;
+  if (!a.vecStore || a.scale || a.resid || a.gate || a.relu) return false;
+  if (g.H % 4 != 0 || g.H > kStemHP - 8 || ((uintptr_t)x & 15) != 0) return false;
+  if (g.pt > 4 || 4 * ((g.sy * (g.Ho - 1) - g.pt + 4 + 7) >> 2) + 3 >= kStemHP) return false;   // last 16-byte row unit a tile loads
+  if (g.Ho < 128) return false;                                                  // a tile spans <= 2 output columns
+  if (g_force_stem != 1 && (long long)g.Ho * g.Wo * g.N < 128 * 512) return false;   // >= one round of the chip
+  (void)f;
+  return true;
+}
+
+static int stem_grid(int NP) { return std::min(256 * XM_STEM_OCC, ((NP + 127) / 128 + 7) / 8 * 8); }
+
+static int launch_stem(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
+  a.A = f;
+  a.lda = R;
+  a.nbm = 1;
+  a.nbn = (a.NP + 127) / 128;
+  a.slab = nullptr;
+  a.hyS = 1, a.hyFull = 0, a.hyTps = 0, a.hyP0 = 0;
+  a.piReal = 0;
+  a.dbgCycles = g_dbg_cycles;
+  const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP;
+  ProfScope ps(5 * 100, 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
+  const int grid = stem_grid(a.NP);
+  if (a.gsy == 2) hipLaunchKernelGGL(conv_stem_kernel<2>, dim3(grid), dim3(256), 0, st, a, a.nbn);
+  else hipLaunchKernelGGL(conv_stem_kernel<1>, dim3(grid), dim3(256), 0, st, a, a.nbn);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
@@ -1194,6 +1233,25 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
+    if (stem_ok(a, g, x, f)) {
+      // the single-channel stem kernel against the best implicit-GEMM configuration (measured once per shape)
+      auto run3 = [&](int h) {
+        if (!h) return run(ci);
+        ConvGemmArgs aa = a;
+        stat_ncg = 0;
+        if (stats_ok) {
+          stat_ncg = stem_grid(a.NP);             // one partial per (persistent) block
+          aa.statPart = statp;
+          aa.statNcg = stat_ncg;
+        }
+        return launch_stem(aa, f, g.R, st);
+      };
+      bool sok[2] = {true, true};
+      TuneKey skey{7, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      const int pick = g_force_stem >= 0 ? g_force_stem : tune_challengers(skey, st, run3, 2, sok, kHaloMargin);
+      rc = run3(pick);
+      if (rc) return rc;
+    } else {
     // <= 3 x 3 taps / unit stride: the halo-patch kernel variants against the best implicit-GEMM configuration
     // (measured once per shape, alternating launches, the challenger must win by a margin)
     ConvGemmArgs ah = a;
@@ -1221,6 +1279,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       rc = run(ci);
     }
     if (rc) return rc;
+    }
     if (stat_ncg > 0) {
       const int S = std::max(1, std::min(64, stat_ncg / 256));
       hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((g.K + 31) / 32, S), dim3(256), 0, st, statp, moments_out,
@@ -1695,6 +1754,12 @@ int xm_debug_force_conv_halo(int on) {
   return old;
 }
 
+int xm_debug_force_conv_stem(int on) {
+  int old = g_force_stem;
+  g_force_stem = on < 0 ? -1 : (on ? 1 : 0);
+  return old;
+}
+
 // ---- persistent tuning table (include/xmodal.h) ----------------------------------------------
 int xm_tune_load(const char *path) {
   g_tune_loaded = true;
@@ -1820,6 +1885,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     const int v = key % 100;
     snprintf(buf, len, "%s<%s, %d>", kind == 3 ? "conv_halo_kernel" : "conv_halo_multi_kernel",
              v == 0 ? "2, 2, 2, 2" : "3, 1, 1, 4", v == 2 ? 1024 : 512);
+    return XM_OK;
+  }
+  if (kind == 5) {
+    snprintf(buf, len, "conv_stem_kernel<2>");
     return XM_OK;
   }
   int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;

@@ -27,6 +27,8 @@
 //   * split-K (grid.y) for layers with few output tiles; partial slabs are combined in a fixed
 //     order by conv_splitk_epilogue_kernel (deterministic, no atomics).
 #pragma once
+#include <type_traits>
+
 #include "xm_common.h"
 
 namespace xm {
@@ -1189,6 +1191,262 @@ conv_halo_multi_kernel(const ConvGemmMulti m) {
   if (T == 9) conv_halo_body<9, TM, TN, WGM, WGN, PS>(a, smem);
   else if (T == 6) conv_halo_body<6, TM, TN, WGM, WGN, PS>(a, smem);
   else conv_halo_body<4, TM, TN, WGM, WGN, PS>(a, smem);
+}
+
+// ---- single-channel stem (the student's conv1: 7 x 7 taps, stride 2, 1 -> 96 channels over 512 x W spectrograms) ----
+// K = 49 and a 462 MB output at 32 spectrograms: the layer is bounded by its stores (0.09 ms at the write rate this
+// store pattern reaches; tools/store_mfma_probe.hip: 0.107 ms with the MFMAs next to them), the generic kernel needs
+// 0.30 ms -- every block pays a gather prologue (49 taps x 128 pixels of dword loads), 4 K-stages of 16, its stores, and
+// then leaves.  This kernel is PERSISTENT, keeps everything a tile needs on chip and has NO barrier in its tile loop:
+//   * the filter bank lives in LDS for the whole kernel in MFMA operand order (k = 8 v + u: filter column v, filter
+//     row u, row 7 = 0; one 16-byte read per (column, row tile)), so a tile issues no global loads for A at all;
+//   * every WAVE owns 32 consecutive output pixels of the 128-pixel tile (a piece of one output column, or the end of
+//     one and the start of the next) and stages the source rows under them itself: 7 source columns x <= 24 16-byte
+//     row units per column group into its own LDS patch (3 loads per lane, issued BEFORE the MFMAs of the current tile
+//     and written behind them: LDS operations of a wave execute in order, so the reads of the current patch are done).
+//     A lane's tap (u, v) is then at base + v * 96 + u, all immediates;
+//   * waves therefore drift apart freely: one wave's epilogue and stores run under another wave's MFMAs (with a barrier
+//     per tile the four waves of a block -- and, measured, the two blocks of a CU -- stay in phase: 165 us);
+//   * the stores of a tile are plain stores; nothing waits on them until the patch loads issued AFTER them are needed,
+//     a whole tile later.  No load is issued under a branch and no epilogue constant is loaded inside the loop (a
+//     register that may be pending at the loop's back edge costs an s_waitcnt vmcnt(0) = a wait for all stores).
+// Tiles are the same 96 x 128 tiles in the same enumeration as conv_gemm_kernel<3, 1, 1, 4, 1> and the epilogue is the
+// same arithmetic (bias, 16-byte stores); the summation order per output is k = 8 v + u ascending.  Statistics for the
+// following train-mode bnorm: per-lane partial sums over all tiles of the block, ONE reduction per block at the end.
+#ifndef XM_STEM_OCC
+#define XM_STEM_OCC 2
+#endif
+constexpr int kStemHP = 520;   // source columns of <= 512 rows (+ 4 rows of padding either side)
+constexpr int kStemNV = 7;     // filter columns; 8 filter rows (the 8th has zero weights) per column
+constexpr int kStemHW = 96;    // rows of a wave's patch per (column group, source column): 24 units of 16 bytes
+constexpr int kStemTP = 36;    // row pitch (floats) of the epilogue's transpose tile: 32 pixels + 4
+
+template <int SY>
+__global__ void __launch_bounds__(256, XM_STEM_OCC)
+conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
+  constexpr int TM = 3, NV = kStemNV, HW = kStemHW, GRP = NV * HW, WPATCH = 2 * GRP + 4;   // floats (+ a dummy unit)
+  __shared__ __attribute__((aligned(16))) float sP[4 * WPATCH];             // [wave][column group][v][row] + dummy
+  __shared__ __attribute__((aligned(16))) float sA[NV * TM * 2 * 32 * 4];   // [v][row tile][half][l31][e]
+  __shared__ __attribute__((aligned(16))) float sT[4 * 32 * kStemTP];        // [wave][channel row][pixel]: epilogue transpose;
+  float *const sred = sT;                                                   // after the loop: 2 * 4 * 96 floats of partial sums
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  for (int i = t; i < 4 * WPATCH / 4; i += 256) reinterpret_cast<f32x4 *>(sP)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the filter bank, in the order the MFMA A operand wants it: lane (l31, half) of row tile i reads
+  // A[32 i + l31][k = 8 v + e + 4 half], e = 0 .. 3, with one 16-byte LDS read per (v, i)
+  for (int idx = t; idx < NV * TM * 2 * 32 * 4; idx += 256) {
+    const int e = idx & 3, l = (idx >> 2) & 31, h = (idx >> 7) & 1, vi = idx >> 8, i = vi % TM, v = vi / TM;
+    const int m = 32 * i + l, u = e + 4 * h;
+    sA[idx] = (m < a.M && u < a.nU && v < a.nV) ? a.A[(size_t)m * a.lda + u + a.nU * v] : 0.f;
+  }
+
+  // block b walks tiles b, b + grid, b + 2 grid, ...: at any moment the chip writes one window of consecutive tiles
+  // (XCD-contiguous ranges -- neighbouring tiles share 5 of their 7 source columns -- measured 2-3 % slower: the 20 MB
+  // input is served by the L2s / MALL either way, the 462 MB of stores prefer the single window)
+  const int tbase = 0, tstep = gridDim.x, tend = ntiles;
+  const int PIJ = (int)a.divPIJ.d, PI = (int)a.divPI.d;
+  float *const sW = sP + wave * WPATCH;   // this wave's patch
+
+  // Patch staging of a wave: lane -> (source column lc = lane / 8, row units lk, lk + 8, lk + 16 of the wave's unit
+  // list: the units of column group 0 first, then those of group 1).  Every lane ALWAYS issues its three loads and
+  // ALWAYS writes three units (a unit outside the image or beyond the list reads the first 16 bytes of X and is written
+  // as zeros / to the dummy unit): no branch around a load (see above).
+  const int lc = lane >> 3, lk = lane & 7;
+  f32x4 ld[3];
+  int ldst[3];      // LDS float index of each unit inside the wave's patch
+  bool ldz[3];      // write zeros
+  // column groups of the wave's 32 pixels in tile `tile`: (sample, column, row) of the first pixel and of the last one
+  // (wave-uniform: scalar registers, scalar divisions)
+  struct Cols {
+    int nF, jF, iF, nL, jL, iL;
+  };
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto wave_cols = [&](int tile) {
+    Cols c;
+    const uint32_t pF = min((uint32_t)tile * 128u + 32u * wv, (uint32_t)a.NP - 1u), pL = min(pF + 31u, (uint32_t)a.NP - 1u);
+    c.nF = (int)xm_div(pF, a.divPIJ);
+    uint32_t q = pF - (uint32_t)c.nF * PIJ;
+    c.jF = (int)xm_div(q, a.divPI);
+    c.iF = (int)q - c.jF * PI;
+    c.nL = (int)xm_div(pL, a.divPIJ);
+    q = pL - (uint32_t)c.nL * PIJ;
+    c.jL = (int)xm_div(q, a.divPI);
+    c.iL = (int)q - c.jL * PI;
+    return c;
+  };
+  auto issue_loads = [&](const Cols &c) {
+    const bool two = c.nF != c.nL || c.jF != c.jL;
+    const int hi0 = two ? PI - 1 : c.iL;
+    const int lo4[2] = {(SY * c.iF + a.gh0 + 4) >> 2, (a.gh0 + 4) >> 2};
+    const int n0 = ((SY * hi0 + a.gh0 + 4 + 7) >> 2) - lo4[0] + 1;
+    const int n1 = two ? ((SY * c.iL + a.gh0 + 4 + 7) >> 2) - lo4[1] + 1 : 0;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int q = lk + 8 * it;
+      const int g = q >= n0 ? 1 : 0, u = q - (g ? n0 : 0);
+      const bool wr = lc < NV && q < n0 + n1;
+      const int n = g ? c.nL : c.nF, j = g ? c.jL : c.jF;
+      const int cc = a.gsx * j + a.gw0 + lc, r = 4 * (lo4[g] + u) - 4;
+      const bool in = wr && lc < a.nV && cc >= 0 && cc < a.LimW && r >= 0 && r < a.LimH;
+      ldst[it] = wr ? (g * NV + lc) * HW + 4 * u : 2 * GRP;
+      ldz[it] = !in;
+      // an asm load: the compiler does not count it, so the wait in front of its use is written by hand (XM_STEM_PATCH_WAIT)
+      const float *src = in ? a.X + (size_t)n * a.xSampleStride + (size_t)cc * a.LimH + r : a.X;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[it]) : "v"(src) : "memory");
+    }
+  };
+  // s_waitcnt vmcnt(N) for the three patch loads: N = number of vector memory operations issued behind them
+#define XM_STEM_PATCH_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]) : : "memory")
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+      *reinterpret_cast<f32x4 *>(sW + ldst[it]) = ldz[it] ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[it];
+  };
+
+  int q = blockIdx.x;
+  __syncthreads();                       // zero fill and filter bank are complete
+  const f32x4 *pa = reinterpret_cast<const f32x4 *>(sA) + half * 32 + l31;
+  float rbias[TM][4];   // bias of the rows this lane stores after the epilogue's transpose
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      rbias[i][g4] = a.bias ? a.bias[min(32 * i + 8 * g4 + 4 * half + (l31 & 3), a.M - 1)] : 0.f;
+  // a.statPart: this lane's share of {sum, sum of squares} of the rows it stores, over ALL tiles of the block (one
+  // reduction per block at the end, statPart[block][row]: a per-tile reduction costs a barrier, 24 DPP chains and an
+  // LDS round trip per tile -- 45 us of the 210 the kernel took with it)
+  float sacc1[TM][4], sacc2[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) sacc1[i][g4] = 0.f, sacc2[i][g4] = 0.f;
+#ifdef XM_DEBUG_CYCLES
+  unsigned long long dc[4] = {0, 0, 0, 0}, c0, c1;
+#define XM_STEM_T(k) c1 = __builtin_readcyclecounter(), dc[k] += c1 - c0, c0 = c1
+  c0 = __builtin_readcyclecounter();
+#else
+#define XM_STEM_T(k)
+#endif
+  Cols cur = wave_cols(tbase + min(q, max(tend, 1) - 1));
+  if (q < tend) {
+    issue_loads(cur);
+    XM_STEM_PATCH_WAIT(0);
+    write_patch();
+  }
+  for (; q < tend; q += tstep) {
+    const int tile = tbase + q;
+    const Cols nxt = wave_cols(q + tstep < tend ? tile + tstep : tile);   // (the last tile is staged once more: no branch)
+    // this lane's pixel: 32 consecutive pixels span at most two output columns (PI >= 128) -- no division
+    int ii = cur.iF + l31, jj = cur.jF, n = cur.nF, grp = 0;
+    if (ii >= PI) ii -= PI, jj = cur.jL, n = cur.nL, grp = 1;
+    const uint32_t qq = (uint32_t)(ii + PI * jj);                              // pixel offset inside its sample
+    const int w0 = grp ? ((a.gh0 + 4) >> 2) : ((SY * cur.iF + a.gh0 + 4) >> 2);   // first row unit of the group's window
+    const float *pb = sW + grp * GRP + SY * ii + a.gh0 + 4 - 4 * w0 + 4 * half;
+    cur = nxt;
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    XM_STEM_T(0);   // loads issued, lane geometry
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = pa[(v * TM + i) * 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float bv = pb[v * HW + e];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv, acc[i][0], 0, 0, 0);
+      }
+    }
+    // The next tile's patch loads are issued BEHIND the MFMAs and IN FRONT of this tile's stores: loads and stores share
+    // one in-order counter, so waiting for a load also waits for every store issued before it.  In this order the wait
+    // in front of write_patch() below is vmcnt(12) (written by hand: XM_STEM_PATCH_WAIT) -- it leaves this tile's 12 stores in flight and only needs the stores
+    // of the PREVIOUS tile, which have had a whole iteration to drain (with the loads in front of the MFMAs the wait
+    // needed the previous tile's stores after one MFMA phase).  The epilogue covers the load latency.
+    __builtin_amdgcn_sched_barrier(0);
+    issue_loads(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    XM_STEM_T(1);   // MFMA phase + loads issued
+    // Epilogue (dense forward output, 16-byte stores, bias [+ statistics]): the arithmetic of conv_gemm_epilogue's
+    // vector path.  The 4 x 4 transpose that turns "4 channel rows of one pixel" into "4 pixels of one channel row" goes
+    // through a wave-private LDS tile (16 dword writes + 4 16-byte reads per row tile) instead of the DPP quad
+    // transpose (16 VALU operations per 4 registers: with K = 49 the epilogue was as long as the MFMA phase).
+    {
+      const int iq = l31 & 3;
+      const bool ok = (uint32_t)tile * 128u + 32u * wave + l31 < (uint32_t)a.NP;   // quads never straddle NP (NP % 4 == 0)
+      // pixel quad base: dense output, p - n * PIJ is the offset inside the sample
+      float *yq = a.Y + (size_t)n * a.oSampleStride + (qq - iq);
+      float *const tw = sT + wave * (32 * kStemTP) + 4 * half * kStemTP + l31;              // + row(r) * TP
+      const float *const tr = sT + wave * (32 * kStemTP) + (4 * half + iq) * kStemTP + (l31 & ~3);   // + 8 g4 * TP
+      // a wave whose 32 pixels and 96 rows all exist (every wave but those of the last tile) runs without any lane
+      // predicate: no exec-mask branch around the LDS reads and the stores, so that they are issued back to back
+      auto rows = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2)) * kStemTP] = acc[i][0][r];
+          f32x4 v[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4 *>(tr + 8 * g4 * kStemTP);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int row = 32 * i + 8 * g4 + 4 * half + iq;
+            const f32x4 o = {v[g4].x * 1.f + rbias[i][g4], v[g4].y * 1.f + rbias[i][g4], v[g4].z * 1.f + rbias[i][g4],
+                             v[g4].w * 1.f + rbias[i][g4]};
+            if (FULL || ok) {
+              sacc1[i][g4] += (o.x + o.y) + (o.z + o.w);
+              sacc2[i][g4] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+              if (FULL || row < a.M) *reinterpret_cast<f32x4 *>(yq + (size_t)row * a.oChanStride) = o;
+            }
+          }
+        }
+      };
+      const bool full = (uint32_t)tile * 128u + 32u * wave + 32u <= (uint32_t)a.NP && a.M == 32 * TM;   // wave-uniform
+      if (full) {
+        rows(std::true_type{});
+        XM_STEM_PATCH_WAIT(12);   // exactly 12 stores, no branch: they stay in flight
+      } else {
+        rows(std::false_type{});
+        XM_STEM_PATCH_WAIT(0);
+      }
+    }
+    XM_STEM_T(2);   // epilogue + wait for the loads
+    __builtin_amdgcn_sched_barrier(0);
+    write_patch();                       // (LDS operations of a wave execute in order: behind its reads of the old patch)
+    XM_STEM_T(3);   // wait for the loads, patch write
+  }
+#ifdef XM_DEBUG_CYCLES
+  if (a.dbgCycles && t == 0 && blockIdx.x < 4096)
+    for (int k = 0; k < 4; ++k) a.dbgCycles[blockIdx.x * 4 + k] = dc[k];
+#endif
+  if (a.statPart) {
+    // 8 lanes of a row class (DPP), the 4 waves of the block through LDS in wave order, one contiguous run of rows per
+    // block (blocks without tiles store zeros: conv_stats_reduce_kernel adds all gridDim.x partials)
+    const int iq = l31 & 3;
+    __syncthreads();                     // every wave is done with its transpose tile (sred lives there)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float u = quad_class_sum8(sacc1[i][g4]), w = quad_class_sum8(sacc2[i][g4]);
+        const int rl = i * 32 + 8 * g4 + 4 * half + iq;
+        if ((l31 >> 2) == 0) *reinterpret_cast<float2 *>(sred + 2 * (wave * 96 + rl)) = make_float2(u, w);
+      }
+    __syncthreads();
+    if (t < 96 && t < a.M) {
+      float u = 0.f, w = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const float2 z = *reinterpret_cast<const float2 *>(sred + 2 * (wv * 96 + t));
+        u += z.x;
+        w += z.y;
+      }
+      *reinterpret_cast<float2 *>(a.statPart + ((size_t)blockIdx.x * a.M + t) * 2) = make_float2(u, w);
+    }
+  }
 }
 
 // combine split-K slabs in split order and apply the fused epilogue.  VEC (vecStore destinations, slab pitch and

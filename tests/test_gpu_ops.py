@@ -336,6 +336,49 @@ def test_conv_halo_kernel(gpu, case):
         L.xm_debug_force_conv_halo(old)
 
 
+STEM_CASES = [  # H, W, N, K, FH, FW, stride, pad
+    (512, 60, 2, 96, 7, 7, 2, 1),             # the student's conv1 on short spectrograms (254 x 28 outputs)
+    (512, 42, 3, 96, 7, 7, (2, 2), [1, 1, 1, 2]),   # tiles that straddle columns AND samples, ragged last tile
+    (256, 20, 2, 64, 5, 5, 1, 2),             # unit stride, fewer filters than the 96-row tile, fewer taps than 8 x 7
+    (504, 31, 2, 96, 8, 6, (2, 1), [2, 2, 1, 1]),   # 8 filter rows, stride 2 x 1, bottom padding read from zero rows
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_conv_stem_kernel(gpu, case):
+    """single-channel stem (conv_stem_kernel: persistent blocks, filter bank resident in LDS, source columns staged as
+    a patch, stores draining under the next tile's MFMAs) against the oracle and against the implicit-GEMM kernel it
+    replaces, incl. the batch moments from its epilogue; the profiler hook proves which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, N, K, FH, FW, stride, pad = case
+    rng = np.random.default_rng(H + 3 * W + K + FH)
+    x, f, b = rnd(rng, H, W, 1, N), rnd(rng, FH, FW, 1, K), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, stride=stride, pad=pad, acc64=True)
+    assert (y_ref.shape[0] * y_ref.shape[1]) % 4 == 0
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+    old = L.xm_debug_force_conv_stem(1)
+    try:
+        y, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad))
+        assert any("stem" in n for n in names), names
+        close(vl.to_numpy(y), y_ref, what="stem fwd")
+        mo = vl.mat_empty(K, 2, device=xd.device)
+        ym, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad, moments_out=mo))
+        assert any("stem" in n for n in names), names
+        _, m_ref = O.vl_nnbnorm(y_ref, O.F(np.ones(K)), O.F(np.zeros(K)), acc64=True)
+        close(vl.to_numpy(ym), y_ref, what="stem fwd + moments")
+        m = vl.to_numpy(mo)
+        close(m[:, 0], m_ref[:, 0], what="stem mean")
+        assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4
+        L.xm_debug_force_conv_stem(0)
+        y0, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad))
+        assert not any("stem" in n for n in names), names
+        d = np.abs(vl.to_numpy(y) - vl.to_numpy(y0)).max()
+        assert d <= 2e-5 * max(1.0, float(np.abs(y_ref).max())), d
+    finally:
+        L.xm_debug_force_conv_stem(old)
+
+
 @pytest.mark.parametrize("N,variant", [(3, 1), (3, 3), (16, 3), (16, 1)])
 def test_conv_halo_strided_dgrad(gpu, N, variant):
     """dgrad of a 5 x 5 / stride-2 convolution (the student's conv2): four stride-parity classes with 3x3, 3x2, 2x3 and
