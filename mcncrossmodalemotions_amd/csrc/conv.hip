@@ -1281,7 +1281,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     if (rc) return rc;
     }
     if (stat_ncg > 0) {
-      const int S = std::max(1, std::min(64, stat_ncg / 256));
+      const int S = std::max(1, std::min(64, stat_ncg / 768));   // one launch up to ~1500 partial rows per channel
       hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((g.K + 31) / 32, S), dim3(256), 0, st, statp, moments_out,
                          statp2, g.K, stat_ncg, S, (double)a.NP, eps);
       XM_LAUNCH_CHECK();

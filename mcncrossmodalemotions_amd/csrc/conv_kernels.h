@@ -1239,10 +1239,13 @@ conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
     sA[idx] = (m < a.M && u < a.nU && v < a.nV) ? a.A[(size_t)m * a.lda + u + a.nU * v] : 0.f;
   }
 
-  // block b walks tiles b, b + grid, b + 2 grid, ...: at any moment the chip writes one window of consecutive tiles
-  // (XCD-contiguous ranges -- neighbouring tiles share 5 of their 7 source columns -- measured 2-3 % slower: the 20 MB
-  // input is served by the L2s / MALL either way, the 462 MB of stores prefer the single window)
-  const int tbase = 0, tstep = gridDim.x, tend = ntiles;
+  // XCD-contiguous tile ranges: XCD x (blocks b % 8 == x) walks tiles [x * per, (x + 1) * per).  With the plain order
+  // (block b: tiles b, b + grid, ...) every output row is written in 512-byte pieces that alternate between the eight
+  // L2s: tools/store_mfma_probe.hip measures 142 us for this tile shape and output layout ([sample][row][pixel]) against
+  // 117 us with contiguous ranges (MFMAs alone: 114) -- the stores only hide under the MFMAs when each L2 writes runs
+  // of consecutive tiles.  (Neighbouring tiles also share 5 of their 7 source columns through the XCD's L2.)
+  const int per = (ntiles + 7) >> 3, tbase = (blockIdx.x & 7) * per, tstep = gridDim.x >> 3;
+  const int tend = min(per, ntiles - tbase);
   const int PIJ = (int)a.divPIJ.d, PI = (int)a.divPI.d;
   float *const sW = sP + wave * WPATCH;   // this wave's patch
 
@@ -1302,7 +1305,7 @@ conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
       *reinterpret_cast<f32x4 *>(sW + ldst[it]) = ldz[it] ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[it];
   };
 
-  int q = blockIdx.x;
+  int q = blockIdx.x >> 3;
   __syncthreads();                       // zero fill and filter bank are complete
   const f32x4 *pa = reinterpret_cast<const f32x4 *>(sA) + half * 32 + l31;
   float rbias[TM][4];   // bias of the rows this lane stores after the epilogue's transpose
@@ -1386,9 +1389,9 @@ conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          f32x4 v[4];
 #pragma unroll
           for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2)) * kStemTP] = acc[i][0][r];
-          f32x4 v[4];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4 *>(tr + 8 * g4 * kStemTP);
 #pragma unroll
