@@ -46,6 +46,7 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the prev
 | `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
 | `{R}/bench_distill_torch_1rank.json`, `bench_distill_capi_late_init.json` | the same single-rank run through `torch.distributed` ({tor1['value']} pairs/s), and with the library's communicator created AFTER the networks (`XM_PS_LATE=1`: {late['value']} pairs/s -- the call-order trap of `include/xmodal.h`) |
 | `{R}/phase_marks.txt` | `XM_BENCH_MARKS=1`: timing events on the main stream at the phase boundaries of the student step (forward / backward / join / update / gap to the next step) for the default line and its one-stream / no-side-stream / no-teacher-overlap variants |
+| `{R}/stem_bench.txt` | the student's conv1 through `conv_stem_kernel` and through the implicit-GEMM kernel, with / without batch moments; `tools/store_mfma_probe.hip`: stores / MFMAs / both for the same tile shape, three output layouts, two tile orders (DESIGN.md 2.1e) |
 | `{R}/schedule_experiments.txt` | A/B lines behind DESIGN.md 2.3b: teacher pass over 64 / 128 / 256 faces, `--teacher-gate`, wgrad deferred behind dgrad, stream priorities, and every round-3 kernel change switched off by its environment variable |
 | `{R}/halo_bench.txt`, `stats_bench.txt`, `bnbwd_bench.txt` | `tools/halo_bench.py` (halo-patch variants vs the best implicit-GEMM configuration, 32 / 64 / 256 samples), `tools/stats_bench.py` (conv with / without fused batch moments), `tools/bnbwd_bench.py` (bnorm backward chains) |
 | `{R}/kernel_stats_senet50_b256.txt` | rocprofv3 per-kernel summary of north_star's configuration (SE-ResNet50 teacher, 256 pairs, serial mode) |
@@ -92,7 +93,8 @@ Round 2 -> round 3 on the default line: 3812 -> {d['value']} pairs/s; student ba
 moments from the convolution epilogue (no second pass over the conv output; +0.9 % / +3.5 % at 64); the FC-shaped dgrad
 filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32);
 the SE tail of the frozen teachers fused algebraically (2.2d: config 3 11044 -> {te['value']} img/s, every SE-ResNet50 line); the hybrid
-schedule for partly filled last rounds (+1 % on the teacher and batch-256 lines).
+schedule for partly filled last rounds (within +-1 % in this collection's A/B lines); the persistent single-channel stem kernel for the
+student's conv1 (2.1e, `stem_bench.txt`: conv1 + batch moments 307 -> 204 us at 32 spectrograms, 566 -> 340 us at 64).
 What did NOT move the step is in `schedule_experiments.txt`: the step is work-conserving (serial sum 9.2 ms -> {d['ms_per_step']} ms overlapped),
 its main stream never waits (`phase_marks.txt`), and only work removed from the main stream shows up one to one.
 
