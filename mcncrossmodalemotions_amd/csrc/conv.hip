@@ -403,7 +403,8 @@ static const int kCfgOcc[kNumBaseCfg] = {2, 2, 2, 3, 4, 3, 4};
 static int hybrid_plan(const ConvGemmArgs &a, int ci, int *full_out) {
   static const bool off = getenv("XM_NO_HYBRID") != nullptr;
   *full_out = 0;
-  if (off || is_dma_cfg(ci) || a.statPart || g_force_splits > 0) return 1;
+  if (off || is_dma_cfg(ci) || g_force_splits > 0) return 1;
+  if (a.statPart && (!a.vecStore || a.relu || a.resid)) return 1;   // conv_splitk_epilogue_stats_kernel's case only
   const int tiles = a.nbm * a.nbn, slots = 256 * kCfgOcc[ci];
   if (tiles <= slots || a.nkt < 16) return 1;
   int full = tiles / slots * slots;
@@ -484,7 +485,13 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
     const int np = a.NP - a.hyP0;                       // pixels the slabs cover
     const bool vec = a.vecStore && (np & 3) == 0 && (a.hyP0 & 3) == 0 && (a.NPs & 3) == 0 && ((uintptr_t)a.slab & 15) == 0;
     const size_t n = (size_t)a.M * (vec ? np / 4 : np);
-    if (vec)
+    if (hyS > 1 && a.statPart) {
+      // the full rounds left their partial sums per pixel tile; the remainder's come from the combine kernel
+      const int cols = np / 4, chunks = (cols + 255) / 256, statBase = a.hyFull / a.nbm;
+      if (!vec) return fail(XM_EINVAL, "vl_nnconv: hybrid schedule with statistics needs vector stores");
+      hipLaunchKernelGGL(conv_splitk_epilogue_stats_kernel, dim3(chunks, a.M), dim3(256), 0, st, a, z, cols, statBase);
+      a.statNcg = statBase + chunks;
+    } else if (vec)
       hipLaunchKernelGGL(conv_splitk_epilogue_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                          a, z, make_fastdiv((uint32_t)(np / 4)));
     else
@@ -1229,7 +1236,9 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
         aa.statPart = statp;
         aa.statNcg = stat_ncg;
       }
-      return launch_gemm(aa, mode, ci, sp, slab, st);
+      const int rc_ = launch_gemm(aa, mode, ci, sp, slab, st);
+      if (aa.statPart) stat_ncg = aa.statNcg;     // (hybrid schedule: full pixel tiles + the combine kernel's chunks)
+      return rc_;
     };
     TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);

@@ -1497,6 +1497,45 @@ conv_splitk_epilogue_kernel(const ConvGemmArgs a, int splits, FastDiv divCols) {
   }
 }
 
+// The same combine for the remainder of a HYBRID launch that carries batch statistics (a.statPart; vector stores, no
+// ReLU / residual): grid (ceil(cols / 256), M) -- a block owns 256 pixel quads of ONE row, so that it can leave the
+// row's {sum, sum of squares} over its quads as one more partial entry: statPart[statBase + blockIdx.x][row].
+__global__ void __launch_bounds__(256)
+conv_splitk_epilogue_stats_kernel(const ConvGemmArgs a, int splits, int cols, int statBase) {
+  __shared__ float red[2][4];
+  const int m = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < cols) {
+    const int pr = c * 4, p = pr + a.hyP0;
+    const uint32_t n = xm_div((uint32_t)p, a.divPIJ);
+    const uint32_t q = (uint32_t)p - n * a.divPIJ.d;
+    const uint32_t jj = xm_div(q, a.divPI);
+    const uint32_t ii = q - jj * a.divPI.d;
+    const uint32_t mc = xm_div((uint32_t)m, a.divMU);
+    const int off = (a.oh0 + (int)ii * a.osy) + a.OH * (a.ow0 + (int)jj * a.osx) + (int)n * a.oSampleStride +
+                    (int)mc * a.oChanStride + (m - (int)mc * (int)a.divMU.d) * a.oUStride;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(a.slab + ((size_t)z * a.M + m) * a.NPs + pr);
+    // same operand order as conv_gemm_epilogue: acc * scale + (bias * scale + shift)
+    float rmul = 1.f, radd = 0.f;
+    if (a.scale) rmul = a.scale[m], radd = a.shift[m];
+    if (a.bias) radd += a.bias[m] * rmul;
+    v = v * rmul + radd;
+    if (a.gate) v *= a.gate[m + (int)n * a.gateStride];
+    s1 = (v.x + v.y) + (v.z + v.w);
+    s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    *reinterpret_cast<f32x4 *>(a.Y + off) = v;
+  }
+  s1 = xm_wave_sum(s1);
+  s2 = xm_wave_sum(s2);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[0][wv] = s1, red[1][wv] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *reinterpret_cast<float2 *>(a.statPart + ((size_t)(statBase + blockIdx.x) * a.M + m) * 2) =
+        make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+}
+
 // ------------------------------------------------------------------------------------------
 // wgrad:  dF[k][r] = sum_p dY[k][p] * G(p, r)      (p = flat output pixel (ho, wo, n))
 // MFMA rows = output channel k, MFMA cols = tap r (contiguous in dF), reduction = pixels.

@@ -469,6 +469,7 @@ def test_conv_hybrid_schedule(gpu, geom):
     kw = dict(scale=vl.from_numpy(sc.reshape(K, 1)), shift=vl.from_numpy(sh.reshape(K, 1)), residual=vl.from_numpy(res), relu=True)
     dzdy = rnd(rng, *y_ref.shape)
     dx_ref, _, _ = O.vl_nnconv(x, f, b, dzdy, pad=pad, acc64=True, no_der_filters=True)
+    _, m_ref = O.vl_nnbnorm(y_ref, O.F(np.ones(K)), O.F(np.zeros(K)), acc64=True)
     old = L.xm_debug_force_conv_halo(0)
     try:
         for cfg in range(7):
@@ -477,6 +478,13 @@ def test_conv_hybrid_schedule(gpu, geom):
             close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=pad, **kw)), ref2, what="hybrid cfg %d, fused epilogue" % cfg)
             dx, _, _ = vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), pad=pad, no_der_filters=True)
             close(vl.to_numpy(dx), dx_ref, what="hybrid cfg %d dgrad" % cfg)
+            # batch moments: per-tile partial sums from the full rounds + the combine kernel's chunks for the remainder
+            mo = vl.mat_empty(K, 2, device=xd.device)
+            ym = vl.vl_nnconv(xd, fd, bd, pad=pad, moments_out=mo)
+            close(vl.to_numpy(ym), y_ref, what="hybrid cfg %d + moments" % cfg)
+            m = vl.to_numpy(mo)
+            close(m[:, 0], m_ref[:, 0], what="hybrid cfg %d mean" % cfg)
+            assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4, cfg
     finally:
         L.xm_debug_force_conv_cfg(-1)
         L.xm_debug_force_conv_halo(old)
