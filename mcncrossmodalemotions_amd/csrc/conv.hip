@@ -1034,12 +1034,73 @@ fc_skinny_kernel(const float *__restrict__ x, const float *__restrict__ f, const
     y[(p - n * HW) + (size_t)HW * (m + (size_t)M * n)] = v;
   }
 }
+// The same for FOUR output rows and a chunk of 16 pixels per block (H*W == 1, 16-byte loads): a block of the one-row
+// kernel reads its 32 pixels' whole channel runs, i.e. the input is read M times from the L2s (512 MB for the student's
+// fc7 at 32 clips: 22 us); four rows per block share every load.  64 accumulators per lane (row r, pixel j -> 16 r + j),
+// the transposing butterfly over all six lane bits leaves value i in lane i, the waves' partials meet in LDS.
+template <int ACT>
+__global__ void __launch_bounds__(256)
+fc_skinny4_kernel(const float *__restrict__ x, const float *__restrict__ f, const float *__restrict__ b,
+                  float *__restrict__ y, int K, int M, int NP, int chunks, FastDiv divChunks,
+                  const float *__restrict__ scale, const float *__restrict__ shift) {
+  __shared__ float red[4][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int mg = (int)xm_div(blockIdx.x, divChunks);
+  const int p0 = ((int)blockIdx.x - mg * chunks) * 16, m0 = 4 * mg;
+  int xb[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xb[j] = K * min(p0 + j, NP - 1);
+  float acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+  const float *fr = f + (size_t)K * m0;
+  for (int k = (wv * 64 + lane) * 4; k < K; k += nw * 256) {
+    f32x4 w[4], v[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4 *>(fr + (size_t)K * r + k);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4 *>(x + xb[j] + k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(v[j]));   // pins the uses behind all the loads (see fc_skinny_kernel)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        acc[16 * r + j] = fmaf(w[r].w, v[j].w, fmaf(w[r].z, v[j].z, fmaf(w[r].y, v[j].y, fmaf(w[r].x, v[j].x, acc[16 * r + j]))));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int o = 32 >> s, h = 32 >> s;
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const float lo = acc[i] + __shfl_xor(acc[i], o, 64);
+      const float hi = acc[i + h] + __shfl_xor(acc[i + h], o, 64);
+      acc[i] = up ? hi : lo;
+    }
+  }
+  red[wv][lane] = acc[0];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = red[0][threadIdx.x];
+    for (int w = 1; w < nw; ++w) v += red[w][threadIdx.x];
+    const int m = m0 + (int)(threadIdx.x >> 4), p = p0 + (int)(threadIdx.x & 15);
+    if (b) v += b[m];
+    if (scale) v = v * scale[m] + shift[m];
+    if (ACT == 1) v = fmaxf(v, 0.f);
+    if (ACT == 2) v = 1.f / (1.f + expf(-v));
+    if (p < NP) y[m + (size_t)M * p] = v;
+  }
+}
 static bool fc_skinny_ok(const Geo &g) {
   static const bool off = getenv("XM_NO_SKINNY") != nullptr;
   if (off || g.FH != 1 || g.FW != 1 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.G != 1) return false;
   if (g.pt | g.pb | g.pl | g.pr) return false;
   const long long NP = (long long)g.Ho * g.Wo * g.N;
-  if (!(g.K <= 16 || NP <= 128)) return false;
+  const bool rows4 = g.H * g.W == 1 && (g.C & 3) == 0 && (g.K & 3) == 0;   // fc_skinny4_kernel's geometry
+  if (!(g.K <= 16 || NP <= (rows4 ? 512 : 128))) return false;
   return (long long)g.K * ((NP + 31) / 32) <= 65535 && (long long)g.H * g.W * g.C * g.N < (1ll << 31);
 }
 static int fc_skinny_forward(const float *x, const float *f, const float *b, float *y, const Geo &g, int act,
@@ -1048,6 +1109,20 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
   const bool vec = HW == 1 && (g.C & 3) == 0 && (((uintptr_t)x | (uintptr_t)f) & 15) == 0;
   const int units = vec ? g.C / 4 : g.C;   // k positions handed out per lane step
   const int nw = std::max(1, std::min(4, (units + 63) / 64));
+  static const bool no4 = getenv("XM_NO_SKINNY4") != nullptr;
+  if (vec && (g.K & 3) == 0 && g.K >= 16 && !no4) {
+    const int ch = (NP + 15) / 16;
+    dim3 grid4((unsigned)(g.K / 4 * ch)), block4(64 * nw);
+    FastDiv dc4 = make_fastdiv((uint32_t)ch);
+#define XM_FC4_LAUNCH(A) \
+  hipLaunchKernelGGL((fc_skinny4_kernel<A>), grid4, block4, 0, st, x, f, b, y, g.C, g.K, NP, ch, dc4, scale, shift)
+    if (act == 2) XM_FC4_LAUNCH(2);
+    else if (act == 1) XM_FC4_LAUNCH(1);
+    else XM_FC4_LAUNCH(0);
+#undef XM_FC4_LAUNCH
+    XM_LAUNCH_CHECK();
+    return XM_OK;
+  }
   dim3 grid(g.K * chunks), block(64 * nw);
   FastDiv dc = make_fastdiv((uint32_t)chunks), dh = make_fastdiv((uint32_t)HW);
 #define XM_FC_LAUNCH(A, V) \

@@ -73,7 +73,9 @@ def test_conv_forward_backward(gpu, case):
 # (H, W, C, N, K, activation): 1x1 filters over few output values -> fc_skinny_kernel (SE gates, classifier, fc8)
 SKINNY_CASES = [(1, 1, 2048, 32, 128, "relu"), (1, 1, 128, 32, 2048, "sigmoid"), (1, 1, 2048, 32, 8, None),
                 (1, 8, 1024, 32, 8, None), (1, 1, 77, 5, 3, "relu"), (2, 3, 40, 7, 5, "sigmoid"),
-                (1, 1, 16, 128, 256, "sigmoid"), (1, 1, 300, 33, 9, None)]
+                (1, 1, 16, 128, 256, "sigmoid"), (1, 1, 300, 33, 9, None),
+                # four rows per block (fc_skinny4_kernel): the student's fc7, SE gates at 256 faces, a ragged pixel chunk
+                (1, 1, 4096, 32, 1024, None), (1, 1, 512, 256, 32, "relu"), (1, 1, 64, 300, 128, "sigmoid")]
 
 
 @pytest.mark.parametrize("case", SKINNY_CASES)
