@@ -1589,6 +1589,20 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         XM_LAUNCH_CHECK();
       }
       if (prepare_only) continue;
+      // FC-shaped layer over few pixels (the student's fc7, the SE gates of a trainable teacher): dX = W^T dY is the
+      // skinny forward product with the transposed filter bank as its filter
+      if (pure_t && !foldH && !accum && g.FH == 1 && g.sy == 1 && g.sx == 1 && (g.pt | g.pb | g.pl | g.pr) == 0 &&
+          g.H * g.W == 1 && (g.FC & 3) == 0 && g.N <= 512 && g_force_cfg < 0 && g_force_splits == 0) {
+        Geo gs = g;
+        gs.C = gs.FC = g.Kg;
+        gs.K = gs.Kg = g.FC;
+        gs.R = g.Kg;
+        if (fc_skinny_ok(gs)) {
+          int rc = fc_skinny_forward(dzdy, Ag, nullptr, dxo, gs, 0, st);
+          if (rc) return rc;
+          continue;
+        }
+      }
       ConvGemmArgs a{};
       a.A = Ag;
       a.lda = c.Rp;

@@ -43,6 +43,7 @@ CONV_CASES = [
     (9, 8, 24, 4, 9, 1, 24, 80, (1, 1), (0, 0, 0, 0), (1, 1)),     # fc6 shape, K % 16 == 0: dgrad operand = plain transpose
     (1, 1, 100, 5, 1, 1, 100, 96, (1, 1), (0, 0, 0, 0), (1, 1)),   # fc7 shape, K % 16 == 0 (transpose_filter_kernel)
     (6, 6, 72, 2, 1, 1, 72, 64, (2, 2), (0, 0, 0, 0), (1, 1)),     # 1x1 stride 2, transposed operand + untouched pixels
+    (1, 1, 512, 40, 1, 1, 512, 256, (1, 1), (0, 0, 0, 0), (1, 1)),  # fc7-like: forward AND dgrad through fc_skinny4_kernel
 ]
 
 
