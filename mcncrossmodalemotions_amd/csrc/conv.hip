@@ -195,29 +195,30 @@ bias_grad_finalize_kernel(const double *__restrict__ part, float *__restrict__ d
 
 // batch moments from the convolution epilogue's partial sums (ConvGemmArgs::statPart, [pixel tile][row] pairs of fp32
 // {sum, sum of squares} over <= 256 values each): fp64 accumulation over the pixel tiles in a fixed order.
-// mom = [mean, sqrt(var + eps)] (M x 2).  Block = 32 channels x 8 tile lanes (a wave reads two runs of 32 consecutive
-// pairs); grid (ceil(M / 32), S): S > 1 splits the tiles, the partial fp64 sums go to part2[s][M][2] and
-// conv_stats_finalize2_kernel adds them.
+// mom = [mean, sqrt(var + eps)] (M x 2).  Block = 8 channels x 32 tile lanes (a wave reads eight runs of 8 consecutive
+// pairs): with 32 channels per block a 96-channel layer ran on THREE blocks whose lanes each walked ncg / 8 dependent
+// loads -- 21-34 us for 0.5-2 MB.  grid (ceil(M / 8), S): S > 1 splits the tiles, the partial fp64 sums go to
+// part2[s][M][2] and conv_stats_finalize2_kernel adds them.
 __global__ void __launch_bounds__(256)
 conv_stats_reduce_kernel(const float *__restrict__ part, float *__restrict__ mom, double *__restrict__ part2, int M,
                          int ncg, int S, double m, float eps) {
-  const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl, s = blockIdx.y;
+  const int cl = threadIdx.x & 7, j = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl, s = blockIdx.y;
   const int chunk = (ncg + S - 1) / S, g0 = s * chunk, g1 = min(ncg, g0 + chunk);
   double a = 0.0, b = 0.0;
   if (c < M)
-    for (int g = g0 + j; g < g1; g += 8) {
+    for (int g = g0 + j; g < g1; g += 32) {
       const float2 v = *reinterpret_cast<const float2 *>(part + ((size_t)g * M + c) * 2);
       a += (double)v.x;
       b += (double)v.y;
     }
-  __shared__ double ra[8][32], rb[8][32];
+  __shared__ double ra[32][8], rb[32][8];
   ra[j][cl] = a;
   rb[j][cl] = b;
   __syncthreads();
   if (j == 0 && c < M) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a += ra[k][cl], b += rb[k][cl];
+    for (int k = 1; k < 32; ++k) a += ra[k][cl], b += rb[k][cl];
     if (S == 1) {
       const double mu = a / m;
       double var = b / m - mu * mu;
@@ -1366,7 +1367,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     }
     if (stat_ncg > 0) {
       const int S = std::max(1, std::min(64, stat_ncg / 768));   // one launch up to ~1500 partial rows per channel
-      hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((g.K + 31) / 32, S), dim3(256), 0, st, statp, moments_out,
+      hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((g.K + 7) / 8, S), dim3(256), 0, st, statp, moments_out,
                          statp2, g.K, stat_ncg, S, (double)a.NP, eps);
       XM_LAUNCH_CHECK();
       if (S > 1) {
