@@ -1805,6 +1805,62 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
   return XM_OK;
 }
 
+// ---- filter derivative of the single-channel stem (conv_stem_wgrad_kernel) ------------------------------------------
+static bool stem_wgrad_ok(const Geo &g, const float *x, const float *dzdy) {
+  static const bool off = getenv("XM_NO_STEM") != nullptr || getenv("XM_NO_STEM_WGRAD") != nullptr;
+  if (off || g_force_cfg >= 0 || g_force_splits > 0) return false;
+  if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
+  if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.FH * g.FW > 64 || g.Kg > 96) return false;
+  if (g.sy != 1 && g.sy != 2) return false;
+  if (g.H % 4 != 0 || g.H > kStemHP - 8 || (((uintptr_t)x | (uintptr_t)dzdy) & 15) != 0) return false;
+  if ((g.Ho * g.Wo) % 4 != 0) return false;                                      // dY pixel quads stay inside a sample
+  if (g.pt > 4 || 4 * ((g.sy * (g.Ho - 1) - g.pt + 4 + 7) >> 2) + 3 >= kStemHP) return false;
+  if (g.Ho < 128) return false;
+  if (g_force_stem != 1 && (long long)g.Ho * g.Wo * g.N < 128 * 512) return false;
+  return true;
+}
+
+static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int grid, hipStream_t st) {
+  StemWgradArgs a{};
+  a.dY = dzdy;
+  a.X = x;
+  a.part = part;
+  a.M = g.Kg;
+  a.R = g.R;
+  a.nU = g.FH;
+  a.nV = g.FW;
+  a.PI = g.Ho;
+  a.PJ = g.Wo;
+  a.NP = g.Ho * g.Wo * g.N;
+  a.divPIJ = make_fastdiv((uint32_t)(g.Ho * g.Wo));
+  a.divPI = make_fastdiv((uint32_t)g.Ho);
+  a.gsx = g.sx;
+  a.gh0 = -g.pt;
+  a.gw0 = -g.pl;
+  a.LimH = g.H;
+  a.LimW = g.W;
+  a.xSampleStride = g.H * g.W;
+  a.dySampleStride = g.Ho * g.Wo * g.K;
+  a.dyChanStride = g.Ho * g.Wo;
+  static bool attr_done = false;
+  if (!attr_done) {
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmem));
+    attr_done = true;
+  }
+  const int ntiles = (a.NP + 127) / 128;
+  {
+    const double abytes = 4.0 * g.H * g.W * g.N + 4.0 * a.M * (double)a.NP + 4.0 * a.M * a.R;
+    ProfScope ps(6 * 100, 2.0 * a.M * (double)a.NP * a.R, st, abytes);
+    if (g.sy == 2) hipLaunchKernelGGL(conv_stem_wgrad_kernel<2>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
+    else hipLaunchKernelGGL(conv_stem_wgrad_kernel<1>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
+  }
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(a.M), dim3(1024), 0, st, part, dfo, grid, a.M, a.R);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
   // analytic fallback: minimal padded work (split-K supplies the parallelism)
   int fb = 0;
@@ -1825,13 +1881,24 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   const int nkt = (NP + kBK - 1) / kBK;
   const size_t slab = (size_t)g.Kg * g.R;
   const int max_splits = std::max(1, std::min(1024, nkt / 8));
+  const bool stem = stem_wgrad_ok(g, x, dzdy);
+  const int stem_grid_ = stem ? stem_grid(NP) : 0;
   WsCarver ws;
-  int rc = ws.init(WsCarver::need(slab * max_splits, 4), st);
+  int rc = ws.init(WsCarver::need(slab * max_splits, 4) + WsCarver::need((size_t)stem_grid_ * 96 * 64, 4), st);
   if (rc) return rc;
   float *part = ws.take<float>(slab * max_splits);
+  float *spart = stem ? ws.take<float>((size_t)stem_grid_ * 96 * 64) : nullptr;
   auto run = [&](int ci) { return wgrad_run(x, dzdy, dfo, g, ci, part, st); };
   TuneKey key{2, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
   int ci = tune_cfg(key, fb, st, run);
+  if (stem) {
+    // the single-channel stem's own wgrad kernel against the best generic configuration (measured once per shape)
+    auto run2 = [&](int h) { return h ? launch_stem_wgrad(x, dzdy, dfo, g, spart, stem_grid_, st) : run(ci); };
+    bool sok[2] = {true, true};
+    TuneKey skey{8, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    const int pick = g_force_stem >= 0 ? g_force_stem : tune_challengers(skey, st, run2, 2, sok, kHaloMargin);
+    return run2(pick);
+  }
   return run(ci);
 }
 
@@ -1986,8 +2053,8 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
              v == 0 ? "2, 2, 2, 2" : "3, 1, 1, 4", v == 2 ? 1024 : 512);
     return XM_OK;
   }
-  if (kind == 5) {
-    snprintf(buf, len, "conv_stem_kernel<2>");
+  if (kind == 5 || kind == 6) {
+    snprintf(buf, len, kind == 5 ? "conv_stem_kernel<2>" : "conv_stem_wgrad_kernel<2>");
     return XM_OK;
   }
   int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;

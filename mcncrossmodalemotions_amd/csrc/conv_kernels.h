@@ -1452,6 +1452,207 @@ conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
   }
 }
 
+// ---- filter derivative of the single-channel stem ------------------------------------------------------------------
+// dF[m][u, v] = sum over output pixels p of dY[m][p] * X[origin(p) + (u, v)]: 96 x 49 outputs, a reduction over 1.2 M
+// pixels (462 MB of dY at 32 spectrograms).  The generic wgrad kernel covers the 96 x 49 output with 128 x 64 of MFMA
+// tiles (1.74 x the work) and gathers the im2col operand tap by tap: 0.22 ms.  Here (MFMA rows = filters, columns =
+// taps padded to 64, reduction = pixels) every WAVE walks its own 32-pixel segments like conv_stem_kernel:
+//   * its source patch (the same wave-private LDS patch, same staging) gives the B operand: lane = tap, a pixel's tap
+//     is patch[base(pixel) + u + 96 v];
+//   * its dY tile (96 rows x 32 pixels) is loaded with 12 16-byte loads per lane (8 rows x 128 bytes per instruction),
+//     parked in a wave-private LDS tile and read back as the A operand with one 16-byte read per (row tile, 4 steps):
+//     MFMA step s multiplies pixels s (lanes 0-31) and 16 + s (lanes 32-63) of the segment;
+//   * 96 accumulator registers per wave hold its share of dF for the whole kernel; at the end the four waves add theirs
+//     in LDS in wave order, the block writes one partial [96][64] and conv_stem_wgrad_reduce_kernel adds the blocks in
+//     block order (deterministic, no atomics).
+struct StemWgradArgs {
+  const float *dY, *X;
+  float *part;                       // [grid][96][64]
+  int M, R, nU, nV;                  // filters, taps (nU * nV), filter rows / columns
+  int PI, PJ, NP;                    // output pixel grid
+  FastDiv divPIJ, divPI;
+  int gsx, gh0, gw0, LimH, LimW;     // as ConvGemmArgs (forward gather geometry)
+  int xSampleStride, dySampleStride, dyChanStride;
+};
+constexpr int kStemWgTP = 36;        // row pitch (floats) of a wave's dY tile: 32 pixels + 4
+constexpr int kStemWgWave = 2 * kStemNV * kStemHW + 4 + 96 * kStemWgTP;   // floats of LDS per wave: patch + dummy unit + dY tile
+constexpr int kStemWgSmem = (4 * kStemWgWave + 4) * 4;                    // bytes per block (+ a zero unit)
+
+template <int SY>
+__global__ void __launch_bounds__(256, 2)
+conv_stem_wgrad_kernel(const StemWgradArgs a, const int ntiles) {
+  constexpr int TM = 3, NV = kStemNV, HW = kStemHW, GRP = NV * HW, WPATCH = 2 * GRP + 4, TP = kStemWgTP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  for (int i = t; i < 4 * kStemWgWave / 4 + 1; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float *const sW = smem + wave * kStemWgWave;        // this wave's source patch
+  float *const tW = sW + WPATCH;                      // this wave's dY tile [96][TP]
+  const int per = (ntiles + 7) >> 3, tbase = (blockIdx.x & 7) * per, tstep = gridDim.x >> 3;
+  const int tend = min(per, ntiles - tbase);
+  const int PIJ = (int)a.divPIJ.d, PI = (int)a.divPI.d;
+
+  // ---- staging: source patch exactly as conv_stem_kernel, dY tile: lane -> (row lane / 8 + 8 k, pixel quad lane % 8)
+  const int lc = lane >> 3, lk = lane & 7;
+  f32x4 ld[3], dl[12];
+  int ldst[3];
+  bool ldz[3], dpin = false;
+  struct Cols {
+    int nF, jF, iF, nL, jL, iL;
+  };
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto wave_cols = [&](int tile) {
+    Cols c;
+    const uint32_t pF = min((uint32_t)tile * 128u + 32u * wv, (uint32_t)a.NP - 1u), pL = min(pF + 31u, (uint32_t)a.NP - 1u);
+    c.nF = (int)xm_div(pF, a.divPIJ);
+    uint32_t q = pF - (uint32_t)c.nF * PIJ;
+    c.jF = (int)xm_div(q, a.divPI);
+    c.iF = (int)q - c.jF * PI;
+    c.nL = (int)xm_div(pL, a.divPIJ);
+    q = pL - (uint32_t)c.nL * PIJ;
+    c.jL = (int)xm_div(q, a.divPI);
+    c.iL = (int)q - c.jL * PI;
+    return c;
+  };
+  auto issue_loads = [&](const Cols &c, int tile) {
+    const bool two = c.nF != c.nL || c.jF != c.jL;
+    const int hi0 = two ? PI - 1 : c.iL;
+    const int lo4[2] = {(SY * c.iF + a.gh0 + 4) >> 2, (a.gh0 + 4) >> 2};
+    const int n0 = ((SY * hi0 + a.gh0 + 4 + 7) >> 2) - lo4[0] + 1;
+    const int n1 = two ? ((SY * c.iL + a.gh0 + 4 + 7) >> 2) - lo4[1] + 1 : 0;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int q = lk + 8 * it;
+      const int g = q >= n0 ? 1 : 0, u = q - (g ? n0 : 0);
+      const bool wr = lc < NV && q < n0 + n1;
+      const int n = g ? c.nL : c.nF, j = g ? c.jL : c.jF;
+      const int cc = a.gsx * j + a.gw0 + lc, r = 4 * (lo4[g] + u) - 4;
+      const bool in = wr && lc < a.nV && cc >= 0 && cc < a.LimW && r >= 0 && r < a.LimH;
+      ldst[it] = wr ? (g * NV + lc) * HW + 4 * u : 2 * GRP;
+      ldz[it] = !in;
+      ld[it] = *reinterpret_cast<const f32x4 *>(in ? a.X + (size_t)n * a.xSampleStride + (size_t)cc * a.LimH + r : a.X);
+    }
+    // dY: pixel quad of this lane (quads never straddle samples: PIJ % 4 == 0), rows lc + 8 k
+    const uint32_t pq = (uint32_t)tile * 128u + 32u * wv + 4u * lk;
+    int qq = c.iF + PI * c.jF + 4 * lk, n = c.nF;
+    if (qq >= PIJ) qq -= PIJ, ++n;
+    const float *row0 = a.dY + (size_t)n * a.dySampleStride + qq;
+    dpin = pq < (uint32_t)a.NP;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int m = lc + 8 * k;
+      // (rows / pixels that do not exist read dY[0] and are zeroed when the tile is WRITTEN: a select here would put
+      // the wait for the load in front of the MFMAs)
+      dl[k] = *reinterpret_cast<const f32x4 *>(dpin && m < a.M ? row0 + (size_t)m * a.dyChanStride : a.dY);
+    }
+  };
+  auto write_tiles = [&]() {
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+      *reinterpret_cast<f32x4 *>(sW + ldst[it]) = ldz[it] ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[it];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      *reinterpret_cast<f32x4 *>(tW + (lc + 8 * k) * TP + 4 * lk) = dpin && lc + 8 * k < a.M ? dl[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // this lane's two taps (column tiles jt = 0, 1): offset inside a patch column group, or invalid
+  int tapoff[2];
+  bool tapok[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int n = l31 + 32 * jt;
+    tapok[jt] = n < a.R;
+    const int v = tapok[jt] ? n / a.nU : 0, u = tapok[jt] ? n - v * a.nU : 0;
+    tapoff[jt] = u + HW * v;
+  }
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jt][r] = 0.f;
+
+  int q = blockIdx.x >> 3;
+  __syncthreads();                       // zero fill complete
+  Cols cur = wave_cols(tbase + min(q, max(tend, 1) - 1));
+  if (q < tend) {
+    issue_loads(cur, tbase + q);
+    write_tiles();
+  }
+  for (; q < tend; q += tstep) {
+    const int tile = tbase + q;
+    const bool more = q + tstep < tend;
+    const Cols nxt = wave_cols(more ? tile + tstep : tile);
+    issue_loads(nxt, more ? tile + tstep : tile);    // (the last tile is staged once more: no branch around the loads)
+    __builtin_amdgcn_sched_barrier(0);               // the loads stay in front of the MFMAs
+    // B operand: pixel 16 half + s of the segment sits in column group 0 until the column ends (w pixels), then in group 1
+    const int w = PI - cur.iF - 16 * half;           // steps s < w are in group 0
+    const int b0 = (cur.iF + 16 * half) * SY + a.gh0 + 4 - 4 * ((SY * cur.iF + a.gh0 + 4) >> 2);
+    const int b1 = GRP + (cur.iF + 16 * half - PI) * SY + a.gh0 + 4 - 4 * ((a.gh0 + 4) >> 2);
+    const float *tr = tW + l31 * TP + 16 * half;     // A operand: row 32 i + l31, pixels 16 half + 4 c .. + 3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(tr + 32 * i * TP + 4 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * c + e;
+        const float *px = sW + (s < w ? b0 : b1) + SY * s;
+        float bv[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          bv[jt] = px[tapoff[jt]];
+          bv[jt] = tapok[jt] ? bv[jt] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv[jt], acc[i][jt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);               // ... and the uses of the loads behind them
+    write_tiles();                                   // (LDS operations of a wave execute in order)
+    cur = nxt;
+  }
+  // the four waves add their accumulators in LDS in wave order; the block leaves one partial [96][64]
+  float *const sD = smem;                            // 96 x 64 floats (the tiles are dead)
+  for (int wq = 0; wq < 4; ++wq) {
+    __syncthreads();
+    if (wave == wq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float *d = sD + (32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * jt + l31;
+            *d = wq ? *d + acc[i][jt][r] : acc[i][jt][r];
+          }
+    }
+  }
+  __syncthreads();
+  float *out = a.part + (size_t)blockIdx.x * (96 * 64);
+  for (int i = t; i < 96 * 64 / 4; i += 256) reinterpret_cast<f32x4 *>(out)[i] = reinterpret_cast<const f32x4 *>(sD)[i];
+}
+
+// dF[r + R m] = sum over the blocks' partials in a fixed order; grid = M blocks of 64 taps x 16 block groups
+__global__ void __launch_bounds__(1024)
+conv_stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ df, int nblk, int M, int R) {
+  __shared__ float red[16][64];
+  const int r = threadIdx.x & 63, g = threadIdx.x >> 6, m = blockIdx.x;
+  float v = 0.f;
+  for (int b = g; b < nblk; b += 16) v += part[(size_t)b * (96 * 64) + m * 64 + r];
+  red[g][r] = v;
+  __syncthreads();
+  if (g == 0 && r < R) {
+    v = red[0][r];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += red[k][r];
+    df[r + (size_t)R * m] = v;
+  }
+}
+
 // combine split-K slabs in split order and apply the fused epilogue.  VEC (vecStore destinations, slab pitch and
 // pixel count multiples of 4): a thread owns 4 consecutive pixels of one row -- 16-byte slab loads, one 16-byte
 // store; otherwise one (m, p) per thread.  divCols = NP / 4 resp. NP.

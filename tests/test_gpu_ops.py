@@ -373,7 +373,18 @@ def test_conv_stem_kernel(gpu, case):
         m = vl.to_numpy(mo)
         close(m[:, 0], m_ref[:, 0], what="stem mean")
         assert np.abs(m[:, 1] / m_ref[:, 1] - 1).max() <= 1e-4
+        # filter derivative through conv_stem_wgrad_kernel (no input derivative: the stem is the first layer)
+        dzdy = rnd(rng, *y_ref.shape)
+        _, df_ref, _ = O.vl_nnconv(x, f, b, dzdy, stride=stride, pad=pad, acc64=True, no_der_data=True)
+        (_, df, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), stride=stride, pad=pad,
+                                                                  no_der_data=True))
+        assert any("stem_wgrad" in n for n in names), names
+        close(vl.to_numpy(df), df_ref, what="stem wgrad")
         L.xm_debug_force_conv_stem(0)
+        (_, df0, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, vl.from_numpy(dzdy), stride=stride, pad=pad,
+                                                                   no_der_data=True))
+        assert not any("stem" in n for n in names), names
+        close(vl.to_numpy(df0), df_ref, what="generic wgrad of the stem")
         y0, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=stride, pad=pad))
         assert not any("stem" in n for n in names), names
         d = np.abs(vl.to_numpy(y) - vl.to_numpy(y0)).max()

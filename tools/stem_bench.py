@@ -28,13 +28,15 @@ for W in (300,):
     f = (torch.randn((96, 1, 7, 7), device="cuda") * 0.05).permute(3, 2, 1, 0)
     b = vl.mat_empty(96, 1, device=x.device); b.fill_(0.1)
     mo = vl.mat_empty(96, 2, device=x.device)
+    dz = torch.randn((N, 96, (W + 2 - 7) // 2 + 1, 254), device="cuda").permute(3, 2, 1, 0)
     out_bytes = 96 * 254 * ((W + 2 - 7) // 2 + 1) * N * 4
     for force in (0, 1, 0, 1):
         L.xm_debug_force_conv_stem(force)
         t0 = t(lambda: vl.vl_nnconv(x, f, b, stride=2, pad=1))
         t1 = t(lambda: vl.vl_nnconv(x, f, b, stride=2, pad=1, moments_out=mo))
-        print("conv1 N=%d W=%d %-14s conv %.1f us (%.2f TB/s of output)   conv + moments %.1f us" %
-              (N, W, "stem kernel" if force else "implicit GEMM", t0, out_bytes / t0 / 1e6, t1))
+        t2 = t(lambda: vl.vl_nnconv(x, f, b, dz, stride=2, pad=1, no_der_data=True, no_der_biases=True))
+        print("conv1 N=%d W=%d %-14s conv %.1f us (%.2f TB/s of output)   conv + moments %.1f us   wgrad %.1f us" %
+              (N, W, "stem kernels" if force else "implicit GEMM", t0, out_bytes / t0 / 1e6, t1, t2))
     L.xm_debug_force_conv_stem(-1)
 
 if os.environ.get("XM_LIB_PATH", "").endswith("_cyc.so"):       # library built with -DXM_DEBUG_CYCLES: phase clocks
