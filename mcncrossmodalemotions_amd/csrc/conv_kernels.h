@@ -1204,7 +1204,7 @@ conv_halo_multi_kernel(const ConvGemmMulti m) {
 //     one and the start of the next) and stages the source rows under them itself: 7 source columns x <= 24 16-byte
 //     row units per column group into its own LDS patch (3 loads per lane, issued BEFORE the MFMAs of the current tile
 //     and written behind them: LDS operations of a wave execute in order, so the reads of the current patch are done).
-//     A lane's tap (u, v) is then at base + v * 96 + u, all immediates;
+//     A lane's tap (u, v) is then at base + v * 104 + u, all immediates;
 //   * waves therefore drift apart freely: one wave's epilogue and stores run under another wave's MFMAs (with a barrier
 //     per tile the four waves of a block -- and, measured, the two blocks of a CU -- stay in phase: 165 us);
 //   * the stores of a tile are plain stores; nothing waits on them until the patch loads issued AFTER them are needed,
@@ -1218,7 +1218,8 @@ conv_halo_multi_kernel(const ConvGemmMulti m) {
 #endif
 constexpr int kStemHP = 520;   // source columns of <= 512 rows (+ 4 rows of padding either side)
 constexpr int kStemNV = 7;     // filter columns; 8 filter rows (the 8th has zero weights) per column
-constexpr int kStemHW = 96;    // rows of a wave's patch per (column group, source column): 24 units of 16 bytes
+constexpr int kStemHW = 104;   // row pitch of a wave's patch per (column group, source column): 24 units of 16 bytes + 8 (104 = 40
+                               // mod 64: the 49 taps u + 104 v of a pixel fall into 49 different LDS banks -- conv_stem_wgrad_kernel reads one tap per lane)
 constexpr int kStemTP = 36;    // row pitch (floats) of the epilogue's transpose tile: 32 pixels + 4
 
 template <int SY>
@@ -1458,7 +1459,7 @@ conv_stem_kernel(const ConvGemmArgs a, const int ntiles) {
 // tiles (1.74 x the work) and gathers the im2col operand tap by tap: 0.22 ms.  Here (MFMA rows = filters, columns =
 // taps padded to 64, reduction = pixels) every WAVE walks its own 32-pixel segments like conv_stem_kernel:
 //   * its source patch (the same wave-private LDS patch, same staging) gives the B operand: lane = tap, a pixel's tap
-//     is patch[base(pixel) + u + 96 v];
+//     is patch[base(pixel) + u + 104 v];
 //   * its dY tile (96 rows x 32 pixels) is loaded with 12 16-byte loads per lane (8 rows x 128 bytes per instruction),
 //     parked in a wave-private LDS tile and read back as the A operand with one 16-byte read per (row tile, 4 steps):
 //     MFMA step s multiplies pixels s (lanes 0-31) and 16 + s (lanes 32-63) of the segment;
@@ -1556,12 +1557,10 @@ conv_stem_wgrad_kernel(const StemWgradArgs a, const int ntiles) {
 
   // this lane's two taps (column tiles jt = 0, 1): offset inside a patch column group, or invalid
   int tapoff[2];
-  bool tapok[2];
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) {
     const int n = l31 + 32 * jt;
-    tapok[jt] = n < a.R;
-    const int v = tapok[jt] ? n / a.nU : 0, u = tapok[jt] ? n - v * a.nU : 0;
+    const int v = n < a.R ? n / a.nU : 0, u = n < a.R ? n - v * a.nU : 0;
     tapoff[jt] = u + HW * v;
   }
   f32x16 acc[TM][2];
@@ -1601,10 +1600,7 @@ conv_stem_wgrad_kernel(const StemWgradArgs a, const int ntiles) {
         const float *px = sW + (s < w ? b0 : b1) + SY * s;
         float bv[2];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          bv[jt] = px[tapoff[jt]];
-          bv[jt] = tapok[jt] ? bv[jt] : 0.f;
-        }
+        for (int jt = 0; jt < 2; ++jt) bv[jt] = px[tapoff[jt]];   // (columns >= R accumulate finite garbage that is never stored)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
