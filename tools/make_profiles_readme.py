@@ -94,7 +94,8 @@ moments from the convolution epilogue (no second pass over the conv output; +0.9
 filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32);
 the SE tail of the frozen teachers fused algebraically (2.2d: config 3 11044 -> {te['value']} img/s, every SE-ResNet50 line); the hybrid
 schedule for partly filled last rounds (within +-1 % in this collection's A/B lines); the persistent single-channel stem kernel for the
-student's conv1 (2.1e, `stem_bench.txt`: conv1 + batch moments 307 -> 204 us at 32 spectrograms, 566 -> 340 us at 64).
+student's conv1 (2.1e, `stem_bench.txt`: conv1 + batch moments 298 -> 191 us at 32 spectrograms, its filter derivative 236 -> 167 us); four-row skinny
+fully-connected kernel for fc7 and the SE gates (forward and dgrad).
 What did NOT move the step is in `schedule_experiments.txt`: the step is work-conserving (serial sum 9.2 ms -> {d['ms_per_step']} ms overlapped),
 its main stream never waits (`phase_marks.txt`), and only work removed from the main stream shows up one to one.
 
