@@ -32,9 +32,9 @@ NS="--no-cpu-baseline --no-roofline --north-star 0"
 {
   for tb in 0 64 128 256; do echo -n "--teacher-batch $tb: "; $B $NS --teacher-batch $tb 2>/dev/null | tail -1 | cut -c60-112; done
   for g in "" loss conv5 conv3 conv2 bn1; do echo -n "--teacher-gate '$g': "; $B $NS --teacher-gate "$g" 2>/dev/null | tail -1 | cut -c60-112; done
-  for e in "XM_X=1" "XM_WGRAD_AFTER_DGRAD=1" "XM_SIDE_PRIO=0 XM_MAIN_PRIO=-1" "XM_NO_FUSED_STATS=1" "XM_NO_FUSED_BIASDER=1" "XM_NO_FAST_TRANSPOSE=1" "XM_NO_HALO=1" "XM_NO_HYBRID=1" "XM_NO_STEM=1"; do
+  for e in "XM_X=1" "XM_WGRAD_AFTER_DGRAD=1" "XM_SIDE_PRIO=0 XM_MAIN_PRIO=-1" "XM_NO_FUSED_STATS=1" "XM_NO_FUSED_BIASDER=1" "XM_NO_FAST_TRANSPOSE=1" "XM_NO_HALO=1" "XM_NO_HYBRID=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1" "XM_NO_SKINNY4=1"; do
     echo -n "$e: "; env $e $B $NS 2>/dev/null | tail -1 | cut -c60-112; done
-  for e in "XM_X=1" "XM_NO_HALO=1" "XM_NO_FUSED_STATS=1" "XM_NO_STEM=1"; do echo -n "student batch 64, $e: "; env $e $B $NS --workload student 2>/dev/null | tail -1 | cut -c50-100; done
+  for e in "XM_X=1" "XM_NO_HALO=1" "XM_NO_FUSED_STATS=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1"; do echo -n "student batch 64, $e: "; env $e $B $NS --workload student 2>/dev/null | tail -1 | cut -c50-100; done
   for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1"; do echo -n "config 3 (SE-ResNet50 fwd, 128), $e: "; env $e $B $NS --workload teacher 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done
   for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1"; do echo -n "north_star batch 256 (SE-ResNet50), $e: "; env $e $B $NS --teacher senet50 --per-gpu-batch 256 --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c60-112; done
 } > $O/schedule_experiments.txt
