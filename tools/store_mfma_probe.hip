@@ -10,7 +10,7 @@
 // What it showed (boxes of the pool differ by +-20 % in their store behaviour; compare lines of ONE run): in layout 0
 // the stores hide completely under the MFMAs (115 vs 114 us); in the real layout with the plain tile order they do not
 // (142-166 us), row alignment is irrelevant (layout 2 = layout 1), XCD-contiguous ranges recovered the loss on one box
-// (117 us) and not on another (162 us).
+// (117 us) and not on another (162 us); twice the run length per row (probe_run: 64 pixels per wave) gains 4-6 %.
 // Build + run:  hipcc --offload-arch=gfx950 -O3 tools/store_mfma_probe.hip -o /tmp/smp && /tmp/smp
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -100,6 +100,71 @@ static void run(const char *name, float *y, long long NP, int per_cu) {
          (double)kM * NP * 4 / ms / 1e6, 2.0 * 96 * 56 * (double)ntiles * kBN / ms / 1e9);
 }
 
+
+// Run-length variant: a wave owns PW = 32 or 64 consecutive pixels of every row (a 96 x 128 or 96 x 256 block tile), real
+// [sample][row][pixel] layout, XCD-contiguous ranges or plain order: does a longer run per row help the stores?
+template <int PW, int XCD>
+__global__ void __launch_bounds__(256) probe_run(float *y, long long NP, int ntiles, float a0, float b0, int mfma) {
+  extern __shared__ float lds[];
+  constexpr long long PIJ = 37592;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31, iq = l31 & 3;
+  if (a0 == 77.f) lds[t] = b0;
+  constexpr int NJ = PW / 32;
+  f32x16 acc[3][NJ];
+  const int per = (ntiles + 7) / 8, xb = (blockIdx.x & 7) * per, xe = min(ntiles, xb + per);
+  for (int tile = XCD ? xb + (int)(blockIdx.x >> 3) : (int)blockIdx.x; tile < (XCD ? xe : ntiles);
+       tile += XCD ? (int)(gridDim.x >> 3) : (int)gridDim.x) {
+    const float av = a0 + (float)(tile & 1023) * 1e-3f + lane * 1e-6f, bv = b0 + wave * 1e-3f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (mfma)
+#pragma unroll
+          for (int k = 0; k < kMfmaPerSub; ++k)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av + (float)(i + 3 * k), bv + (float)j, acc[i][j], 0, 0, 0);
+        else
+          acc[i][j][0] = av * (float)(i + j);
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int row = 32 * i + 8 * g4 + 4 * half + iq;
+          const long long p = (long long)tile * (4 * PW) + wave * PW + 32 * j + (l31 & ~3);
+          const long long n = p / PIJ, q = p - n * PIJ;
+          if (p + 3 < NP)
+            *reinterpret_cast<f32x4 *>(y + n * (kM * PIJ) + row * PIJ + q) =
+                f32x4{acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+        }
+  }
+}
+
+template <int PW, int XCD>
+static void run2(const char *name, float *y, long long NP, int mfma) {
+  const int ntiles = (int)((NP + 4 * PW - 1) / (4 * PW));
+  const size_t lds = (size_t)(160 * 1024 / 2 - 1024);
+  hipFuncSetAttribute((const void *)probe_run<PW, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe_run<PW, XCD>), dim3(512), dim3(256), lds, 0, y, NP, ntiles, 1.f, 1e-3f, mfma);
+  hipEventRecord(e0, 0);
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe_run<PW, XCD>), dim3(512), dim3(256), lds, 0, y, NP, ntiles, 1.f, 1e-3f, mfma);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  printf("%-44s pixels/wave %d %s  %6.1f us  store %5.0f GB/s\n", name, PW, XCD ? "XCD ranges" : "plain order", ms * 1e3,
+         (double)kM * NP * 4 / ms / 1e6);
+}
+
 int main() {
   const long long NP = 1202944;   // conv1 of the student at 32 spectrograms: 96 x (32 * 254 * 148) floats = 462 MB
   float *y;
@@ -116,6 +181,12 @@ int main() {
     run<2, 3>("stores only, real layout, XCD-contiguous tiles", y, NP, pc);
     run<0, 3>("84 MFMAs + stores, real layout, XCD-contiguous", y, NP, pc);
   }
+  run2<32, 1>("real layout, stores only", y, NP, 0);
+  run2<64, 1>("real layout, stores only", y, NP, 0);
+  run2<32, 1>("real layout, MFMAs + stores", y, NP, 1);
+  run2<64, 1>("real layout, MFMAs + stores", y, NP, 1);
+  run2<32, 0>("real layout, MFMAs + stores", y, NP, 1);
+  run2<64, 0>("real layout, MFMAs + stores", y, NP, 1);
   hipFree(y);
   return 0;
 }
