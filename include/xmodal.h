@@ -47,8 +47,8 @@ enum { XM_AGG_MAX = 0, XM_AGG_MEAN = 1 };
 enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
- * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated (additions never change the revision's meaning
- * for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
+ * 103 = + xm_nnpool_global_avg_backward_accum (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -156,6 +156,11 @@ int xm_nnpool_forward_argmax(const float *x, int H, int W, int C, int N, int ph,
 int xm_nnpool_backward_argmax(const unsigned char *argmax, int H, int W, int C, int N, int ph, int pw,
                               int sy, int sx, int pt, int pb, int pl, int pr, const float *dzdy,
                               float *dx_out, void *stream);
+/* Global average pooling (mcnExtraLayers dagnn.GlobalPooling, the SE squeeze) backward where X has a second consumer
+ * that already left its derivative (the SE excite: dagnn accumulates derivatives at forks): dx = accum + dzdy / (H W)
+ * in one pass; bit-identical to xm_nnpool_backward followed by the sum. */
+int xm_nnpool_global_avg_backward_accum(const float *dzdy, const float *accum, float *dx_out, int H, int W, int C, int N,
+                                        void *stream);
 
 /* ---- vl_nnbnorm  (matlab/vl_nnbnorm.m) -----------------------------------------------------
  * Y = vl_nnbnorm(X, G, B, 'epsilon', e [, 'moments', M]); M is C x 2 = [mean, sqrt(var+e)].

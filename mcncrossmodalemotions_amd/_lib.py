@@ -53,6 +53,7 @@ SIGNATURES = {
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],
     "xm_nnpool_forward_argmax": [c_fp] + [_i] * 12 + [c_fp, c_fp, _vp],
     "xm_nnpool_backward_argmax": [c_fp] + [_i] * 12 + [c_fp, c_fp, _vp],
+    "xm_nnpool_global_avg_backward_accum": [c_fp, c_fp, c_fp, _i, _i, _i, _i, _vp],
     "xm_nnbnorm_forward": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _vp],
     "xm_nnbnorm_forward_fused": [c_fp] + [_i] * 4 + [c_fp, c_fp, _f, c_fp, c_fp, c_fp, _i, _vp],
     "xm_nnbnorm_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp,

@@ -1268,6 +1268,27 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
 
 using namespace xm;
 
+// Global average pooling (the SE squeeze) backward at a FORK: dx = accum + dzdy(plane) / (H W) -- the derivative the
+// other consumer of X (the SE excite) already left is added in the same pass instead of a broadcast pass + a sum pass.
+// Same two roundings as the separate passes (multiply, then add: no fused multiply-add).
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+pool_global_avg_bwd_accum_kernel(const float *__restrict__ dy, const float *__restrict__ accum, float *__restrict__ dx,
+                                 size_t n, xm::FastDiv divHW, float scale) {
+#pragma clang fp contract(off)   // round(accum + round(dy * scale)): the two roundings of the separate passes
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (VEC) {
+    if (idx * 4 >= n) return;
+    const float t = dy[xm_div((uint32_t)(idx * 4), divHW)] * scale;
+    const float4 a = reinterpret_cast<const float4 *>(accum)[idx];
+    reinterpret_cast<float4 *>(dx)[idx] = make_float4(a.x + t, a.y + t, a.z + t, a.w + t);
+  } else {
+    if (idx >= n) return;
+    const float t = dy[xm_div((uint32_t)idx, divHW)] * scale;
+    dx[idx] = accum[idx] + t;
+  }
+}
+
 extern "C" {
 
 int xm_nnbnorm_forward_fused(const float *x, int H, int W, int C, int N, const float *g,
@@ -1326,6 +1347,25 @@ int xm_nnpool_forward_argmax(const float *x, int H, int W, int C, int N, int ph,
   if (!y || !argmax) return fail(XM_EINVAL, "vl_nnpool: NULL tensor");
   return pool_forward(x, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX, y, argmax,
                       (hipStream_t)stream);
+}
+
+int xm_nnpool_global_avg_backward_accum(const float *dzdy, const float *accum, float *dx_out, int H, int W, int C, int N,
+                                        void *stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return xm::fail(XM_EINVAL, "vl_nnpool: empty tensor");
+  if (!dzdy || !accum || !dx_out) return xm::fail(XM_EINVAL, "vl_nnpool: NULL tensor");
+  if (xm::too_big(H, W, C, N)) return xm::fail(XM_ETOOBIG, "vl_nnpool: tensor with >= 2^31 elements");
+  const size_t n = (size_t)H * W * C * N;
+  const xm::FastDiv d = xm::make_fastdiv((uint32_t)(H * W));
+  const float scale = 1.0f / (float)(H * W);   // correctly rounded, as pool_bwd_kernel's
+  const bool vec = (H * W) % 4 == 0 && ((((uintptr_t)accum | (uintptr_t)dx_out)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(pool_global_avg_bwd_accum_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dzdy, accum, dx_out, n, d, scale);
+  else
+    hipLaunchKernelGGL(pool_global_avg_bwd_accum_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dzdy, accum, dx_out, n, d, scale);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
 }
 
 int xm_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int pw, int sy, int sx,

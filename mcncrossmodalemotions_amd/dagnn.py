@@ -459,6 +459,7 @@ class DagNN:
         self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
         self.wgradAfterDgrad = os.environ.get("XM_WGRAD_AFTER_DGRAD") is not None
         self.fuseBiasDer = os.environ.get("XM_NO_FUSED_BIASDER") is None   # conv dzdb = sum(dx) from the bnorm backward
+        self.fuseForkSums = os.environ.get("XM_NO_FORK_SUMS") is None   # global-avg backward adds the fork's other derivative
         self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
@@ -879,6 +880,14 @@ class _Step:
         elif isinstance(r.block, BatchNorm):
             dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r),
                                           dxsum_out=self._bias_der_slot(net))
+        elif isinstance(r.block, GlobalPooling) and r.block.method == "avg" and net.vars[r.inputs[0]].der is not None \
+                and net.fuseForkSums:
+            # fork: the other consumer of X (the SE excite) already left its derivative -> one pass instead of a
+            # broadcast pass + a sum pass over the widest tensors of the block
+            xin = net.vars[r.inputs[0]]
+            acc, xin.der = xin.der, None
+            dins, dpar = [vl.vl_nnpool(ins[0], [int(ins[0].shape[0]), int(ins[0].shape[1])], douts[0], method="avg",
+                                       dx_accum=acc)], []
         elif isinstance(r.block, Pooling):
             outs = [net.vars[v].value for v in r.outputs]
             dins, dpar = r.block.backward(ins, self._params(net), douts,

@@ -229,11 +229,13 @@ def conv_prepare_backward(x, f, stride=1, pad=0, dilate=1):
 _METHOD = {"max": 0, "avg": 1}
 
 
-def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, want_argmax=False):
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, want_argmax=False, dx_accum=None):
     """Y = VL_NNPOOL(X, POOL) / DX = VL_NNPOOL(X, POOL, DZDY).
 
     Extension for max pooling: `want_argmax=True` (forward) also returns the uint8 routing table
-    of first maxima; pass it back as `argmax=` (backward) to skip the recomputation from X."""
+    of first maxima; pass it back as `argmax=` (backward) to skip the recomputation from X.
+    Extension for global average pooling (POOL = the whole plane, the SE squeeze): `dx_accum` = the derivative another
+    consumer of X already left; the result is DX + dx_accum in one pass (xm_nnpool_global_avg_backward_accum)."""
     x = _chk(x, "X")
     if method not in _METHOD:
         raise ValueError("vl_nnpool: unknown METHOD '%s'" % method)
@@ -258,6 +260,12 @@ def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, wa
     if _shape4(dzdy) != [Ho, Wo, Cc, N]:
         raise ValueError("vl_nnpool: DZDY is %r, expected %r" % (tuple(dzdy.shape), (Ho, Wo, Cc, N)))
     dxo = mat_empty(H, W, Cc, N, device=x.device)
+    if dx_accum is not None:
+        if method != "avg" or (ph, pw) != (H, W) or (pt | pb | pl | pr) or _shape4(dx_accum) != [H, W, Cc, N]:
+            raise ValueError("vl_nnpool: dx_accum is built for global average pooling only")
+        _lib.check(L.xm_nnpool_global_avg_backward_accum(_ptr(dzdy), _ptr(_chk(dx_accum, "DX_ACCUM")), _ptr(dxo), H, W, Cc, N,
+                                                         _stream()))
+        return dxo
     if argmax is not None and method == "max":
         _lib.check(L.xm_nnpool_backward_argmax(C.c_void_p(argmax.data_ptr()), H, W, Cc, N, ph, pw, sy,
                                                sx, pt, pb, pl, pr, _ptr(dzdy), _ptr(dxo), _stream()))

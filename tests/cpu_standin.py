@@ -70,11 +70,12 @@ def vl_nnrelu(x, dzdy=None, leak=0.0):
     return _mat(O.vl_nnrelu(_np(x), _np(dzdy), leak=leak))
 
 
-def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, want_argmax=False):
+def vl_nnpool(x, pool, dzdy=None, stride=1, pad=0, method="max", argmax=None, want_argmax=False, dx_accum=None):
     if dzdy is None:
         y = _mat(O.vl_nnpool(_np(x), pool, stride=stride, pad=pad, method=method))
         return (y, None) if want_argmax else y
-    return _mat(O.vl_nnpool(_np(x), pool, _np(dzdy), stride=stride, pad=pad, method=method))
+    dx = O.vl_nnpool(_np(x), pool, _np(dzdy), stride=stride, pad=pad, method=method)
+    return _mat(dx if dx_accum is None else dx + _np(dx_accum))
 
 
 def sum2(a, b, relu=False):

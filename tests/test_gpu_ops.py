@@ -504,6 +504,24 @@ def test_conv_hybrid_schedule(gpu, geom):
         L.xm_debug_force_conv_halo(old)
 
 
+@pytest.mark.parametrize("shape", [(56, 56, 16, 3), (7, 7, 33, 5), (14, 14, 8, 2)])
+def test_global_avg_pool_backward_at_a_fork(gpu, shape):
+    """SE squeeze backward where X has a second consumer: dx = accum + dzdy / (H W) in one pass
+    (xm_nnpool_global_avg_backward_accum) is bit-identical to the broadcast pass followed by the sum pass."""
+    import torch
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N = shape
+    rng = np.random.default_rng(H + C)
+    x, acc, dz = rnd(rng, H, W, C, N), rnd(rng, H, W, C, N), rnd(rng, 1, 1, C, N)
+    xd, ad, dd = vl.from_numpy(x), vl.from_numpy(acc), vl.from_numpy(dz)
+    fused = vl.vl_nnpool(xd, [H, W], dd, method="avg", dx_accum=ad)
+    plain = vl.sum2(ad, vl.vl_nnpool(xd, [H, W], dd, method="avg"))
+    assert torch.equal(fused, plain)
+    close(vl.to_numpy(fused), acc + O.vl_nnpool(x, [H, W], dz, method="avg"), what="global avg backward + accum")
+    with pytest.raises(ValueError):
+        vl.vl_nnpool(xd, [2, 2], vl.from_numpy(rnd(rng, H // 2, W // 2, C, N)), stride=2, method="avg", dx_accum=ad)
+
+
 def test_conv_no_der_flags_and_errors(gpu):
     from mcncrossmodalemotions_amd import vl, _lib
     rng = np.random.default_rng(3)
