@@ -42,7 +42,9 @@ GFLOP = {"student_fwd_bwd_300": 16.633, "resnet50_fwd": 7.712, "senet50_fwd": 7.
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node.  Under torch.distributed.run (WORLD_SIZE set) it must equal the "
+                         "world size; called directly with N > 1 the script starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=0,
                     help="timed steps K (exactly K are timed).  0 = as many as fill --min-seconds, estimated from the "
                          "warm-up (the clocks of this part need ~0.3 s of sustained load to settle: a 0.2 s timed "
@@ -80,6 +82,10 @@ def parse():
                          "batch).  The reference decouples the two as well: buildImdb runs the teacher at batch 128 "
                          "(fetch_emovoxceleb_imdb.m:63), the student trains at 64 (run_distillation.m:75).  One pass "
                          "feeds teacher-batch / per-gpu-batch consecutive steps; every pair still gets its own face")
+    ap.add_argument("--teacher-chunk", type=int, default=0,
+                    help="distill: evaluate the frozen teacher in sample slices of this many faces, one after the other on "
+                         "its stream (samples are independent in test mode; a slice's activations stay in the 256 MB "
+                         "Infinity Cache between layers).  0 = the whole batch in one pass")
     ap.add_argument("--north-star", type=int, default=-1,
                     help="1: after the main measurement, time north_star's own configuration (SE-ResNet50 teacher + "
                          "VGGVox student, 256 pairs on this GPU) for a bounded number of steps in a child process and "
@@ -129,10 +135,38 @@ def host_info():
     return model
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per GPU, cnn_train_dag's
+    numel(opts.gpus) workers, run_distillation.m:71,77,179-181).  Refuses -- never runs fewer ranks than asked for --
+    when the node shows fewer than N devices, unless XM_DEBUG_DIST=gloo0 (functional run of the N-rank path on one GPU)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("XM_DEBUG_DIST") != "gloo0" and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to run fewer ranks than "
+                         "requested (XM_DEBUG_DIST=gloo0 runs all ranks on cuda:0 over gloo for a functional check)"
+                         % (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, dict(os.environ))
+
+
 def main():
     args = parse()
     if args.workload == "cpu-teacher":
         return cpu_teacher_line(args)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%s: the two must agree"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
     # main + wgrad + teacher streams + RCCL's: more than the default 4 hardware queues, see the package
     # __init__ (without this the stream overlap is serialised as soon as a process group exists)
@@ -174,28 +208,14 @@ def main():
     # backward phase 0.8 ms longer even when no collective was ever issued; moving xm_comm_init here removed it).
     if args.parserv == "auto":
         args.parserv = "torch" if shared_gpu else "rccl-capi"      # gloo debug runs have no RCCL communicator
-    parserv = train.ParameterServer(args.parserv)
-    if force_dist and os.environ.get("XM_DEBUG_DIST") in ("1", "3"):
-        parserv.force = True
-    if not os.environ.get("XM_PS_LATE"):
-        try:
-            parserv.start()
-            ok = 1
-        except Exception as e:   # noqa: BLE001 -- report, agree with the other ranks, fall back to torch.distributed
-            print("bench: rccl-capi ParameterServer failed to start (%s); using torch.distributed" % e, file=sys.stderr)
-            ok = 0
-        if world > 1 and args.parserv == "rccl-capi":
-            t = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
-        if not ok:
-            try:
-                parserv.stop()
-            except Exception:    # noqa: BLE001
-                pass
-            args.parserv = "torch"
-            parserv = train.ParameterServer("torch")
-            parserv.start()
+    force_ps = bool(force_dist and os.environ.get("XM_DEBUG_DIST") in ("1", "3"))
+    if os.environ.get("XM_PS_LATE"):         # experiment: communicator created AFTER the networks (the call-order trap)
+        parserv = train.ParameterServer(args.parserv)
+        parserv.force = force_ps
+    else:
+        # every worker ends up on the same backend: the library's communicator, or torch.distributed if any failed
+        parserv = train.ParameterServer.start_agreed(args.parserv, force=force_ps)
+        args.parserv = parserv.backend
     # ---- networks ------------------------------------------------------------------------
     teacher = student = None
     if wl in ("distill", "teacher", "joint"):
@@ -271,6 +291,18 @@ def main():
 
     set_serial(mode["serial"])
 
+    def teacher_logits(x):
+        """frozen teacher forward -> 1 x 1 x 8 x n logits (fetch_emovoxceleb_imdb.m:129-130), optionally in sample slices"""
+        n, ch = int(x.shape[3]), args.teacher_chunk
+        if not ch or ch >= n:
+            teacher.eval(["data", x])
+            return teacher.vars["prediction"].value
+        out = vl.mat_empty(1, 1, 8, n, device=x.device)
+        for a in range(0, n, ch):
+            teacher.eval(["data", x[..., a:a + ch]])
+            out[..., a:a + ch].copy_(teacher.vars["prediction"].value)
+        return out
+
     def step(it):
         if wl == "teacher":
             if mode["serial"]:
@@ -296,8 +328,7 @@ def main():
                              parserv, nb * world)
             return
         if wl == "distill" and (tstream is None or mode["serial"]):
-            teacher.eval(["data", faces if tmult == 1 else faces[..., :nb]])
-            tl = teacher.vars["prediction"].value      # 1 x 1 x 8 x nb teacher logits
+            tl = teacher_logits(faces if tmult == 1 else faces[..., :nb])      # 1 x 1 x 8 x nb teacher logits
             ml = vl.max_label(tl)                       # getBatchEmoVoxCeleb.m:32
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world)
@@ -322,8 +353,7 @@ def main():
                 else:
                     tstream.wait_stream(main)
                 with torch.cuda.stream(tstream):
-                    teacher.eval(["data", faces])
-                    tl_ = teacher.vars["prediction"].value
+                    tl_ = teacher_logits(faces)
                     ml_ = vl.max_label(tl_)
                     ev_ = torch.cuda.Event()
                     ev_.record(tstream)

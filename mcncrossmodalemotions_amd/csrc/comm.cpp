@@ -91,12 +91,6 @@ int xm_parserv_push(float *buf, size_t n, void *producer_stream) {
   if (int m = comm_missing("parserv push")) return m > 0 ? XM_OK : XM_EINVAL;
   if (n == 0) return XM_OK;
   if (!buf) return xm::fail(XM_EINVAL, "parserv: NULL buffer");
-  static const int dbg = getenv("XM_PS_DEBUG") ? atoi(getenv("XM_PS_DEBUG")) : 0;   // experiments only
-  if (dbg == 1) return XM_OK;                       // communicator exists, nothing is ever exchanged
-  if (dbg == 2) {                                   // the collective on the producer stream itself
-    XM_NCCL(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, (hipStream_t)producer_stream));
-    return XM_OK;
-  }
   if (!g_ps_stream) XM_HIP(hipStreamCreateWithFlags(&g_ps_stream, hipStreamNonBlocking));
   hipEvent_t e = ps_event();
   if (!e) return xm::fail(XM_EHIP, "parserv: event creation failed");

@@ -723,7 +723,7 @@ static std::map<TuneKey, int> g_tuned;
 // are then the same in every process, and shapes already in the table pay no timed launches on the caller's
 // stream.  Shapes that are not in the table are still measured once per process (and written back by
 // xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
-constexpr int XM_TUNE_REV = 5;   // 5: hybrid schedule (partly filled last round split along the reduction)
+constexpr int XM_TUNE_REV = 6;   // 6: launches with fused batch statistics are their own entries (mode + 4)
 static bool g_tune_loaded = false;
 static int g_tune_new = 0;  // entries measured in this process (not yet saved)
 
@@ -1221,7 +1221,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   static const bool no_fstats = getenv("XM_NO_FUSED_STATS") != nullptr;
   const bool want_stats = moments_out != nullptr && g.G == 1 && !no_fstats;
   // partial sums: one {sum, sum sq} pair per row and per pixel tile (>= 32 pixels), + 64 fp64 slabs for the reduction
-  const size_t statf = want_stats ? (size_t)2 * g.K * ((proto.NP + 31) / 32) : 0;
+  // (the persistent stem kernel leaves one row per block: stem_grid(NP) can exceed NP / 32 on small problems)
+  const size_t statf = want_stats ? (size_t)2 * g.K * std::max((proto.NP + 31) / 32, stem_grid(proto.NP)) : 0;
   const size_t stat2 = want_stats ? (size_t)2 * g.K * 64 : 0;
   WsCarver ws;
   int rc = ws.init(WsCarver::need(need_pad ? (size_t)g.K * Rp : 0, 4) + WsCarver::need(slabf, 4) +
@@ -1316,7 +1317,10 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       if (aa.statPart) stat_ncg = aa.statNcg;     // (hybrid schedule: full pixel tiles + the combine kernel's chunks)
       return rc_;
     };
-    TuneKey key{0, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    // the launch with fused batch statistics is its own entry: it excludes the LDS-DMA configurations and carries a
+    // longer epilogue, so whichever variant reached a shape first must not fix the choice for the other
+    const int tmode = mode + (stats_ok ? 4 : 0);
+    TuneKey key{0, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
     int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
     if (stem_ok(a, g, x, f)) {
       // the single-channel stem kernel against the best implicit-GEMM configuration (measured once per shape)
@@ -1332,7 +1336,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
         return launch_stem(aa, f, g.R, st);
       };
       bool sok[2] = {true, true};
-      TuneKey skey{7, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      TuneKey skey{7, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
       const int pick = g_force_stem >= 0 ? g_force_stem : tune_challengers(skey, st, run3, 2, sok, kHaloMargin);
       rc = run3(pick);
       if (rc) return rc;
@@ -1354,7 +1358,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
         }
         return launch_halo(aa, h - 1, slab, st);
       };
-      TuneKey hkey{4, a.M, a.NP, Rp, mode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      TuneKey hkey{4, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
       int pick;
       if (g_force_halo == 0) pick = 0;
       else if (g_force_halo > 0) pick = forced_halo_variant(hok);
@@ -2057,7 +2061,7 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     snprintf(buf, len, kind == 5 ? "conv_stem_kernel<2>" : "conv_stem_wgrad_kernel<2>");
     return XM_OK;
   }
-  int ci = kind == 0 ? (key % 100) / 2 : (key % 100) / 4;
+  int ci = (kind == 0 || kind == 2) ? (key % 100) / 2 : (key % 100) / 4;   // keys: ProfScope call sites (ci * 2 [+ mode] / ci * 4 + vec)
   if (ci < 0 || ci >= kNumCfg) return XM_EINVAL;
   const Cfg &c = kCfgs[ci];
   if (kind == 0 && is_dma_cfg(ci))

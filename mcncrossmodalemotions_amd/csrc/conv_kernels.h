@@ -231,16 +231,6 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
                                                    float *sred = nullptr /* LDS, >= 2 * WGN * BM floats (statPart) */,
                                                    bool toSlab = true /* a.slab != NULL: this block writes partials */) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-#if defined(XM_VARIANT) && XM_VARIANT == 2
-  {  // experiment: no stores (keeps the accumulators alive through an impossible condition)
-    float s_ = 0.f;
-    for (int i = 0; i < TM; ++i)
-      for (int j = 0; j < TN; ++j)
-        for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
-    if (s_ == 123456.789f) a.Y[0] = s_;
-    return;
-  }
-#endif
   // C/D map of 32x32 MFMA: col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (a.slab && toSlab) {
     // split-K: raw partial sums, [split][m][p] with p contiguous (hybrid schedule: p relative to hyP0)
@@ -393,11 +383,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
               o.z = fmaxf(o.z, 0.f);
               o.w = fmaxf(o.w, 0.f);
             }
-#if defined(XM_VARIANT) && XM_VARIANT == 3
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(a.Y + offs[g4][j]));
-#else
             xm_st16<ASMST>(a.Y + offs[g4][j], o);
-#endif
           }
         }
       }
@@ -626,16 +612,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   //   read chunk 0 of CUR^1 -> (af0, bf0)      | MFMAs of chunk 1 from (af1, bf1)
   // LDS[CUR^1] was last read (its chunk 1) at the start of the previous stage, i.e. before the
   // previous mid-stage barrier, so overwriting it here is safe.
-#ifndef XM_VARIANT
-#define XM_VARIANT 0
-#endif
-#if XM_VARIANT == 1
-#define XM_FETCH_EARLY(KT)
-#define XM_FETCH_LATE(KT) XM_FETCH_TAPS(KT)
-#else
 #define XM_FETCH_EARLY(KT) XM_FETCH_TAPS(KT)
 #define XM_FETCH_LATE(KT)
-#endif
 #define XM_STAGE_LD(KT, CUR, LA, LB, SA, SB)                                   \
   XM_LOAD_TILE((KT) + 2, LA, LB)                                               \
   XM_FETCH_EARLY((KT) + 3)                                                     \

@@ -48,9 +48,11 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
     if parameterServer == "tmove":
         parameterServer = "rccl-capi" if (dist.is_available() and dist.is_initialized() and
                                           dist.get_backend() == "nccl" and dist.get_world_size() > 1) else "torch"
-    parserv = parameterServer if isinstance(parameterServer, train.ParameterServer) else \
-        train.ParameterServer(parameterServer)
-    parserv.start()
+    if isinstance(parameterServer, train.ParameterServer):
+        parserv = parameterServer
+        parserv.start()
+    else:   # all workers agree on the backend (a failed communicator start falls back to torch.distributed everywhere)
+        parserv = train.ParameterServer.start_agreed(parameterServer)
     net = zoo.emoVoxZoo(student, scratch=1 if fromScratch else 0, lossType=lossType, numSeconds=numSeconds,
                         numOutputs=numPredEmotions, width_mult=widthMult)             # :125-129
     net.meta.setdefault("augmentation", {})["transformation"] = "I"                  # :130

@@ -50,6 +50,13 @@ class ParameterServer:
         self._started = False
         self._handles = []
 
+    _generation = 0      # start() calls of this process so far (store keys; every worker makes the same calls)
+
+    @staticmethod
+    def _store():
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+
     def start(self):
         if self._started:
             return
@@ -61,17 +68,57 @@ class ParameterServer:
             buf = (C.c_char * 128)()
             if self.world == 1:
                 _lib.check(L.xm_debug_comm_force_single(1))
-            if self.rank == 0:
-                _lib.check(L.xm_comm_unique_id(buf))
-            raw = bytes(buf)
+            raw = None
             if self.world > 1:
-                t = torch.tensor(list(raw), dtype=torch.uint8)
-                if dist.get_backend() == "nccl":
-                    t = t.cuda()
-                dist.broadcast(t, 0)
-                raw = bytes(t.cpu().tolist())
+                # the 128-byte id travels through the process group's key-value store (labBroadcast in a MATLAB host):
+                # host memory only -- no device allocation and no collective may precede xm_comm_init (xmodal.h "CALL
+                # ORDER") -- and a worker whose id generation failed tells the others instead of leaving them waiting
+                ParameterServer._generation += 1
+                key = "xm_comm_id/%d" % ParameterServer._generation
+                store = self._store()
+                if self.rank == 0:
+                    rc = L.xm_comm_unique_id(buf)
+                    store.set(key, b"ok" + bytes(buf) if rc == 0 else b"no")
+                    _lib.check(rc)
+                got = bytes(store.get(key))
+                if not got.startswith(b"ok"):
+                    raise RuntimeError("ParameterServer: worker 0 could not create the communicator id")
+                raw = got[2:130]
+            else:
+                _lib.check(L.xm_comm_unique_id(buf))
+                raw = bytes(buf)
             _lib.check(L.xm_comm_init(C.c_char_p(raw), self.rank, self.world))
         self._started = True
+
+    @classmethod
+    def start_agreed(cls, backend="rccl-capi", force=False):
+        """Start the `backend` ParameterServer on every worker, or -- if ANY worker failed to -- torch.distributed
+        on all of them: the outcome is agreed through the process group's store (host side, nothing on the device),
+        so that no worker is left inside a collective the others never enter.  Returns the started instance."""
+        import sys
+        import torch.distributed as dist
+        ps = cls(backend)
+        ps.force = force
+        ok = 1
+        try:
+            ps.start()
+        except Exception as e:   # noqa: BLE001 -- reported, then agreed on with the other workers
+            print("ParameterServer(%s) failed to start: %s" % (backend, e), file=sys.stderr, flush=True)
+            ok = 0
+        if backend != "torch" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            cls._generation += 1
+            store, world, rank = cls._store(), dist.get_world_size(), dist.get_rank()
+            store.set("xm_ps_ok/%d/%d" % (cls._generation, rank), b"1" if ok else b"0")
+            ok = int(all(bytes(store.get("xm_ps_ok/%d/%d" % (cls._generation, r))) == b"1" for r in range(world)))
+        if not ok:
+            try:
+                ps.stop()
+            except Exception:    # noqa: BLE001
+                pass
+            ps = cls("torch")
+            ps.force = force
+            ps.start()
+        return ps
 
     force = False  # debugging: run the collectives even with a single worker
     overlap = True  # bucketed exchange overlapped with the backward pass (GradBuckets); False: one exchange after it
@@ -434,8 +481,9 @@ def load_checkpoint(net, path, strict=True):
     """inverse of save_checkpoint (values stored in the flat buffers' memory order: reversed MATLAB shape).
     The whole file is validated against the net BEFORE anything is copied: a mismatch leaves the net untouched."""
     ck = torch.load(path, map_location=net.device, weights_only=True)
-    if not isinstance(ck, dict) or ck.get("format") != "xmodal-params-v2":
-        raise CheckpointMismatch("%s: not an xmodal checkpoint" % path)
+    if not isinstance(ck, dict) or ck.get("format") != "xmodal-params-v2" or not isinstance(ck.get("params"), dict):
+        # an older-format or foreign file: unreadable for `cont` (skipped with a warning), not a mismatch
+        raise CheckpointUnreadable("%s: not an xmodal-params-v2 checkpoint" % path)
     if net._flat is None:
         net.pack_params()
     todo = []
@@ -463,7 +511,11 @@ def load_checkpoint(net, path, strict=True):
 
 
 class CheckpointMismatch(ValueError):
-    """the file is a readable checkpoint of a DIFFERENT net (names / shapes): never skipped by `cont`"""
+    """the file is a valid xmodal-params-v2 checkpoint of a DIFFERENT net (names / shapes): never skipped by `cont`"""
+
+
+class CheckpointUnreadable(OSError):
+    """the file unpickles but is not an xmodal-params-v2 checkpoint (older format, foreign .pt): `cont` skips it"""
 
 
 def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpochs=300, train=None, val=None,
@@ -500,7 +552,8 @@ def cnn_train_dag(net, imdb, getBatch, learningRate=None, batchSize=64, numEpoch
                 ck = load_checkpoint(net, path(done[-1]))
             except CheckpointMismatch:   # readable, but of another net: restarting would overwrite those files
                 raise
-            except (OSError, EOFError, RuntimeError, pickle.UnpicklingError, KeyError) as e:   # truncated / damaged
+            except (OSError, EOFError, RuntimeError, pickle.UnpicklingError, KeyError, ValueError, TypeError,
+                    AttributeError) as e:   # truncated / damaged / foreign (CheckpointMismatch was re-raised above)
                 print("cnn_train_dag: skipping unreadable checkpoint %s (%s)" % (path(done[-1]), e), flush=True)
                 done.pop()
                 continue

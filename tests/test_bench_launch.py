@@ -1,0 +1,51 @@
+"""bench.py --gpus N is the command the driver runs: it must produce an N-rank line by itself, or refuse.
+
+cnn_train_dag starts numel(opts.gpus) workers (run_distillation.m:71,77,88,179-181); here one process per GPU under
+torch.distributed.run, which `bench.py --gpus N` execs itself into when no launcher is around it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XM_DEBUG_DIST")}
+    env.update(kw)
+    return env
+
+
+def test_refuses_to_run_fewer_ranks_than_asked_for():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node would really launch the ranks")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(), timeout=300)
+    assert r.returncode != 0
+    assert b"refusing to run fewer ranks" in r.stderr and not r.stdout.strip()
+
+
+def test_launcher_world_must_match_the_flag():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and b"must agree" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_flag_starts_the_ranks_itself(gpu):
+    """`python bench.py --gpus 2` with no launcher: two ranks (XM_DEBUG_DIST=gloo0: both on the one GPU of the test
+    box, exchange over gloo -- a functional run of the whole N > 1 path; the throughput means nothing) and ONE json line
+    that says so: n_gpus 2, rccl_ranks 2, dp2, global batch = 2 shards."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=_env(XM_DEBUG_DIST="gloo0"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
+    assert d["value"] > 0 and d["scaling"] == "weak"
