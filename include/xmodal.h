@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -137,6 +137,26 @@ int xm_nnconv_backward_accum(const float *x, int H, int W, int C, int N, const f
                              int FC, int K, const float *dzdy, float *dx_out, float *df_out,
                              float *db_out, int sy, int sx, int pt, int pb, int pl, int pr, int dy,
                              int dx, const float *dx_accum, void *stream);
+/* Extension: [DZDF, DZDB] of a FIRST-layer convolution together with [DG, DB] of the vl_nnbnorm behind it, when the
+ * convolution's output Y feeds vl_nnbnorm -> vl_nnrelu -> vl_nnpool('max') and nothing else (the student's
+ * conv1 -> bn1 -> relu1 -> pool1, emoVoxCeleb/emoVoxZoo.m:50-62) and the convolution's own input
+ * needs no derivative.  Equivalent to
+ *     xm_nnbnorm_relu_pool_backward(Y, ..., argmax, y_pool, dzdy_pool, DX, DG, DB, NULL)   then
+ *     xm_nnconv_backward(X, ..., DZDY = DX, NULL, DZDF, DZDB)
+ * but DX -- the widest tensor of the student's backward pass, 462 MB at 32 spectrograms -- is never written: the
+ * filter-derivative kernel rebuilds it per element from the pooled derivative and the routing table.  Same decisions
+ * (ReLU gates, routing) and the same per-element formula; the normalisation's constants are applied in fp32 with a
+ * two-float mean instead of fp64 (1 ulp of DX).  Arguments: X / geometry of the convolution as for xm_nnconv_backward
+ * (F itself is not needed), Y = its output, then the arguments of xm_nnbnorm_relu_pool_backward.  dzdb_out, dg_out,
+ * db_out may be NULL.  Returns XM_ENOTSUP when the shapes are outside what the fused kernel covers (single input
+ * channel, <= 96 filters, <= 8 x 7 taps, 3 x 3 / stride-2 unpadded pooling, y_pool given): make the two calls then. */
+int xm_nnconv_backward_filter_bnrelupool(const float *x, int H, int W, int C, int N, int FH, int FW, int FC, int K,
+                                         int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx,
+                                         const float *y, const float *bn_g, const float *bn_b, const float *moments,
+                                         int train, int ph, int pw, int psy, int psx, int ppt, int ppb, int ppl,
+                                         int ppr, const unsigned char *argmax, const float *y_pool,
+                                         const float *dzdy_pool, float *dzdf_out, float *dzdb_out, float *dg_out,
+                                         float *db_out, void *stream);
 
 /* ---- vl_nnpool  (matlab/vl_nnpool.m; pool6 resized at emoVoxZoo.m:256-269) ------------------
  * Y = vl_nnpool(X, [ph pw], 'stride', .., 'pad', .., 'method', 'max'|'avg') */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "xm_nnconv_backward_accum": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp] +
                                 [_i] * 8 + [c_fp, _vp],
     "xm_nnconv_prepare_backward": [_i] * 4 + [c_fp] + [_i] * 12 + [_vp],
+    "xm_nnconv_backward_filter_bnrelupool": [c_fp] + [_i] * 16 + [c_fp, c_fp, c_fp, c_fp] + [_i] * 9 +
+                                            [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_params_changed": [],
     "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],

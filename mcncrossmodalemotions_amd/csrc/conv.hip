@@ -1810,9 +1810,9 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
 }
 
 // ---- filter derivative of the single-channel stem (conv_stem_wgrad_kernel) ------------------------------------------
-static bool stem_wgrad_ok(const Geo &g, const float *x, const float *dzdy) {
+static bool stem_wgrad_ok(const Geo &g, const float *x, const float *dzdy, bool structural_only = false) {
   static const bool off = getenv("XM_NO_STEM") != nullptr || getenv("XM_NO_STEM_WGRAD") != nullptr;
-  if (off || g_force_cfg >= 0 || g_force_splits > 0) return false;
+  if (!structural_only && (off || g_force_cfg >= 0 || g_force_splits > 0)) return false;
   if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.FH * g.FW > 64 || g.Kg > 96) return false;
   if (g.sy != 1 && g.sy != 2) return false;
@@ -1820,11 +1820,20 @@ static bool stem_wgrad_ok(const Geo &g, const float *x, const float *dzdy) {
   if ((g.Ho * g.Wo) % 4 != 0) return false;                                      // dY pixel quads stay inside a sample
   if (g.pt > 4 || 4 * ((g.sy * (g.Ho - 1) - g.pt + 4 + 7) >> 2) + 3 >= kStemHP) return false;
   if (g.Ho < 128) return false;
-  if (g_force_stem != 1 && (long long)g.Ho * g.Wo * g.N < 128 * 512) return false;
+  if (!structural_only && g_force_stem != 1 && (long long)g.Ho * g.Wo * g.N < 128 * 512) return false;
   return true;
 }
 
-static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int grid, hipStream_t st) {
+// BNP (bnp != NULL): `dzdy` is the convolution's own OUTPUT, the derivative is rebuilt on the fly (StemWgradArgs)
+struct StemBnp {
+  const float *dP;
+  const unsigned char *amax;
+  const float *rowc;
+  int pHo, pWo;
+  float *dbias;      // NULL, or dzdb of the convolution (column R of the partials multiplies ones)
+};
+static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int grid, hipStream_t st,
+                             const StemBnp *bnp = nullptr) {
   StemWgradArgs a{};
   a.dY = dzdy;
   a.X = x;
@@ -1846,21 +1855,54 @@ static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, cons
   a.xSampleStride = g.H * g.W;
   a.dySampleStride = g.Ho * g.Wo * g.K;
   a.dyChanStride = g.Ho * g.Wo;
+  a.onesCol = -1;
+  if (bnp) {
+    a.dP = bnp->dP;
+    a.amax = bnp->amax;
+    a.rowc = bnp->rowc;
+    a.pHo = bnp->pHo;
+    a.pWo = bnp->pWo;
+    const size_t pooled = (size_t)bnp->pHo * bnp->pWo * g.K * g.N;
+    a.dpBytes = (unsigned)(pooled * 4);
+    a.amBytes = (unsigned)pooled;
+    a.dyBytes = (unsigned)((size_t)g.Ho * g.Wo * g.K * g.N * 4);
+    if (bnp->dbias) a.onesCol = g.R;
+  }
   static bool attr_done = false;
   if (!attr_done) {
     XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmem));
     XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_bnp_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemWgSmemBnp));
     attr_done = true;
   }
   const int ntiles = (a.NP + 127) / 128;
   {
-    const double abytes = 4.0 * g.H * g.W * g.N + 4.0 * a.M * (double)a.NP + 4.0 * a.M * a.R;
-    ProfScope ps(6 * 100, 2.0 * a.M * (double)a.NP * a.R, st, abytes);
-    if (g.sy == 2) hipLaunchKernelGGL(conv_stem_wgrad_kernel<2>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
-    else hipLaunchKernelGGL(conv_stem_wgrad_kernel<1>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
+    // BNP reads the convolution's output once (as the plain kernel reads dY) + the pooled derivative and its table
+    const double abytes = 4.0 * g.H * g.W * g.N + 4.0 * a.M * (double)a.NP + 4.0 * a.M * a.R +
+                          (bnp ? 5.0 * bnp->pHo * bnp->pWo * (double)g.K * g.N : 0.0);
+    ProfScope ps(6 * 100 + (bnp ? 1 : 0), 2.0 * a.M * (double)a.NP * a.R, st, abytes);
+    if (bnp) {
+      const int ones = a.onesCol < 0 ? 0 : (a.onesCol < 32 ? 1 : 2);
+#define XM_BNP_LAUNCH(SY_, ON_) hipLaunchKernelGGL((conv_stem_wgrad_bnp_kernel<SY_, ON_>), dim3(grid), dim3(256), kStemWgSmemBnp, st, a, ntiles)
+      if (g.sy == 2) {
+        if (ones == 0) XM_BNP_LAUNCH(2, 0); else if (ones == 1) XM_BNP_LAUNCH(2, 1); else XM_BNP_LAUNCH(2, 2);
+      } else {
+        if (ones == 0) XM_BNP_LAUNCH(1, 0); else if (ones == 1) XM_BNP_LAUNCH(1, 1); else XM_BNP_LAUNCH(1, 2);
+      }
+#undef XM_BNP_LAUNCH
+    } else {
+      if (g.sy == 2) hipLaunchKernelGGL(conv_stem_wgrad_kernel<2>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
+      else hipLaunchKernelGGL(conv_stem_wgrad_kernel<1>, dim3(grid), dim3(256), kStemWgSmem, st, a, ntiles);
+    }
   }
   XM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(a.M), dim3(1024), 0, st, part, dfo, grid, a.M, a.R);
+  hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3(a.M), dim3(1024), 0, st, part, dfo, grid, a.M, a.R,
+                     bnp ? bnp->dbias : nullptr);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }
@@ -2058,7 +2100,7 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     return XM_OK;
   }
   if (kind == 5 || kind == 6) {
-    snprintf(buf, len, kind == 5 ? "conv_stem_kernel<2>" : "conv_stem_wgrad_kernel<2>");
+    snprintf(buf, len, kind == 5 ? "conv_stem_kernel<2>" : (key % 100 ? "conv_stem_wgrad_bnp_kernel<2, 2>" : "conv_stem_wgrad_kernel<2>"));
     return XM_OK;
   }
   int ci = (kind == 0 || kind == 2) ? (key % 100) / 2 : (key % 100) / 4;   // keys: ProfScope call sites (ci * 2 [+ mode] / ci * 4 + vec)
@@ -2146,6 +2188,44 @@ int xm_nnconv_prepare_backward(int H, int W, int C, int N, const float *f, int F
 int xm_params_changed(void) {
   ++g_param_version;
   return XM_OK;
+}
+
+// dzdf (+ dzdb) of a first-layer convolution whose output feeds vl_nnbnorm -> vl_nnrelu -> vl_nnpool('max') and nothing
+// else (the student's conv1 -> bn1 -> relu1 -> pool1, emoVoxZoo.m:50-62 / Appendix B.1), together with the bnorm's dg / db:
+// the bnorm's DZDX -- the widest tensor of the backward pass, 462 MB at 32 spectrograms -- is rebuilt inside the
+// filter-derivative kernel from the pooled derivative and the routing table instead of being written by
+// xm_nnbnorm_relu_pool_backward and read back by xm_nnconv_backward.  XM_ENOTSUP when the geometry is not the one the
+// kernel is written for (single-channel stem, 3 x 3 / stride-2 unpadded pooling): the caller then makes the two calls.
+int xm_nnconv_backward_filter_bnrelupool(const float *x, int H, int W, int C, int N, int FH, int FW, int FC, int K, int sy,
+                                         int sx, int pt, int pb, int pl, int pr, int dy, int dx, const float *y,
+                                         const float *bn_g, const float *bn_b, const float *moments, int train, int ph,
+                                         int pw, int psy, int psx, int ppt, int ppb, int ppl, int ppr,
+                                         const unsigned char *argmax, const float *y_pool, const float *dzdy_pool,
+                                         float *df_out, float *dbias_out, float *dg_out, float *db_out, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!x || !y || !bn_g || !bn_b || !moments || !argmax || !dzdy_pool || !df_out)
+    return fail(XM_EINVAL, "vl_nnconv(filter derivative through bnorm+relu+pool): NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int pHo = out_size(g.Ho, ppt, ppb, ph, 1, psy), pWo = out_size(g.Wo, ppl, ppr, pw, 1, psx);
+  const bool ok = stem_wgrad_ok(g, x, y, true) && g.G == 1 && g.K == g.Kg && y_pool != nullptr && ph == 3 && pw == 3 &&
+                  psy == 2 && psx == 2 && ppt == 0 && ppb == 0 && ppl == 0 && ppr == 0 && (g.Ho & 1) == 0 && pHo >= 1 &&
+                  pWo >= 1 && (!dbias_out || g.R < 64) && !too_big((long long)pHo * pWo, g.K, g.N, 4) &&
+                  g_force_stem != 0;
+  if (!ok)
+    return fail(XM_ENOTSUP, "vl_nnconv(filter derivative through bnorm+relu+pool): geometry not covered by the fused kernel");
+  const int grid = stem_grid(g.Ho * g.Wo * g.N);
+  WsCarver ws;
+  rc = ws.init(WsCarver::need((size_t)6 * g.K, 4) + WsCarver::need((size_t)grid * 96 * 64, 4) + bnpool_sums_need(g.K, g.N), st);
+  if (rc) return rc;
+  float *rowc = ws.take<float>((size_t)6 * g.K);
+  float *spart = ws.take<float>((size_t)grid * 96 * 64);
+  rc = bnpool_backward_sums(ws, y, g.Ho, g.Wo, g.K, g.N, bn_g, bn_b, moments, train, ph, pw, psy, psx, ppt, ppb, ppl, ppr,
+                            argmax, y_pool, dzdy_pool, dg_out, db_out, rowc, st);
+  if (rc) return rc;
+  StemBnp bnp{dzdy_pool, argmax, rowc, pHo, pWo, dbias_out};
+  return launch_stem_wgrad(x, y, df_out, g, spart, grid, st, &bnp);
 }
 
 int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -1452,10 +1452,21 @@ struct StemWgradArgs {
   FastDiv divPIJ, divPI;
   int gsx, gh0, gw0, LimH, LimW;     // as ConvGemmArgs (forward gather geometry)
   int xSampleStride, dySampleStride, dyChanStride;
+  // conv_stem_wgrad_bnp_kernel only: dY is the convolution's OUTPUT x -- the input of the vl_nnbnorm -> vl_nnrelu ->
+  // vl_nnpool('max', 3 x 3 / stride 2, no padding) chain behind it -- and the bnorm's DZDX is rebuilt on the fly from the
+  // pooled derivative + the routing table, never written to HBM
+  const float *dP;                   // pooled DZDY [pHo][pWo][M][N]
+  const unsigned char *amax;         // routing table of the pooling (first maximum, code = dh + 3 dw)
+  const float *rowc;                 // [M][6]: g/sigma, mu, b, k1 hi, k1 lo, k2   (bnpool_rowconst_kernel)
+  unsigned dpBytes, amBytes, dyBytes;
+  int pHo, pWo;                      // pooled grid
+  int onesCol;                       // >= 0: that B column multiplies ones: partial[.][m][onesCol] = sum of dY[m] (dzdb)
 };
 constexpr int kStemWgTP = 36;        // row pitch (floats) of a wave's dY tile: 32 pixels + 4
 constexpr int kStemWgWave = 2 * kStemNV * kStemHW + 4 + 96 * kStemWgTP;   // floats of LDS per wave: patch + dummy unit + dY tile
 constexpr int kStemWgSmem = (4 * kStemWgWave + 4) * 4;                    // bytes per block (+ a zero unit)
+constexpr int kStemWgSmemBnp = kStemWgSmem + 96 * 6 * 4;   // + the bnorm's per-channel constants (two blocks per CU still
+                                                           // fit: 2 x 80976 B <= 160 KB at any allocation granule up to 1280 B)
 
 template <int SY>
 __global__ void __launch_bounds__(256, 2)
@@ -1612,19 +1623,336 @@ conv_stem_wgrad_kernel(const StemWgradArgs a, const int ntiles) {
 
 // dF[r + R m] = sum over the blocks' partials in a fixed order; grid = M blocks of 64 taps x 16 block groups
 __global__ void __launch_bounds__(1024)
-conv_stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ df, int nblk, int M, int R) {
+conv_stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ df, int nblk, int M, int R,
+                              float *__restrict__ db /* NULL, or dzdb: column R of the partials (StemWgradArgs::onesCol) */) {
   __shared__ float red[16][64];
   const int r = threadIdx.x & 63, g = threadIdx.x >> 6, m = blockIdx.x;
   float v = 0.f;
   for (int b = g; b < nblk; b += 16) v += part[(size_t)b * (96 * 64) + m * 64 + r];
   red[g][r] = v;
   __syncthreads();
-  if (g == 0 && r < R) {
+  if (g == 0 && (r < R || (db && r == R))) {
     v = red[0][r];
 #pragma unroll
     for (int k = 1; k < 16; ++k) v += red[k][r];
-    df[r + (size_t)R * m] = v;
+    if (r < R) df[r + (size_t)R * m] = v;
+    else db[m] = v;
   }
+}
+
+// ---- the same filter derivative THROUGH vl_nnpool('max') o vl_nnrelu o vl_nnbnorm ------------------------------------
+// xm_nnconv_backward_filter_bnrelupool: dY above is the derivative the bnorm hands to its input -- 462 MB at 32
+// spectrograms, written by bnpool_bwd_apply_patch_kernel and read once, here.  This kernel takes the bnorm's INPUT x
+// (= the convolution's own output, same layout) in its place and rebuilds the derivative per element:
+//     dz = [g/sigma (x - mu) + b > 0] * sum over the <= 2 x 2 covering windows w [argmax(w) == this element] dP(w)
+//     dx = g/sigma dz - k1 - k2 (x - mu)                         (k1, k2: per-channel constants, bnpool_rowconst_kernel)
+// A lane's pixel quad = two stride cells of the 3 x 3 / stride-2 pooling (quad origins and PI are even); cell (kh, column
+// j): the even row 2 kh is covered by window rows kh - 1 (as their row 2) and kh (row 0), the odd row by kh (row 1); the
+// column by window columns (j >> 1) - 1 (j even only; column 2 of the window) and j >> 1 (column j & 1).  Per cell and
+// window column ONE 8-byte load fetches the derivatives of window rows (kh - 1, kh) and one 2-byte load their routing
+// codes; a candidate that does not exist gets the expected code 255 (never recorded): no validity masks.  The first cell
+// of a column (kh = 0) loads the pair one row later, so that no load starts in front of the tensor.  Contributions are
+// added in the order of bnpool_bwd_apply_patch_kernel (window column outer, window row inner).  The transform runs in
+// fp32 with k1 = g/sigma mean(dz) split in two floats (a rounded k1 would shift every element of a channel the same
+// way; sum(dx) must stay at rounding-noise level, xm_common.h).
+// Schedule: the MFMA loop runs ROW TILE by row tile (3 phases of 32 MFMAs); the 32 rows of the dY tile a phase has read
+// are dead afterwards (LDS operations of a wave execute in order), so production runs exactly two phases ahead of
+// consumption -- phase p of tile T writes row tile (p + 2) % 3 of tile T + (p > 0) -- with the x quads requested one
+// phase before that and the pooled operands inside the phase, two row groups at a time: 32 + 24 registers in flight
+// instead of a whole tile's (the tile-ahead variant of conv_stem_wgrad_kernel needed 48 + 36 and spilled).
+// ONES: 0 = no bias derivative; 1 / 2 = the ones column sits in column tile 0 / 1 (only that tile's B operand carries the select)
+template <int SY, int ONES>
+__global__ void __launch_bounds__(256, 2)
+conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
+  constexpr int TM = 3, NV = kStemNV, HW = kStemHW, GRP = NV * HW, WPATCH = 2 * GRP + 4, TP = kStemWgTP;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  for (int i = t; i < 4 * kStemWgWave / 4 + 1; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float *const sW = smem + wave * kStemWgWave;        // this wave's source patch
+  float *const tW = sW + WPATCH;                      // this wave's dY tile [96][TP]
+  float *const sRC = smem + 4 * kStemWgWave + 4;      // the bnorm's per-channel constants [96][6]
+  for (int i = t; i < 96 * 6; i += 256) sRC[i] = i < 6 * a.M ? a.rowc[i] : 0.f;
+  const int per = (ntiles + 7) >> 3, tbase = (blockIdx.x & 7) * per, tstep = gridDim.x >> 3;
+  const int tend = min(per, ntiles - tbase);
+  const int PIJ = (int)a.divPIJ.d, PI = (int)a.divPI.d;
+  const int pHW = a.pHo * a.pWo;
+  const __amdgpu_buffer_rsrc_t dprsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dP, 0, a.dpBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t amrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.amax, 0, a.amBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
+  // All streaming loads are buffer loads with a per-lane byte offset that is fixed for a tile + a SCALAR offset for the
+  // channel row (rows 32 rt + 8 kk + lc: the lane's lc sits in the per-lane part): 64-bit per-row addresses kept live
+  // across the tile loop were what made the first version of this kernel spill.  Rows / quads that do not exist read
+  // in-range garbage or, past the end of the tensor, zeros (range check) and are zeroed when the tile is WRITTEN.
+
+  const int lc = lane >> 3, lk = lane & 7;
+  struct Cols {
+    int nF, jF, iF, nL, jL, iL;
+  };
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto wave_cols = [&](int tile) {
+    Cols c;
+    const uint32_t pF = min((uint32_t)tile * 128u + 32u * wv, (uint32_t)a.NP - 1u), pL = min(pF + 31u, (uint32_t)a.NP - 1u);
+    c.nF = (int)xm_div(pF, a.divPIJ);
+    uint32_t q = pF - (uint32_t)c.nF * PIJ;
+    c.jF = (int)xm_div(q, a.divPI);
+    c.iF = (int)q - c.jF * PI;
+    c.nL = (int)xm_div(pL, a.divPIJ);
+    q = pL - (uint32_t)c.nL * PIJ;
+    c.jL = (int)xm_div(q, a.divPI);
+    c.iL = (int)q - c.jL * PI;
+    return c;
+  };
+  // ---- source patch: exactly conv_stem_wgrad_kernel's --------------------------------------------------------------
+  f32x4 ld[3];
+  int ldst[3];
+  bool ldz[3];
+  auto issue_patch = [&](const Cols &c) {
+    const bool two = c.nF != c.nL || c.jF != c.jL;
+    const int hi0 = two ? PI - 1 : c.iL;
+    const int lo4[2] = {(SY * c.iF + a.gh0 + 4) >> 2, (a.gh0 + 4) >> 2};
+    const int n0 = ((SY * hi0 + a.gh0 + 4 + 7) >> 2) - lo4[0] + 1;
+    const int n1 = two ? ((SY * c.iL + a.gh0 + 4 + 7) >> 2) - lo4[1] + 1 : 0;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int q = lk + 8 * it;
+      const int g = q >= n0 ? 1 : 0, u = q - (g ? n0 : 0);
+      const bool wr = lc < NV && q < n0 + n1;
+      const int n = g ? c.nL : c.nF, j = g ? c.jL : c.jF;
+      const int cc = a.gsx * j + a.gw0 + lc, r = 4 * (lo4[g] + u) - 4;
+      const bool in = wr && lc < a.nV && cc >= 0 && cc < a.LimW && r >= 0 && r < a.LimH;
+      ldst[it] = wr ? (g * NV + lc) * HW + 4 * u : 2 * GRP;
+      ldz[it] = !in;
+      ld[it] = *reinterpret_cast<const f32x4 *>(in ? a.X + (size_t)n * a.xSampleStride + (size_t)cc * a.LimH + r : a.X);
+    }
+  };
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+      *reinterpret_cast<f32x4 *>(sW + ldst[it]) = ldz[it] ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[it];
+  };
+
+  // ---- production of one row tile (rows 32 rt + lc + 8 kk, kk = 0 .. 3; pixel quad lk) of a tile ---------------------
+  // Measured on the way (whole chain at 32 spectrograms, this mapping: 373 ... 385 us against 482 for the two separate
+  // passes; the sums stage is ~60 us of both): pooled loads removed -110 us, decode arithmetic removed -30 us -- the
+  // kernel is bound by the NUMBER of vector-memory instructions (~16 clocks of the CU's address path each: 96 pooled + 12
+  // + 3 per wave and tile), not by bytes, cache lines or latency: touching the pooled lines one phase early cost +90 us,
+  // a one-stride-cell-per-lane mapping (half the cache lines per instruction, 24 instead of 12 x loads) +50 us, and two
+  // decode variants behind a wave-uniform branch +50 us.
+  struct Prod {            // per lane and tile
+    unsigned xoff;         // byte offset of x at (row lc, the lane's pixel quad)
+    bool in;               // the quad exists (quads never straddle NP: NP % 4 == 0)
+  };
+  auto prod_of = [&](const Cols &c, int tile) {
+    Prod p;
+    const uint32_t pq = (uint32_t)tile * 128u + 32u * wv + 4u * lk;
+    int qq = c.iF + PI * c.jF + 4 * lk, n = c.nF;
+    if (qq >= PIJ) qq -= PIJ, ++n;
+    p.xoff = (unsigned)(n * a.dySampleStride + qq + lc * a.dyChanStride) * 4u;
+    p.in = pq < (uint32_t)a.NP;
+    return p;
+  };
+  // The pair of a cell is (window row kh - 1, kh).  The first cell of a column (kh = 0) loads (0, 1) and the last one
+  // (kh = pHo: rows 2 pHo, 2 pHo + 1, covered by window row pHo - 1 only) loads (pHo - 2, pHo - 1) instead, so that every
+  // load of an EXISTING window lies inside its plane -- nothing depends on how the hardware range-checks an access
+  // that straddles the end of the tensor (a 2-byte load whose second byte is out of range returns zero for both).
+  // The decode picks the slot by pshift (four selects per loaded pair).
+  int pbase[2];          // per cell: element index of the loaded pair at window column j >> 1, channel row lc
+  int pshift[2];         // 0: normal, 1: first cell (window row kh arrives in slot 0), 2: last cell (kh - 1 arrives in slot 1)
+  unsigned pcode[2][2];  // per cell, per window column: expected codes (even row / window row kh - 1) | (even / kh) << 8 | (odd / kh) << 16
+  bool pin = false;      // Prod::in of the tile these belong to
+  bool pfull = false;    // wave-uniform: all 32 pixels and all 96 rows of the tile exist (no zeroing at the write)
+  auto pooled_geometry = [&](const Cols &c, const Prod &pr, int tile) {
+    const int q0 = c.iF + PI * c.jF + 4 * lk;
+    pin = pr.in;
+    pfull = (uint32_t)tile * 128u + 32u * wv + 32u <= (uint32_t)a.NP && a.M == 32 * TM;
+#pragma unroll
+    for (int cell = 0; cell < 2; ++cell) {
+      int qq = q0 + 2 * cell, n = c.nF;
+      if (qq >= PIJ) qq -= PIJ, ++n;
+      const int j = (int)xm_div((uint32_t)qq, a.divPI), i = qq - PI * j, kh = i >> 1;
+      const int wo1 = j >> 1, dw1 = j & 1;
+      pshift[cell] = kh == 0 ? 1 : (kh >= a.pHo ? 2 : 0);
+      pbase[cell] = (kh - 1 + (kh == 0 ? 1 : (kh >= a.pHo ? -1 : 0))) + a.pHo * wo1 + (n * a.M + lc) * pHW;
+      const bool lo = kh >= 1 && kh - 1 < a.pHo, hi = kh < a.pHo;
+      const bool c0 = dw1 == 0 && wo1 >= 1 && wo1 - 1 < a.pWo, c1 = wo1 < a.pWo;
+      auto codes = [&](bool cv, int dw) {
+        const unsigned e_lo = (cv && lo) ? 2u + 3u * dw : 255u, e_hi = (cv && hi) ? 0u + 3u * dw : 255u,
+                       o_hi = (cv && hi) ? 1u + 3u * dw : 255u;
+        return e_lo | (e_hi << 8) | (o_hi << 16);
+      };
+      pcode[cell][0] = codes(c0, 2);
+      pcode[cell][1] = codes(c1, dw1);
+    }
+  };
+  auto x_issue = [&](f32x4 (&xq)[4], const Prod &pr, int rt) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)pr.xoff, (32 * rt + 8 * kk) * a.dyChanStride * 4, 0);
+      xq[kk] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  f32x2 pd[2][2][2];     // [row group of the half][cell][window column]: derivatives of the loaded window-row pair
+  unsigned pa[2][2][2];  // their routing codes (2 bytes)
+  auto pooled_issue = [&](int rt, int h) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int mrow = (32 * rt + 8 * (2 * h + kk)) * pHW;     // scalar part of the channel row
+#pragma unroll
+      for (int cell = 0; cell < 2; ++cell)
+#pragma unroll
+        for (int wc = 0; wc < 2; ++wc) {
+          typedef unsigned u2 __attribute__((ext_vector_type(2)));
+          const int idx = pbase[cell] - (wc ? 0 : a.pHo);     // (may be negative in front of the tensor: out of range -> 0, code 255)
+          const u2 v = __builtin_amdgcn_raw_buffer_load_b64(dprsrc, idx * 4, mrow * 4, 0);
+          pd[kk][cell][wc] = __builtin_bit_cast(f32x2, v);
+          pa[kk][cell][wc] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(amrsrc, idx, mrow, 0);
+        }
+    }
+  };
+  auto decode_write = [&](const f32x4 (&xq)[4], int rt, int h) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int row = 32 * rt + lc + 8 * (2 * h + kk);
+      const int m = min(row, a.M - 1);
+      const float2 rca = *reinterpret_cast<const float2 *>(sRC + 6 * m);        // g/sigma, mu
+      const float2 rcb = *reinterpret_cast<const float2 *>(sRC + 6 * m + 2);    // b, k1 hi
+      const float2 rcc = *reinterpret_cast<const float2 *>(sRC + 6 * m + 4);    // k1 lo, k2
+      float dz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cell = 0; cell < 2; ++cell)
+#pragma unroll
+        for (int wc = 0; wc < 2; ++wc) {
+          const unsigned x_ = pa[kk][cell][wc], e_ = pcode[cell][wc];
+          const unsigned b0_ = x_ & 255u, b1_ = (x_ >> 8) & 255u;
+          const unsigned chi = pshift[cell] == 1 ? b0_ : b1_, clo = pshift[cell] == 2 ? b1_ : b0_;
+          const float vhi = pshift[cell] == 1 ? pd[kk][cell][wc].x : pd[kk][cell][wc].y;
+          const float vlo = pshift[cell] == 2 ? pd[kk][cell][wc].y : pd[kk][cell][wc].x;
+          const bool m0 = clo == (e_ & 255u), m1 = chi == ((e_ >> 8) & 255u), m2 = chi == (e_ >> 16);
+          dz[2 * cell] += m0 ? vlo : 0.f;       // (window column outer, window row inner: bnpool_bwd_apply_patch_kernel's order)
+          dz[2 * cell] += m1 ? vhi : 0.f;
+          dz[2 * cell + 1] += m2 ? vhi : 0.f;
+        }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t_ = xq[2 * h + kk][e] - rca.y;
+        const float d_ = (rca.x * t_ + rcb.x > 0.f) ? dz[e] : 0.f;
+        o[e] = (rca.x * d_ - rcb.y) - (rcc.y * t_ + rcc.x);
+      }
+      if (!pfull) o = (pin && row < a.M) ? o : f32x4{0.f, 0.f, 0.f, 0.f};      // (wave-uniform: the last tile / fewer than 96 rows)
+      *reinterpret_cast<f32x4 *>(tW + row * TP + 4 * lk) = o;
+    }
+  };
+
+  // this lane's two taps (column tiles jt = 0, 1): offset inside a patch column group; the column that multiplies ones
+  int tapoff[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int n = l31 + 32 * jt;
+    const int v = n < a.R ? n / a.nU : 0, u = n < a.R ? n - v * a.nU : 0;
+    tapoff[jt] = u + HW * v;
+  }
+  const bool onesLane = ONES && a.onesCol == l31 + 32 * (ONES - 1);
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jt][r] = 0.f;
+
+  int q = blockIdx.x >> 3;
+  __syncthreads();                       // zero fill and constants complete
+  f32x4 xc[4], xn[4];                    // x quads of the row tile produced in this phase / requested for the next one
+  Cols cur = wave_cols(tbase + min(q, max(tend, 1) - 1));
+  if (q < tend) {
+    // prologue: row tiles 0 and 1 of the first tile, its patch, and the x quads of its row tile 2 (produced in phase 0)
+    const Prod pr = prod_of(cur, tbase + q);
+    pooled_geometry(cur, pr, tbase + q);
+    issue_patch(cur);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      x_issue(xc, pr, rt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pooled_issue(rt, h);
+        decode_write(xc, rt, h);
+      }
+    }
+    x_issue(xc, pr, 2);
+    write_patch();
+  }
+  for (; q < tend; q += tstep) {
+    const int tile = tbase + q;
+    const bool more = q + tstep < tend;
+    const int ntile = more ? tile + tstep : tile;    // (the last tile is staged once more: no branch around the loads)
+    const Cols nxt = wave_cols(ntile);
+    const Prod prn = prod_of(nxt, ntile);
+    // B operand: pixel 16 half + s of the segment sits in column group 0 until the column ends (w pixels), then in group 1
+    const int w = PI - cur.iF - 16 * half;           // steps s < w are in group 0
+    const int b0 = (cur.iF + 16 * half) * SY + a.gh0 + 4 - 4 * ((SY * cur.iF + a.gh0 + 4) >> 2);
+    const int b1 = GRP + (cur.iF + 16 * half - PI) * SY + a.gh0 + 4 - 4 * ((a.gh0 + 4) >> 2);
+    const float *tr = tW + l31 * TP + 16 * half;     // A operand: row 32 i + l31, pixels 16 half + 4 c .. + 3
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      // phase i multiplies row tile i and produces row tile (i + 2) % 3 -- of this tile in phase 0 (geometry still this
+      // tile's), of the next one afterwards
+      const int prt = (i + 2) % 3;
+      if (i == 1) pooled_geometry(nxt, prn, ntile);
+      if (i == 2) issue_patch(nxt);
+      x_issue(xn, prn, i);                            // the row tile the NEXT phase produces: (next tile, row tile i)
+      pooled_issue(prt, 0);
+      __builtin_amdgcn_sched_barrier(0);             // the loads stay in front of the MFMAs
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 af = *reinterpret_cast<const f32x4 *>(tr + 32 * i * TP + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = 4 * c + e;
+          const float *px = sW + (s < w ? b0 : b1) + SY * s;
+          float bv[2];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) bv[jt] = px[tapoff[jt]];   // (columns >= R accumulate finite garbage that is never stored)
+          if (ONES) bv[ONES ? ONES - 1 : 0] = onesLane ? 1.f : bv[ONES ? ONES - 1 : 0];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bv[jt], acc[i][jt], 0, 0, 0);
+        }
+        if (c == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          decode_write(xc, prt, 0);
+          pooled_issue(prt, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      decode_write(xc, prt, 1);
+      if (i == 2) write_patch();                     // (LDS operations of a wave execute in order: behind the last B reads)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xc[kk] = xn[kk];
+    }
+    cur = nxt;
+  }
+  // the four waves add their accumulators in LDS in wave order; the block leaves one partial [96][64]
+  float *const sD = smem;                            // 96 x 64 floats (the tiles are dead)
+  for (int wq = 0; wq < 4; ++wq) {
+    __syncthreads();
+    if (wave == wq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float *d = sD + (32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * jt + l31;
+            *d = wq ? *d + acc[i][jt][r] : acc[i][jt][r];
+          }
+    }
+  }
+  __syncthreads();
+  float *out = a.part + (size_t)blockIdx.x * (96 * 64);
+  for (int i = t; i < 96 * 64 / 4; i += 256) reinterpret_cast<f32x4 *>(out)[i] = reinterpret_cast<const f32x4 *>(sD)[i];
 }
 
 // combine split-K slabs in split order and apply the fused epilogue.  VEC (vecStore destinations, slab pitch and

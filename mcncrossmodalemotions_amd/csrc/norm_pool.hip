@@ -1264,6 +1264,57 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   return XM_OK;
 }
 
+// ---- the sums of the fused backward, for a consumer that rebuilds the bnorm's DZDX itself ----------------------------
+// conv.hip's xm_nnconv_backward_filter_bnrelupool never materialises DZDX of the bnorm: the filter-derivative kernel of the
+// producing convolution recomputes it per element from the pooled derivative and the routing table.  What it needs from
+// here: dg / db, and per channel the constants of  dx = g/sigma dz - k1 - k2 (x - mu)  in fp32, k1 = g/sigma mean(dz)
+// split in two floats (a rounded k1 would shift all elements of a channel the same way).
+__global__ void __launch_bounds__(256)
+bnpool_rowconst_kernel(const float *__restrict__ gg, const float *__restrict__ bb, const float *__restrict__ mom,
+                       const double *__restrict__ sums, float *__restrict__ rowc, int C, double m, int train) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double sg = (double)mom[C + c], gsd = (double)gg[c] / sg;
+  const double k1 = train ? gsd * (sums[c] / m) : 0.0;
+  const double k2 = train ? gsd * (sums[C + c] / (m * sg * sg)) : 0.0;
+  const float k1h = (float)k1;
+  float *o = rowc + 6 * c;
+  o[0] = gg[c] / mom[C + c];      // the gate uses the forward pass's own fp32 expression g/sigma (x - mu) + b > 0
+  o[1] = mom[c];
+  o[2] = bb[c];
+  o[3] = k1h;
+  o[4] = (float)(k1 - (double)k1h);
+  o[5] = (float)k2;
+}
+
+size_t bnpool_sums_need(int C, int N) {
+  return WsCarver::need((size_t)2 * C * bn_splits(C, N), 8) + WsCarver::need((size_t)2 * C, 8);
+}
+
+int bnpool_backward_sums(WsCarver &ws, const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                         const float *moments, int train, int ph, int pw, int sy, int sx, int pt, int pb, int pl, int pr,
+                         const unsigned char *amax, const float *y_pool, const float *dzdy_pool, float *dg_out,
+                         float *db_out, float *rowc_out, hipStream_t st) {
+  PoolGeo pg;
+  int rc = pool_geo(pg, H, W, C, N, ph, pw, sy, sx, pt, pb, pl, pr, XM_POOL_MAX);
+  if (rc) return rc;
+  if (!x || !g || !b || !moments || !amax || !y_pool || !dzdy_pool || !rowc_out)
+    return fail(XM_EINVAL, "bnorm+relu+pool sums: NULL tensor");
+  const int S2 = bn_splits(C, N);
+  double *part = ws.take<double>((size_t)2 * C * S2);
+  double *sums = ws.take<double>((size_t)2 * C);
+  hipLaunchKernelGGL(bnpool_bwd_partial_pooled_kernel, dim3(C, S2), dim3(256), 0, st, x, y_pool, dzdy_pool, amax, g, b,
+                     moments, part, pg, make_fastdiv((uint32_t)pg.Ho), C, N, S2);
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, moments, sums, dg_out, db_out, C,
+                     S2);
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bnpool_rowconst_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, b, moments, sums, rowc_out, C,
+                     (double)H * W * N, train);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 }  // namespace xm
 
 using namespace xm;

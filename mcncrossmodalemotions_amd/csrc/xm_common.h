@@ -63,6 +63,14 @@ const void *cached_device_table(const void *host, size_t bytes);
 // convolution epilogue of conv.hip replaces when its tile configuration cannot carry the partial sums
 int bn_batch_moments(const float *x, int H, int W, int C, int N, float eps, float *moments_out, hipStream_t st);
 
+// sums of the fused bnorm + relu + max-pool backward for a consumer that rebuilds DZDX itself (norm_pool.hip): dg, db
+// and the per-channel constants [C][6] = {g/sigma, mu, b, k1 hi, k1 lo, k2}; scratch comes from the caller's carver
+size_t bnpool_sums_need(int C, int N);
+int bnpool_backward_sums(WsCarver &ws, const float *x, int H, int W, int C, int N, const float *g, const float *b,
+                         const float *moments, int train, int ph, int pw, int sy, int sx, int pt, int pb, int pl, int pr,
+                         const unsigned char *amax, const float *y_pool, const float *dzdy_pool, float *dg_out,
+                         float *db_out, float *rowc_out, hipStream_t st);
+
 static inline int out_size(int in, int pa, int pb, int f, int d, int s) {
   int feff = (f - 1) * d + 1;
   int t = in + pa + pb - feff;

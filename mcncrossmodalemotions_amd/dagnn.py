@@ -459,6 +459,9 @@ class DagNN:
         self.fuseStats = os.environ.get("XM_NO_FUSED_STATS") is None  # bnorm batch moments from the conv epilogue
         self.wgradAfterDgrad = os.environ.get("XM_WGRAD_AFTER_DGRAD") is not None
         self.fuseBiasDer = os.environ.get("XM_NO_FUSED_BIASDER") is None   # conv dzdb = sum(dx) from the bnorm backward
+        # first-layer Conv -> BatchNorm -> ReLU -> Pooling: the bnorm's DZDX is rebuilt inside the convolution's
+        # filter-derivative kernel instead of being written and read back (vl.conv_backward_filter_bnrelupool)
+        self.fuseStemBackward = os.environ.get("XM_NO_FUSED_STEM_BWD") is None
         self.fuseForkSums = os.environ.get("XM_NO_FORK_SUMS") is None   # global-avg backward adds the fork's other derivative
         self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
@@ -970,6 +973,8 @@ class _BnReluPoolStep(_Step):
         self._saved = None
         self.bias_conv = bias_conv        # _Step of the biased Conv feeding this BN (or None)
         self.bias_conv_done = False
+        self.producer_conv = None         # _Step of the Conv whose ONLY consumer is this BN (training plans, build_plan)
+        self._stem_fused = True           # cleared when the library reports the shapes as not covered
         if bias_conv is not None:
             bias_conv.bias_from = self
 
@@ -1004,6 +1009,11 @@ class _BnReluPoolStep(_Step):
         g, b, mom = self._params(net)
         test = net.mode == "test"
         do = net._direct_der(r)
+        if self._stem_backward(net, x, g, b, mom if test else mo, am, out, do, test):
+            net._set_param_der(r.params[2], mo)
+            if net.conserveMemory and not out.precious:
+                out.der = None
+            return
         # the producing convolution's bias derivative (= per-channel sum of this dx) comes for free
         bias_der = None
         if self.bias_conv is not None and net._flat is not None and not net.accumulateParamDers:
@@ -1020,6 +1030,47 @@ class _BnReluPoolStep(_Step):
             net._set_param_der(p, d)
         if net.conserveMemory and not out.precious:
             out.der = None
+
+
+    def _stem_backward(self, net, x, g, b, moments, am, out, do, test):
+        """The producing convolution is a first layer (its input needs no derivative) and feeds only this step: one
+        fused call leaves its filter / bias derivative and this bnorm's dg / db; the bnorm's DZDX is never written.
+        Runs on the side stream when there is one (nothing on the main stream depends on it).  False = not applicable,
+        the two separate steps run."""
+        cs = self.producer_conv
+        if cs is None or not self._stem_fused or not net.fuseStemBackward or net._flat is None or \
+                net.accumulateParamDers or do is None:
+            return False
+        cr = cs.rec
+        if net.vars[cr.inputs[0]].fanin > 0 or net.vars[cr.outputs[0]].precious:
+            return False
+        cdo = net._direct_der(cr)
+        if cdo is None or any(net.params[p].fanout != 1 for p in cr.params):
+            return False
+        blk, pb = cr.block, self.pool_rec.block
+        xin = net.vars[cr.inputs[0]].value
+        side = net.wgradStream
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            res = vl.conv_backward_filter_bnrelupool(
+                xin, blk.size, x, g, b, moments, am, out.value, out.der, pb.poolSize, stride=blk.stride, pad=blk.pad,
+                dilate=blk.dilate, pool_stride=pb.stride, pool_pad=pb.pad, train=not test, df_out=cdo[0],
+                dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1], has_bias=blk.hasBias)
+            if res is not None and net.gradHook is not None:
+                if side is None and net._side_pending:
+                    main.wait_stream(net.wgradStream)
+                net.gradHook(cr.name)
+        if res is None:
+            self._stem_fused = False
+            return False
+        if side is not None:
+            for t in (xin, x, am, out.value, out.der, moments):
+                t.record_stream(side)
+            net._side_pending = True
+        self.bias_conv_done = True
+        return True
 
 
 class _ConvActStep(_Step):
@@ -1270,4 +1321,6 @@ def build_plan(net, training):
                 cs = conv_of.get(r.inputs[0])
                 if cs is not None and len(consumers.get(r.inputs[0], [])) == 1:
                     cs.moments_for = r
+                    if type(st) is _BnReluPoolStep:
+                        st.producer_conv = cs
     return steps

@@ -30,6 +30,9 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+XM_ENOTSUP = 5   # include/xmodal.h
+
+
 def mat_empty(*shape, device=None):
     """uninitialised `single` array of MATLAB shape `shape` (column-major)."""
     shape = tuple(int(s) for s in (shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape))
@@ -376,6 +379,37 @@ def bnorm_relu_pool_backward(x, g, b, moments, argmax, dzdy, pool, stride=1, pad
         None if y_pool is None else _ptr(_chk(y_pool, "Y_POOL")), _ptr(dzdy), _ptr(dx), _ptr(dg), _ptr(db),
         _ptr(dxsum_out), _stream()))
     return dx, dg, db
+
+
+def conv_backward_filter_bnrelupool(x, filter_shape, y, g, b, moments, argmax, y_pool, dzdy, pool, stride=1, pad=0,
+                                    dilate=1, pool_stride=1, pool_pad=0, train=True, df_out=None, dbias_out=None,
+                                    dg_out=None, db_out=None, has_bias=True):
+    """Extension (xm_nnconv_backward_filter_bnrelupool): [DZDF, DZDB] of the first-layer convolution Y = vl_nnconv(X, F, B)
+    and [DG, DB] of the bnorm in  vl_nnpool(vl_nnrelu(vl_nnbnorm(Y, G, B)))  from the POOLED derivative `dzdy`: the
+    bnorm's DZDX is never materialised.  Returns (df, dbias, dg, db), or None when the shapes are outside what the fused
+    kernel covers (the caller then runs bnorm_relu_pool_backward + vl_nnconv backward)."""
+    x, y, g, b, dzdy = _chk(x, "X"), _chk(y, "Y"), _chk(g, "G"), _chk(b, "B"), _chk(dzdy, "DZDY")
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = (int(v) for v in filter_shape)
+    sy, sx = _pair(stride, "STRIDE")
+    dy, dx = _pair(dilate, "DILATE")
+    pt, pb, pl, pr = _pad4(pad)
+    ph, pw = _pair(pool, "POOL")
+    psy, psx = _pair(pool_stride, "STRIDE")
+    ppt, ppb, ppl, ppr = _pad4(pool_pad)
+    df = df_out if df_out is not None else mat_empty(FH, FW, FC, K, device=x.device)
+    dbias = (dbias_out if dbias_out is not None else mat_empty(K, 1, device=x.device)) if has_bias else None
+    dg = dg_out if dg_out is not None else mat_empty(K, 1, device=x.device)
+    db = db_out if db_out is not None else mat_empty(K, 1, device=x.device)
+    rc = _L().xm_nnconv_backward_filter_bnrelupool(
+        _ptr(x), H, W, Cc, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx, _ptr(y), _ptr(g), _ptr(b),
+        _ptr(_chk(moments, "MOMENTS")), 1 if train else 0, ph, pw, psy, psx, ppt, ppb, ppl, ppr,
+        C.c_void_p(argmax.data_ptr()), None if y_pool is None else _ptr(_chk(y_pool, "Y_POOL")), _ptr(dzdy), _ptr(df),
+        _ptr(dbias), _ptr(dg), _ptr(db), _stream())
+    if rc == XM_ENOTSUP:
+        return None
+    _lib.check(rc)
+    return df, dbias, dg, db
 
 
 # --------------------------------------------------------------------------------------------

@@ -393,6 +393,87 @@ def test_conv_stem_kernel(gpu, case):
         L.xm_debug_force_conv_stem(old)
 
 
+STEM_BNP_CASES = [  # H, W, N, K, FH, FW, stride, pad, train, with conv bias
+    (512, 60, 2, 96, 7, 7, 2, 1, True, True),                       # the student's conv1 -> bn1 -> relu1 -> pool1, short clips
+    (512, 42, 3, 96, 7, 7, (2, 2), [1, 1, 1, 2], True, False),      # tiles straddle columns AND samples, ragged last tile
+    (512, 44, 2, 80, 7, 7, 2, 1, False, True),                      # fewer filters than the 96-row tile, test-mode moments
+    (260, 37, 2, 96, 5, 5, 1, 2, True, True),                       # unit stride: 260 x 37 outputs, odd pooled width
+]
+
+
+@pytest.mark.parametrize("case", STEM_BNP_CASES)
+def test_conv_stem_wgrad_through_bnorm_relu_pool(gpu, case):
+    """xm_nnconv_backward_filter_bnrelupool (conv_stem_wgrad_bnp_kernel): the first layer's filter / bias derivative and
+    the bnorm's dg / db straight from the POOLED derivative -- the bnorm's DZDX is rebuilt per element inside the kernel
+    and never written.  Against the oracle's composition vl_nnconv <- vl_nnbnorm <- vl_nnrelu <- vl_nnpool (fp64
+    accumulate) and against the two separate HIP calls.  The inputs plant window maxima on the first / last rows and
+    columns of the first / last planes (the loads of the routing operands touch both ends of the pooled tensors), and
+    on equal values (first-maximum routing)."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, N, K, FH, FW, stride, pad, train, has_bias = case
+    rng = np.random.default_rng(H + 5 * W + K + FH + int(train))
+    x, f, b = rnd(rng, H, W, 1, N), O.F(rng.standard_normal((FH, FW, 1, K)) * 0.2), rnd(rng, K)
+    if not has_bias:
+        b = O.F(np.zeros(K))
+    y = O.vl_nnconv(x, f, b, stride=stride, pad=pad, acc64=True)
+    Ho, Wo = y.shape[:2]
+    assert Ho % 2 == 0 and (Ho * Wo) % 4 == 0 and Ho >= 128
+    # planted maxima: corners of the first and of the last plane, last covered row / column, and a plateau
+    big = float(np.abs(y).max()) * 4 + 1
+    pHo, pWo = (Ho - 3) // 2 + 1, (Wo - 3) // 2 + 1
+    for (c, n) in ((0, 0), (K - 1, N - 1)):
+        y[0, 0, c, n] = big
+        y[2 * (pHo - 1) + 2, 2 * (pWo - 1) + 2, c, n] = big      # last row / column any window covers
+        y[2 * (pHo - 1) + 2, 0, c, n] = big
+        y[0, 2 * (pWo - 1) + 2, c, n] = big
+        y[10:13, 6:9, c, n] = big * 0.5                           # plateau: the FIRST maximum of each window wins
+    g, bb = O.F(rng.uniform(0.5, 1.5, K) * rng.choice([-1, 1], K)), rnd(rng, K)
+    mom = None if train else O.F(np.stack([rng.standard_normal(K) * 0.3, rng.uniform(0.5, 1.5, K)], 1))
+    yb, mref = O.vl_nnbnorm(y, g, bb, moments=mom, acc64=True)
+    yr = np.maximum(yb, 0)
+    yp = O.vl_nnpool(yr, [3, 3], stride=2, pad=0, method="max")
+    dz = rnd(rng, *yp.shape)
+    dyr = O.vl_nnpool(yr, [3, 3], dz, stride=2, pad=0, method="max")
+    dx_ref, dg_ref, db_ref, _ = O.vl_nnbnorm(y, g, bb, dyr * (yb > 0), moments=mom, acc64=True)
+    _, df_ref, dbias_ref = O.vl_nnconv(x, f, b, dx_ref, stride=stride, pad=pad, acc64=True, no_der_data=True)
+
+    xd, yd = vl.from_numpy(x), vl.from_numpy(y)
+    gd, bd = vl.from_numpy(g.reshape(K, 1)), vl.from_numpy(bb.reshape(K, 1))
+    md = None if mom is None else vl.from_numpy(mom)
+    ypd, am, mo = vl.bnorm_relu_pool(yd, gd, bd, [3, 3], stride=2, pad=0, moments=md)
+    close(vl.to_numpy(ypd), yp, what="pooled forward")
+    dzd = vl.from_numpy(dz)
+    res, names = _kernels_run(L, lambda: vl.conv_backward_filter_bnrelupool(
+        xd, (FH, FW, 1, K), yd, gd, bd, mo, am, ypd, dzd, [3, 3], stride=stride, pad=pad, pool_stride=2, pool_pad=0,
+        train=train, has_bias=has_bias))
+    assert res is not None, "the fused kernel must cover this geometry"
+    assert any("stem_wgrad_bnp" in n for n in names), names
+    df, dbias, dg, db = res
+    # the two separate calls (bnorm + relu + pool backward writes DX, the convolution's backward reads it)
+    dx2, dg2, db2 = vl.bnorm_relu_pool_backward(yd, gd, bd, mo, am, dzd, [3, 3], stride=2, pad=0, train=train, y_pool=ypd)
+    close(vl.to_numpy(dx2), dx_ref, what="unfused dx")
+    _, df2, dbias2 = vl.vl_nnconv(xd, vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), dx2, stride=stride, pad=pad,
+                                  no_der_data=True)
+    scale = max(1.0, float(np.abs(df_ref).max()))
+    close(vl.to_numpy(df2), df_ref, what="unfused filter derivative")
+    close(vl.to_numpy(df), df_ref, what="fused filter derivative")
+    assert np.abs(vl.to_numpy(df) - vl.to_numpy(df2)).max() <= 2e-5 * scale      # same decisions, same formula
+    close(vl.to_numpy(dg).ravel(), dg_ref, what="fused dg")
+    close(vl.to_numpy(db).ravel(), db_ref, what="fused db")
+    assert np.array_equal(vl.to_numpy(dg), vl.to_numpy(dg2)) and np.array_equal(vl.to_numpy(db), vl.to_numpy(db2))
+    if has_bias:
+        # sum of DX over pixels and samples: exactly zero in exact arithmetic for a train-mode bnorm, i.e. pure round-off
+        # of ~1e5 ... 1e6 terms in both implementations -- compared on the scale of sum |DX|
+        ref = dx_ref.astype(np.float64).sum((0, 1, 3))
+        mag = np.abs(dx_ref.astype(np.float64)).sum((0, 1, 3)).max()
+        assert np.abs(vl.to_numpy(dbias).ravel() - ref).max() <= 2e-6 * max(1.0, mag), "fused conv bias derivative"
+        close(vl.to_numpy(dbias2).ravel(), dbias_ref, 2e-4, what="unfused conv bias derivative")
+    # shapes the fused kernel does not cover come back as None (the caller makes the two calls)
+    assert vl.conv_backward_filter_bnrelupool(xd, (FH, FW, 1, K), yd, gd, bd, mo, am, ypd, dzd, [3, 3], stride=stride,
+                                              pad=pad, pool_stride=2, pool_pad=[0, 1, 0, 1], train=train) is None
+
+
 @pytest.mark.parametrize("N,variant", [(3, 1), (3, 3), (16, 3), (16, 1)])
 def test_conv_halo_strided_dgrad(gpu, N, variant):
     """dgrad of a 5 x 5 / stride-2 convolution (the student's conv2): four stride-parity classes with 3x3, 3x2, 2x3 and
