@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -247,6 +247,16 @@ int xm_scale_axpy(const float *x, int HW, int CN, const float *a, const float *r
 int xm_scale_backward(const float *x, int HW, int CN, const float *a, const float *dzdy,
                       float *dx_out, float *da_out, void *stream);
 
+/* ---- vl_nndropout (dagnn.DropOut, inserted behind fc6 / fc7 by emoVoxZoo.m:116-135,272-277 when opts.dropout > 0) ----
+ * [Y, MASK] = vl_nndropout(X, 'rate', r):  MASK = (u >= r) / (1 - r), u ~ U[0, 1), Y = MASK .* X.  MATLAB's random
+ * stream cannot be reproduced; the mask comes from a stateless Philox4x32-10 stream: key = seed, counter = element
+ * index / 4 + offset (four elements per counter).  The host advances `offset` by ceil(n / 4) per call so that masks
+ * never repeat within a run.  mask_out (size of X, single, values 0 or 1 / (1 - r)) may be NULL. */
+int xm_nndropout_forward(const float *x, size_t n, float rate, unsigned long long seed, unsigned long long offset,
+                         float *y, float *mask_out, void *stream);
+/* Y = X .* MASK: DZDX = vl_nndropout(X, DZDY, 'mask', MASK), and the forward call with a given mask */
+int xm_nndropout_apply(const float *x, const float *mask, size_t n, float *y, void *stream);
+
 /* ---- losses --------------------------------------------------------------------------------
  * vl_nnsoftmaxt(X, 'temperature', T): softmax(X / T) along dim 3; X is HW x C x N */
 int xm_nnsoftmaxt(const float *x, int HW, int C, int N, float temperature, float *y, void *stream);
@@ -315,6 +325,11 @@ int xm_comm_destroy(void);
 /* ---- batch-provider arithmetic (device side of getBatchEmoVoxCeleb / getImageBatch) ---------
  * getBatchEmoVoxCeleb.m:164-169: per-frequency-row mean / unbiased std over time; H x W x 1 x N */
 int xm_spec_rownorm(const float *spec, int H, int W, int N, float *out, void *stream);
+/* z = resample(zo, p, q) of the speed-perturbation branch (getBatchEmoVoxCeleb.m:102-108, transformation 'S'; MATLAB
+ * Signal Processing Toolbox [EXT]): y[j] = sum_k h[(j + delay) q - k p] x[k], j = 0 .. Ly - 1 -- upfirdn(x, h, p, q)
+ * with the filter delay removed.  The host designs h (Kaiser-windowed ideal low-pass, batch.resample_design restates
+ * the toolbox's recipe) and passes it with p, q already reduced by their gcd. */
+int xm_resample(const float *x, int Lx, const float *h, int Lh, int p, int q, int delay, float *y, int Ly, void *stream);
 /* |STFT| from the output of the framing convolution (runSpec of getBatchEmoVoxCeleb.m:162 [EXT VGGVox]):
  * reim is 1 x Wo x 2B x N (channel b = Re of bin b, channel B+b = Im), out is B x Wo x 1 x N with
  * out(b, j, 1, n) = sqrt(Re^2 + Im^2).  The framing/windowing/pre-emphasis/DFT itself is one

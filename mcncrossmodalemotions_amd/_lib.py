@@ -68,6 +68,8 @@ SIGNATURES = {
                                     [c_fp, c_fp, c_fp, _vp],
     "xm_nnbnorm_relu_pool_backward": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, _i] + [_i] * 8 +
                                      [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_nndropout_forward": [c_fp, _sz, _f, C.c_ulonglong, C.c_ulonglong, c_fp, c_fp, _vp],
+    "xm_nndropout_apply": [c_fp, c_fp, _sz, c_fp, _vp],
     "xm_nnrelu": [c_fp, _sz, _f, c_fp, c_fp, _vp],
     "xm_nnsigmoid": [c_fp, _sz, c_fp, c_fp, _vp],
     "xm_sum2": [c_fp, c_fp, _sz, _i, c_fp, _vp],
@@ -90,6 +92,7 @@ SIGNATURES = {
     "xm_comm_destroy": [],
     "xm_spec_rownorm": [c_fp, _i, _i, _i, c_fp, _vp],
     "xm_spec_magnitude": [c_fp, _i, _i, _i, c_fp, _vp],
+    "xm_resample": [c_fp, _i, c_fp, _i, _i, _i, _i, c_fp, _i, _vp],
     "xm_aggregate_logits": [c_fp, _i, _i, c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],
     "xm_max_label": [c_fp, _i, _i, c_fp, _vp],
     "xm_class_stats": [c_fp, c_fp, _i, _i, c_fp, c_fp, _vp],

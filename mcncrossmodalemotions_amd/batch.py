@@ -9,6 +9,8 @@ shapes the tensors the hot path consumes, fed from seeded synthetic sources:
     time2idx + logit slicing     getBatchEmoVoxCeleb.m:145-158,210-214
     aggregation (max | mean)     getBatchEmoVoxCeleb.m:179-188      -> HIP xm_aggregate_logits
     per-row normalisation ('I')  getBatchEmoVoxCeleb.m:164-169      -> HIP xm_spec_rownorm
+    speed perturbation ('S')     getBatchEmoVoxCeleb.m:102-108,217-245 -> HIP xm_resample (filter designed on the host)
+    additive noise ('N')         getBatchEmoVoxCeleb.m:123-135      -> HIP xm_scale_axpy (z + Nratio * y)
     target selection + maxLabel  getBatchEmoVoxCeleb.m:30-32
     face normalisation           fetch_emovoxceleb_imdb.m:176-193   -> HIP xm_normalize_face
 """
@@ -81,6 +83,43 @@ def runSpec(z, audio=None):
     return vl.spec_magnitude(reim)
 
 
+def findSettings(transformation):
+    """[chspeed, inputnorm, noisy] = findSettings(transformation, opts) -- getBatchEmoVoxCeleb.m:217-245: 'S' = speed
+    perturbation, 'I' = per-row input normalisation, 'N' = additive noise; 'v' (validation) switches S and N off."""
+    isVal = "v" in transformation
+    return ("S" in transformation and not isVal), ("I" in transformation), ("N" in transformation and not isVal)
+
+
+def resample_design(p, q, N=10, beta=5.0):
+    """Filter of y = resample(x, p, q) [EXT: MATLAB Signal Processing Toolbox, called at getBatchEmoVoxCeleb.m:108;
+    restated from its documented recipe]: p, q reduced by their gcd; h = firls(2 N max(p, q), [0 2fc 2fc 1], [1 1 0 0])
+    .* kaiser(L, 5) with fc = 1 / (2 max(p, q)) -- with a zero-width transition band the least-squares design IS the
+    truncated ideal low-pass 2 fc sinc(2 fc (n - (L-1)/2)) -- scaled to p * h / sum(h); zeros are put in front so that
+    the delay is a whole number of OUTPUT samples, which is then dropped.  Returns (h float64, p, q, delay); the output
+    has ceil(Lx p / q) samples."""
+    g = math.gcd(int(p), int(q))
+    p, q = int(p) // g, int(q) // g
+    pqmax = max(p, q)
+    fc = 0.5 / pqmax
+    L = 2 * N * pqmax + 1
+    n = np.arange(L, dtype=np.float64) - (L - 1) / 2
+    h = 2 * fc * np.sinc(2 * fc * n) * np.kaiser(L, beta)
+    h = p * h / h.sum()
+    Lhalf = (L - 1) / 2
+    nz = int(math.floor(q - (Lhalf % q)))
+    h = np.concatenate([np.zeros(nz), h])
+    delay = int(math.floor(math.ceil(Lhalf + nz) / q))
+    return h, p, q, delay
+
+
+def resample(x, p, q):
+    """z = resample(zo, p, q) on the device (one clip, 1-D tensor)."""
+    h, p, q, delay = resample_design(p, q)
+    Ly = -(-int(x.numel()) * p // q)
+    hd = torch.from_numpy(h.astype(np.float32)).to(x.device)
+    return vl.resample(x.contiguous(), hd, p, q, delay, Ly)
+
+
 class SyntheticEmoVoxImdb:
     """Stand-in for the imdb of fetch_emovoxceleb_imdb: per-track wav length (samples) and the
     cached teacher logits imdb.wavLogits{i} (F_i x 8 single, one row per sampled face frame)."""
@@ -108,6 +147,18 @@ class SyntheticEmoVoxImdb:
             g.manual_seed(self.seed * 100003 + int(ii))
             cache[ii] = torch.randn(int(self.num_samples[ii]), generator=g, device=device, dtype=torch.float32) * 0.1
         return cache[ii]
+
+    # meta.noise of the reference (noisedir with `noisenum` wav files of `noiselen` samples, mixing volume `noisevol`,
+    # getBatchEmoVoxCeleb.m:125-133): a seeded synthetic bank
+    noisenum, noiselen, noisevol = 4, 20 * 16000, 0.3
+
+    def device_noise(self, ir, device):
+        cache = self.__dict__.setdefault("_noise", {})
+        if ir not in cache:
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed * 7919 + 1000003 + int(ir))
+            cache[ir] = torch.randn(self.noiselen, generator=g, device=device, dtype=torch.float32) * 0.05
+        return cache[ir]
 
     def device_logits(self, device):
         """all tracks' logits concatenated (F_total x E) on the device + row offsets."""
@@ -155,23 +206,62 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
     N = len(batch)
     H, W = imageSize
     audSamp = aud_samples(W)
+    chspeed, _, noisy = findSettings(transformation)
+    if (chspeed or noisy) and not (use_wav and spec_source is None):
+        raise ValueError("transformations 'S' / 'N' act on the waveform: they need use_wav=True")
     logits, offs = imdb.device_logits(device)
     first = np.zeros(N, np.int32)
     last = np.zeros(N, np.int32)
     crops = []
     for k, ii in enumerate(batch):
-        # getBatchEmoVoxCeleb.m:81-89: no clip of the dataset is longer than DATASET_LIMIT = 19.9 s; the sample count
-        # is thresholded accordingly (the cached teacher logits end there too)
-        wr, s, e = crop_window(int(imdb.num_samples[ii]), audSamp, imdb.fs, imdb.wavLogits[ii].shape[0], rng,
-                               fixedSegments, None if timeOffsets is None else timeOffsets[k])
-        crops.append((ii, wr - 1))        # 0-based slice start of audioread(audfile, [wr wr+audSamp-1])
+        total, rows = int(imdb.num_samples[ii]), imdb.wavLogits[ii].shape[0]
+        speedR = audSampR = None
+        if chspeed and not fixedSegments:
+            # :102-108 -- draw order as upstream: speed first, then the crop offset; the window read is audSampR long
+            # while the logit rows still follow [wr, wr + audSamp) (:141-142 use audSamp)
+            total = min(total, int(19.9 * imdb.fs))
+            speedR = 0.95 + float(rng.random()) * 0.1
+            audSampR = int(round(audSamp * speedR))
+            wd = total - audSampR
+            if wd < 1:
+                raise ValueError("clip %d is shorter than the speed-perturbed window (randi(wd) fails upstream, :106)" % ii)
+            wr = int(rng.integers(1, wd + 1))
+            s = time2idx(wr / imdb.fs)
+            e = min(time2idx((wr + audSamp - 1) / imdb.fs), int(rows))
+        else:
+            # getBatchEmoVoxCeleb.m:81-89: no clip of the dataset is longer than DATASET_LIMIT = 19.9 s; the sample
+            # count is thresholded accordingly (the cached teacher logits end there too)
+            wr, s, e = crop_window(total, audSamp, imdb.fs, rows, rng, fixedSegments,
+                                   None if timeOffsets is None else timeOffsets[k])
+        mix = None
+        if noisy:                                                       # :123-135, draw order Nir, Nwr, Nratio
+            nz = (-(-audSampR * int(round(imdb.fs / speedR)) // imdb.fs)) if speedR else int(round(audSamp))
+            mix = (int(rng.integers(1, imdb.noisenum + 1)), int(rng.integers(1, imdb.noiselen - nz + 1)),
+                   float(rng.random()) * imdb.noisevol)
+        crops.append((ii, wr - 1, speedR, audSampR, mix))   # 0-based slice start of audioread(audfile, [wr ...])
         first[k], last[k] = offs[ii] + s, offs[ii] + e
     if spec_source is None and use_wav:
         L = int(round(audSamp))
         z = torch.zeros((N, L), dtype=torch.float32, device=device)      # storage of the L x N mat
-        for k, (ii, wr) in enumerate(crops):
-            w = imdb.device_wav(ii, device)[wr:wr + L]
+        for k, (ii, wr, speedR, audSampR, mix) in enumerate(crops):
+            if speedR is not None:
+                zo = imdb.device_wav(ii, device)[wr:wr + audSampR]
+                w = resample(zo, int(round(imdb.fs / speedR)), imdb.fs)   # z = resample(zo, round(fs / speedR), fs)
+                if abs(int(w.numel()) - L) > 160:
+                    raise RuntimeError("resample produced %d samples for a window of %d" % (int(w.numel()), L))
+                w = w[:L]        # (the spectrogram width only depends on floor((len - 400) / 160): +-1 sample is immaterial)
+            else:
+                w = imdb.device_wav(ii, device)[wr:wr + L]
             z[k, :w.numel()].copy_(w)                                    # zero padding when short (:117)
+            if mix is not None:
+                nir, nwr, ratio = mix
+                nzlen = int(w.numel())
+                y = imdb.device_noise(nir, device)[nwr - 1:nwr - 1 + nzlen]
+                a = vl.mat_empty(1, 1, 1, 1, device=device)
+                a.fill_(ratio)
+                zk = z[k, :nzlen]
+                col = lambda t: t.reshape(1, 1, 1, -1).permute(3, 2, 1, 0)     # noqa: E731  (L x 1 x 1 x 1 mat view)
+                zk.copy_(vl.scale_axpy(col(y), a, col(zk)).permute(3, 2, 1, 0).reshape(-1))   # z = z + y .* Nratio (:134)
         spec_source = runSpec(z.t(), {"fs": imdb.fs})
         if int(spec_source.shape[1]) != W:
             raise RuntimeError("runSpec produced %d frames, expected %d" % (int(spec_source.shape[1]), W))

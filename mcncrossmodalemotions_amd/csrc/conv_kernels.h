@@ -1736,9 +1736,10 @@ conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
   // Measured on the way (whole chain at 32 spectrograms, this mapping: 373 ... 385 us against 482 for the two separate
   // passes; the sums stage is ~60 us of both): pooled loads removed -110 us, decode arithmetic removed -30 us -- the
   // kernel is bound by the NUMBER of vector-memory instructions (~16 clocks of the CU's address path each: 96 pooled + 12
-  // + 3 per wave and tile), not by bytes, cache lines or latency: touching the pooled lines one phase early cost +90 us,
-  // a one-stride-cell-per-lane mapping (half the cache lines per instruction, 24 instead of 12 x loads) +50 us, and two
-  // decode variants behind a wave-uniform branch +50 us.
+  // + 3 per wave and tile), not by bytes or latency: touching the pooled lines one phase early (3 more instructions per
+  // phase, counted by the compiler or not) cost +80 us, a one-stride-cell-per-lane mapping (half the cache lines per
+  // pooled instruction, but 24 instead of 12 x loads) +50 us, two decode variants behind a wave-uniform branch +50 us,
+  // a streaming cache policy on the x loads nothing.
   struct Prod {            // per lane and tile
     unsigned xoff;         // byte offset of x at (row lc, the lane's pixel quad)
     bool in;               // the quad exists (quads never straddle NP: NP % 4 == 0)

@@ -293,6 +293,44 @@ __global__ void scale_kernel(float *__restrict__ x, size_t n, float a) {
   if (i < n) x[i] *= a;
 }
 
+// ---- vl_nndropout (emoVoxZoo.m:116-135,272-277: dagnn.DropOut behind fc6 / fc7 when opts.dropout > 0) -------------
+// mask = (u >= rate) / (1 - rate), u ~ U[0, 1); Y = mask .* X.  MATLAB's generator stream cannot be reproduced, so the
+// stream is our own and stateless: Philox4x32-10 keyed by `seed`, counter = (element index / 4 + offset): the same
+// (seed, offset) gives the same mask on any launch geometry; a host advances `offset` by ceil(n / 4) per call.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1,
+                   n3 = (unsigned)p0;
+    c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__global__ void __launch_bounds__(256)
+dropout_fwd_kernel(const float *__restrict__ x, size_t n, float rate, float scale, unsigned long long seed,
+                   unsigned long long offset, float *__restrict__ y, float *__restrict__ mask) {
+  const size_t g = blockIdx.x * (size_t)256 + threadIdx.x;   // one counter = four elements
+  if (4 * g >= n) return;
+  const unsigned long long ctr = g + offset;
+  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const size_t i = 4 * g + e;
+    if (i >= n) break;
+    const float u = (float)(c[e] >> 8) * (1.0f / 16777216.0f);   // 24 random bits: exact in fp32, in [0, 1)
+    const float m = u >= rate ? scale : 0.f;
+    if (mask) mask[i] = m;
+    y[i] = m * x[i];
+  }
+}
+__global__ void mul_kernel(const float *__restrict__ x, const float *__restrict__ m, size_t n, float *__restrict__ y) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = m[i] * x[i];
+}
+
 __global__ void average_kernel(float *__restrict__ w, const float *__restrict__ der, size_t n,
                                float lr, float inv_workers) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -544,6 +582,26 @@ int xm_scale_f32(float *x, size_t n, float a, void *stream) {
   return XM_OK;
 }
 
+int xm_nndropout_forward(const float *x, size_t n, float rate, unsigned long long seed, unsigned long long offset,
+                         float *y, float *mask_out, void *stream) {
+  if (n == 0) return XM_OK;
+  if (!x || !y) return fail(XM_EINVAL, "vl_nndropout: NULL tensor");
+  if (!(rate >= 0.f && rate < 1.f)) return fail(XM_EINVAL, "vl_nndropout: rate must be in [0, 1)");
+  const size_t groups = (n + 3) / 4;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     rate, 1.f / (1.f - rate), seed, offset, y, mask_out);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_nndropout_apply(const float *x, const float *mask, size_t n, float *y, void *stream) {
+  if (n == 0) return XM_OK;
+  if (!x || !mask || !y) return fail(XM_EINVAL, "vl_nndropout: NULL tensor");
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, n, y);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 int xm_average_update(float *w, const float *der, size_t n, float lr, float nworkers, void *stream) {
   ++xm::g_param_version;
   if (n == 0) return XM_OK;
@@ -586,6 +644,35 @@ int xm_spec_magnitude(const float *reim, int Wo, int B, int N, float *out, void 
   if (!reim || !out) return fail(XM_EINVAL, "spec_magnitude: NULL tensor");
   hipLaunchKernelGGL(spec_magnitude_kernel, dim3((Wo + 31) / 32, (B + 31) / 32, N), dim3(256), 0,
                      (hipStream_t)stream, reim, out, Wo, B, N);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+// ---- resample (chspeed branch of the batch provider, getBatchEmoVoxCeleb.m:102-108) --------------------------------
+// y[j] = sum_k h[(j + delay) q - k p] x[k]: the polyphase form of upfirdn(x, h, p, q) with the filter delay removed
+// (MATLAB resample [EXT Signal Processing Toolbox]); ~2 * 10 + 1 taps per output, one thread per output sample.
+__global__ void __launch_bounds__(256)
+resample_kernel(const float *__restrict__ x, int Lx, const float *__restrict__ h, int Lh, int p, int q, int delay,
+                float *__restrict__ y, int Ly) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Ly) return;
+  const long long t0 = (long long)(j + delay) * q;
+  // k with 0 <= t0 - k p < Lh and 0 <= k < Lx
+  long long klo = (t0 - (Lh - 1) + p - 1) / p;
+  if (t0 - (Lh - 1) < 0) klo = 0;
+  long long khi = t0 / p;
+  if (khi > Lx - 1) khi = Lx - 1;
+  float acc = 0.f;
+  for (long long k = klo; k <= khi; ++k) acc = fmaf(h[t0 - k * p], x[k], acc);
+  y[j] = acc;
+}
+
+int xm_resample(const float *x, int Lx, const float *h, int Lh, int p, int q, int delay, float *y, int Ly, void *stream) {
+  if (Lx <= 0 || Lh <= 0 || p <= 0 || q <= 0 || delay < 0 || Ly < 0) return fail(XM_EINVAL, "resample: bad sizes");
+  if (Ly == 0) return XM_OK;
+  if (!x || !h || !y) return fail(XM_EINVAL, "resample: NULL tensor");
+  hipLaunchKernelGGL(resample_kernel, dim3((Ly + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, Lx, h, Lh, p, q, delay,
+                     y, Ly);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

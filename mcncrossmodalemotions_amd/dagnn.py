@@ -250,20 +250,31 @@ class SoftMax(Layer):
 
 
 class DropOut(Layer):
-    """dagnn.DropOut -- identity in test mode; training-time masks are not built (dropout is
-    off by default in the reference: emoVoxZoo.m:18)."""
+    """dagnn.DropOut [EXT]: identity in test mode; in training mode Y = MASK .* X with a fresh mask per call
+    (vl_nndropout), the backward pass multiplies by the same mask.  emoVoxZoo.m:116-135,272-277 inserts it behind fc6
+    and fc7 when opts.dropout > 0.  Masks come from the library's stateless Philox stream: `seed` per layer, the
+    counter offset advances by ceil(numel / 4) per call."""
 
-    def __init__(self, rate=0.5):
+    def __init__(self, rate=0.5, seed=0):
         super().__init__()
         self.rate = rate
+        self.seed = seed
+        self.frozen = False
+        self.mask = None
+        self._offset = 0
 
     def forward(self, inputs, params):
-        if self.net is not None and self.net.mode != "test" and self.rate > 0:
-            raise NotImplementedError("dropout > 0 in training mode is outside the built path")
-        return [inputs[0]]
+        if self.net is None or self.net.mode == "test" or self.frozen or self.rate <= 0:
+            self.mask = None
+            return [inputs[0]]
+        y, self.mask = vl.vl_nndropout(inputs[0], rate=self.rate, seed=self.seed, offset=self._offset)
+        self._offset += (int(inputs[0].numel()) + 3) // 4
+        return [y]
 
     def backward(self, inputs, params, derOutputs):
-        return [derOutputs[0]], []
+        if self.mask is None:
+            return [derOutputs[0]], []
+        return [vl.vl_nndropout(inputs[0], derOutputs[0], mask=self.mask)], []
 
 
 class LossBase(Layer):
@@ -503,6 +514,20 @@ class DagNN:
         for p in params:
             if p not in self.params:
                 self.params[p] = Param(p)
+        self.rebuild()
+        return self
+
+    def insertLayerAfter(self, prev, name, block, inputs, outputs, params=()):
+        """addLayer, placed right behind layer `prev` (the layer list is the execution order here; MatConvNet's
+        dagnn re-derives the order from the graph, so net.addLayer + setLayerInputs suffice there)"""
+        self.addLayer(name, block, inputs, outputs, params)
+        rec = self.layers.pop()
+        self.layers.insert(self.getLayerIndex(prev) + 1, rec)
+        self.rebuild()
+        return self
+
+    def setLayerInputs(self, name, inputs):
+        self.layers[self.getLayerIndex(name)].inputs = [inputs] if isinstance(inputs, str) else list(inputs)
         self.rebuild()
         return self
 

@@ -425,6 +425,25 @@ def vl_nnrelu(x, dzdy=None, leak=0.0):
     return y
 
 
+def vl_nndropout(x, dzdy=None, rate=0.5, mask=None, seed=0, offset=0):
+    """[Y, MASK] = vl_nndropout(X, 'rate', r) / Y = vl_nndropout(X, 'mask', M) / DZDX = vl_nndropout(X, DZDY, 'mask', M).
+    Without a mask one is drawn from the library's stateless Philox stream (seed, offset: include/xmodal.h)."""
+    x = _chk(x, "X")
+    y = mat_empty(*x.shape, device=x.device)
+    if dzdy is not None:
+        if mask is None:
+            raise ValueError("vl_nndropout: the backward call needs the forward call's mask")
+        _lib.check(_L().xm_nndropout_apply(_ptr(_chk(dzdy, "DZDY")), _ptr(_chk(mask, "MASK")), x.numel(), _ptr(y), _stream()))
+        return y
+    if mask is not None:
+        _lib.check(_L().xm_nndropout_apply(_ptr(x), _ptr(_chk(mask, "MASK")), x.numel(), _ptr(y), _stream()))
+        return y, mask
+    mask = mat_empty(*x.shape, device=x.device)
+    _lib.check(_L().xm_nndropout_forward(_ptr(x), x.numel(), float(rate), int(seed), int(offset), _ptr(y), _ptr(mask),
+                                         _stream()))
+    return y, mask
+
+
 def vl_nnsigmoid(x, dzdy=None):
     x = _chk(x, "X")
     y = mat_empty(*x.shape, device=x.device)
@@ -625,6 +644,14 @@ def spec_magnitude(reim):
     out = mat_empty(C2 // 2, Wo, 1, N, device=reim.device)
     _lib.check(_L().xm_spec_magnitude(_ptr(reim), Wo, C2 // 2, N, _ptr(out), _stream()))
     return out
+
+
+def resample(x, h, p, q, delay, Ly):
+    """y = upfirdn(x, h, p, q) without the filter delay, Ly samples (xm_resample); x, h: 1-D device tensors."""
+    y = torch.empty(int(Ly), dtype=torch.float32, device=x.device)
+    _lib.check(_L().xm_resample(_ptr(x), int(x.numel()), _ptr(h), int(h.numel()), int(p), int(q), int(delay), _ptr(y),
+                                int(Ly), _stream()))
+    return y
 
 
 def aggregate_logits(frame_logits, first, last, agg="max"):

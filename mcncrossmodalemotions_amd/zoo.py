@@ -269,8 +269,24 @@ def prepareFromDagNN(net, numOutputs, seed=0):
     return net
 
 
-def configureForRegression(net, lossType, numOutputs):
-    """emoVoxZoo.m:137-177."""
+def insert_dropout(net, prev, nxt, rate):
+    """emoVoxZoo.m:272-277: a dagnn.DropOut named <prev>_drop between layer `prev` and its consumer `nxt`."""
+    prec = net.layers[net.getLayerIndex(prev)]
+    out = "%s_drop" % prev
+    net.insertLayerAfter(prev, out, dagnn.DropOut(rate=rate, seed=net.getLayerIndex(prev) + 1), prec.outputs, out)
+    nrec = net.layers[net.getLayerIndex(nxt)]
+    net.setLayerInputs(nxt, [out if v == prec.outputs[0] else v for v in nrec.inputs])
+    return net
+
+
+def configureForRegression(net, lossType, numOutputs, dropout=0):
+    """emoVoxZoo.m:105-177 (the dropout layers of :116-135 first, then the loss heads)."""
+    if dropout and dropout > 0 and not any(isinstance(l.block, dagnn.DropOut) for l in net.layers):
+        convs = [l for l in net.layers if isinstance(l.block, dagnn.Conv)]
+        for sel in convs[-3:-1]:                      # convLayers(end-2:end-1): "reduce aggression" (:120)
+            nxt = [l.name for l in net.layers if sel.outputs[0] in l.inputs]
+            assert nxt, "target layer was not found"  # :132
+            insert_dropout(net, sel.name, nxt[0], float(dropout))
     if lossType == "softmaxlog":
         layer, inputs = dagnn.Loss("softmaxlog"), ["prediction", "maxLabel"]
     elif lossType == "hot-cross-ent":
@@ -309,9 +325,9 @@ def updatePooling(net, numSeconds):
 
 
 def emoVoxZoo(modelName="emovoxceleb-student", scratch=1, lossType="hot-cross-ent", numSeconds=4,
-              numOutputs=8, seed=200, width_mult=1.0):
+              numOutputs=8, seed=200, width_mult=1.0, dropout=False):
     """dag = emoVoxZoo(name, 'scratch', 1, 'lossType', 'hot-cross-ent', 'numSeconds', 4,
-    'numOutputs', 8) -- emoVoxZoo.m:1-62 (call site run_distillation.m:125-129)."""
+    'numOutputs', 8, 'dropout', rate) -- emoVoxZoo.m:1-62 (call site run_distillation.m:125-129)."""
     if modelName not in ("emovoxceleb-student", "vggvox-ver", "vggvox-ident"):
         raise ValueError("%s is not a recognised student model" % modelName)
     net = vggvox(1251, width_mult)
@@ -319,7 +335,7 @@ def emoVoxZoo(modelName="emovoxceleb-student", scratch=1, lossType="hot-cross-en
     if scratch:
         prepareFromDagNN(net, numOutputs)
         net.initParams(seed)           # emoVoxZoo.m:54: re-randomise everything
-        configureForRegression(net, lossType, numOutputs)
+        configureForRegression(net, lossType, numOutputs, dropout)
     else:
         prepareFromDagNN(net, numOutputs)
     updatePooling(net, numSeconds)

@@ -37,9 +37,10 @@ def _bn(name, x, y, C, eps, pnames):
     return Layer(name, "bnorm", [x], [y], list(pnames), dict(numChannels=C, epsilon=eps))
 
 
-def vggvox_student(width=300, num_outputs=8, loss="hot-cross-ent"):
+def vggvox_student(width=300, num_outputs=8, loss="hot-cross-ent", dropout=0.0):
     """Appendix B.1 after the surgery of emoVoxZoo.m:187-253 (Loss/SoftMax stripped, 8-way fc8 ->
-    'prediction', input 'data'), configureForRegression (:137-177) and updatePooling (:256-269)."""
+    'prediction', input 'data'), configureForRegression (:105-177, incl. the dagnn.DropOut layers it puts behind
+    fc6 / fc7 when `dropout` > 0, :116-135,272-277) and updatePooling (:256-269)."""
     Ls = []
     x = "data"
     for nm, fh, ci, co, s, p in (("1", 7, 1, 96, 2, 1), ("2", 5, 96, 256, 2, 1), ("3", 3, 256, 384, 1, 1),
@@ -57,12 +58,18 @@ def vggvox_student(width=300, num_outputs=8, loss="hot-cross-ent"):
                             dict(poolSize=[5, 3], stride=(3, 2), pad=(0, 0, 0, 0), method="max")))
             x = "x_mpool5"
     Ls.append(_conv("fc6", x, "x_fc6", (9, 1, 256, 4096), True))
-    Ls.append(_bn("bn6", "x_fc6", "x_bn6", 4096, 1e-4, ["bn6m", "bn6b", "bn6x"]))
+    d6 = d7 = None
+    if dropout and dropout > 0:
+        Ls.append(Layer("fc6_drop", "dropout", ["x_fc6"], ["fc6_drop"], [], dict(rate=float(dropout))))
+        d6, d7 = "fc6_drop", "fc7_drop"
+    Ls.append(_bn("bn6", d6 or "x_fc6", "x_bn6", 4096, 1e-4, ["bn6m", "bn6b", "bn6x"]))
     Ls.append(Layer("relu6", "relu", ["x_bn6"], ["x_relu6"], [], {}))
     Ls.append(Layer("pool6", "pool", ["x_relu6"], ["x_pool6"], [],
                     dict(poolSize=[1, POOL6_WIDTH[width]], stride=(1, 1), pad=(0, 0, 0, 0), method="avg")))
     Ls.append(_conv("fc7", "x_pool6", "x_fc7", (1, 1, 4096, 1024), True))
-    Ls.append(_bn("bn7", "x_fc7", "x_bn7", 1024, 1e-4, ["bn7m", "bn7b", "bn7x"]))
+    if d7:
+        Ls.append(Layer("fc7_drop", "dropout", ["x_fc7"], ["fc7_drop"], [], dict(rate=float(dropout))))
+    Ls.append(_bn("bn7", d7 or "x_fc7", "x_bn7", 1024, 1e-4, ["bn7m", "bn7b", "bn7x"]))
     Ls.append(Layer("relu7", "relu", ["x_bn7"], ["x_relu7"], [], {}))
     Ls.append(_conv("fc8", "x_relu7", "prediction", (1, 1, 1024, num_outputs), True))
     if loss == "hot-cross-ent":      # emoVoxZoo.m:152: temperature hard-coded to 2, logit targets
@@ -217,6 +224,11 @@ def forward(graph, inputs, P, mode="normal", acc64=True, keep=None):
             aux[l.name] = mom
         elif l.type == "relu":
             y = O.vl_nnrelu(ins[0])
+        elif l.type == "dropout":
+            # vl_nndropout(X, 'mask', M): the mask is an INPUT of the pass ('<layer>.mask' in `inputs`); test mode and a
+            # missing mask are the identity (dagnn.DropOut in test mode)
+            m = None if mode == "test" else inputs.get(l.name + ".mask")
+            y = ins[0] if m is None else O.vl_nndropout(ins[0], m)
         elif l.type == "sigmoid":
             y = O.vl_nnsigmoid(ins[0])
         elif l.type == "gpool":
@@ -334,6 +346,9 @@ def backward(graph, V, der_outputs, P, mode="normal", acc64=True, gates=None):
                 add(l.inputs[0], O.vl_nnrelu(ins[0], dz))
         elif l.type == "sigmoid":
             add(l.inputs[0], O.vl_nnsigmoid(ins[0], dz))
+        elif l.type == "dropout":
+            m = None if mode == "test" else V.get(l.name + ".mask")
+            add(l.inputs[0], dz if m is None else O.vl_nndropout(dz, m))
         elif l.type == "gpool":
             add(l.inputs[0], O.vl_nnpool(ins[0], ins[0].shape[:2], dz, method=a["method"]))
         elif l.type == "pool":

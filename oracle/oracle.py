@@ -162,6 +162,32 @@ def vl_nnsigmoid(x, dzdy=None):
     return y
 
 
+def vl_nndropout(x, mask):
+    """Y = vl_nndropout(X, 'mask', M) = M .* X (also the backward call: DZDX = M .* DZDY) [EXT MatConvNet]."""
+    return np.asfortranarray((F(x) * F(mask)).astype(np.float32))
+
+
+def dropout_mask(shape, rate, seed, offset=0):
+    """The mask the PRODUCT draws (include/xmodal.h, xm_nndropout_forward): MATLAB's random stream cannot be
+    reproduced, so there is no reference stream to follow; this restates the library's documented one -- Philox4x32-10,
+    key = seed, counter = (column-major element index / 4 + offset), word e of the block for element 4 g + e,
+    u = (word >> 8) / 2^24, mask = (u >= rate) / (1 - rate) -- so that tests can check it bit for bit."""
+    n = int(np.prod(shape))
+    g = np.arange((n + 3) // 4, dtype=np.uint64) + np.uint64(offset)
+    c = [(g & np.uint64(0xFFFFFFFF)).astype(np.uint64), (g >> np.uint64(32)).astype(np.uint64),
+         np.zeros_like(g), np.zeros_like(g)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    words = np.stack(c, 1).reshape(-1)[:n]
+    u = (words >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    return np.asfortranarray(np.where(u >= np.float32(rate), scale, np.float32(0)).astype(np.float32).reshape(shape, order="F"))
+
+
 def sum2(a, b, relu=False):
     a, b = F(a), F(b)
     y = np.zeros(a.shape, np.float32, order="F")
@@ -297,6 +323,42 @@ def run_spec(z, fs=16000, Tw=25, Ts=10, alpha=0.97, nfft=1024):
         fr = np.stack([y[j * Ns:j * Ns + Nw, n] * win for j in range(W)], 1)   # Nw x W
         out[:, :, 0, n] = np.abs(np.fft.fft(fr, nfft, axis=0))[:nfft // 2]
     return out
+
+
+def resample(x, p, q, N=10, beta=5.0):
+    """y = resample(x, p, q) of the speed-perturbation branch (getBatchEmoVoxCeleb.m:108).  [EXT] MATLAB Signal
+    Processing Toolbox -- not in the reference tree, restated from its documented recipe (doubly unpinned, like
+    run_spec): p, q reduced by gcd; h = firls(2 N max(p,q), [0 2fc 2fc 1], [1 1 0 0]) .* kaiser(L, 5), fc = 1/(2 max(p,q))
+    -- a zero-width transition band makes the least-squares design the truncated ideal low-pass --, h <- p h / sum(h),
+    zeros in front so that the delay is a whole number of output samples, y = upfirdn(x, h, p, q) with the delay removed
+    and ceil(Lx p / q) samples kept.  float64 throughout; scipy.signal.resample_poly is the second opinion
+    (tests/test_oracle.py)."""
+    import math
+    x = np.asarray(x, np.float64).ravel()
+    g = math.gcd(int(p), int(q))
+    p, q = int(p) // g, int(q) // g
+    pqmax = max(p, q)
+    fc = 0.5 / pqmax
+    L = 2 * N * pqmax + 1
+    n = np.arange(L, dtype=np.float64) - (L - 1) / 2
+    h = 2 * fc * np.sinc(2 * fc * n) * np.kaiser(L, beta)
+    h = p * h / h.sum()
+    Lhalf = (L - 1) / 2
+    nz = int(math.floor(q - (Lhalf % q)))
+    h = np.concatenate([np.zeros(nz), h])
+    delay = int(math.floor(math.ceil(Lhalf + nz) / q))
+    Lx = x.size
+    Ly = -(-Lx * p // q)
+    y = np.zeros(Ly)
+    t0 = (np.arange(Ly, dtype=np.int64) + delay) * q
+    kmax = int(h.size // p) + 2
+    khi = t0 // p
+    for d in range(kmax):                      # y[j] = sum_k h[t0 - k p] x[k]
+        k = khi - d
+        t = t0 - k * p
+        ok = (k >= 0) & (k < Lx) & (t >= 0) & (t < h.size)
+        y[ok] += h[t[ok]] * x[k[ok]]
+    return y
 
 
 def time2idx(t):

@@ -68,7 +68,9 @@ def forward(net, inputs, params=None, acc64=True, mode=None):
             loss = b.loss if isinstance(b, dagnn.Loss) else "classerror"
             y = np.float32(O.vl_nnloss(ins[0], ins[1], loss=loss))
         elif isinstance(b, dagnn.DropOut):
-            y = ins[0]
+            # vl_nndropout(X, 'mask', M): the mask is an input of the pass ('<layer>.mask'); test mode / no mask = identity
+            m = None if mode == "test" else V.get(l.name + ".mask")
+            y = ins[0] if m is None else O.vl_nndropout(ins[0], m)
         else:
             raise NotImplementedError(type(b))
         V[l.outputs[0]] = y
@@ -135,6 +137,9 @@ def backward(net, V, der_outputs, params=None, acc64=True, mode=None):
             add(l.inputs[0], O.vl_nnloss(ins[0], ins[1], np.asarray(dz, np.float32).ravel(), loss=b.loss))
         elif isinstance(b, dagnn.SoftMax):
             add(l.inputs[0], O.vl_nnsoftmaxt_backward(ins[0], dz, 1.0))
+        elif isinstance(b, dagnn.DropOut):
+            m = None if mode == "test" else V.get(l.name + ".mask")
+            add(l.inputs[0], dz if m is None else O.vl_nndropout(dz, m))
         else:
             raise NotImplementedError(type(b))
     return D, DP

@@ -64,6 +64,48 @@ def test_student_step_matches_oracle(gpu, fuse):
         close(vl.to_numpy(p.value), ref, 1e-5, "sgd " + name)
 
 
+def test_student_step_with_dropout(gpu):
+    """emoVoxZoo(..., 'dropout', 0.5) (emoVoxZoo.m:18,116-135): training-mode dagnn.DropOut behind fc6 and fc7.  The
+    masks the HIP step drew are the documented stream (seed = layer index + 1, offsets advancing per call), and with
+    those masks as inputs the oracle reproduces prediction, loss and every parameter derivative; a second step draws
+    different masks; test mode is the identity."""
+    from mcncrossmodalemotions_amd import dagnn, vl, zoo
+    rng = np.random.default_rng(23)
+    N, W = 4, 100
+    net = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=5, dropout=0.5)
+    drops = [l for l in net.layers if isinstance(l.block, dagnn.DropOut)]
+    assert [l.name for l in drops] == ["fc6_drop", "fc7_drop"]
+    P0 = oracle_net.host_params(net)
+    data, lgo, lab = _student_inputs(rng, W, N)
+    net.pack_params()
+    inputs = ["data", vl.from_numpy(data), "logitTarget", vl.from_numpy(lgo), "maxLabel", vl.from_numpy(lab)]
+    net.vars["prediction"].precious = True
+    net.mode = "normal"
+    net.eval(inputs, ["objective", 1])
+    masks = {}
+    for l in drops:
+        m = vl.to_numpy(l.block.mask)
+        assert np.array_equal(m, O.dropout_mask(m.shape, 0.5, l.block.seed, 0)), l.name
+        masks[l.name + ".mask"] = m
+    ins = dict({"data": data, "logitTarget": lgo, "maxLabel": lab}, **masks)
+    V = oracle_net.forward(net, ins, P0, mode="normal")
+    _, DP = oracle_net.backward(net, V, {"objective": np.float32(1)}, P0, mode="normal")
+    close(vl.to_numpy(net.vars["prediction"].value), V["prediction"], 1e-4, "prediction")
+    close(vl.to_numpy(net.vars["objective"].value).ravel()[0], V["objective"], 1e-5, "objective")
+    for name, ref in DP.items():
+        close(vl.to_numpy(net.params[name].der).reshape(ref.shape, order="F"), ref, 2e-4, "der " + name)
+    first = {l.name: vl.to_numpy(l.block.mask) for l in drops}
+    net.eval(inputs, ["objective", 1])
+    for l in drops:
+        m = vl.to_numpy(l.block.mask)
+        assert not np.array_equal(m, first[l.name])
+        assert np.array_equal(m, O.dropout_mask(m.shape, 0.5, l.block.seed, (m.size + 3) // 4))
+    net.mode = "test"
+    net.eval(inputs)
+    Vt = oracle_net.forward(net, {"data": data, "logitTarget": lgo, "maxLabel": lab}, P0, mode="test")
+    close(vl.to_numpy(net.vars["prediction"].value), Vt["prediction"], 1e-4, "test-mode prediction")
+
+
 def test_pool6_buckets_on_device(gpu):
     """emoVoxZoo.m:258-259: every clip width bucket yields a 1 x 1 x C pool6 output."""
     from mcncrossmodalemotions_amd import vl, zoo
@@ -192,6 +234,71 @@ def test_batch_provider(gpu):
     assert f.shape == (224, 224, 3, 4)
     # the three channels differ only by the mean offset (fetch_emovoxceleb_imdb.m:176-193)
     assert np.abs((f[:, :, 0] - f[:, :, 1]) - (103.8827 - 131.0912)).max() < 1e-3
+
+
+@pytest.mark.parametrize("transformation", ["IS", "IN", "ISN", "ISNv"])
+def test_batch_provider_speed_and_noise_augmentation(gpu, transformation):
+    """getBatchEmoVoxCeleb.m:102-135,217-245: 'S' reads a window of round(audSamp * speedR) samples, speedR = 0.95 +
+    0.1 rand, and resamples it by round(fs / speedR) / fs; 'N' adds Nratio = rand * noisevol times a random stretch of a
+    random noise file; 'v' (validation) switches both off.  The device path (xm_resample with the host-designed filter,
+    xm_scale_axpy, runSpec, row normalisation) against the oracle's float64 composition on the replayed draws; the
+    logit rows follow [wr, wr + audSamp) as upstream."""
+    from mcncrossmodalemotions_amd import batch, vl
+    imdb = batch.SyntheticEmoVoxImdb(num_tracks=6, seed=9, min_seconds=2.5, max_seconds=6.0)
+    idx = [1, 4, 5]
+    W = 100
+    aud = batch.aud_samples(W)
+    L = int(round(aud))
+    rng = np.random.default_rng(77)
+    inp = batch.getBatchEmoVoxCeleb(imdb, idx, imageSize=(512, W), rng=rng, use_wav=True, transformation=transformation)
+    d = {inp[i]: inp[i + 1] for i in range(0, len(inp), 2)}
+    im, lg = vl.to_numpy(d["data"]), vl.to_numpy(d["logitTarget"]).reshape(8, len(idx))
+    chspeed, _, noisy = batch.findSettings(transformation)
+    assert (chspeed, noisy) == ("S" in transformation and "v" not in transformation,
+                                "N" in transformation and "v" not in transformation)
+    rng = np.random.default_rng(77)
+    fs = 16000
+    for k, ii in enumerate(idx):
+        total = min(int(imdb.num_samples[ii]), int(19.9 * fs))
+        wav = imdb.device_wav(ii, d["data"].device).cpu().numpy().astype(np.float64)
+        if chspeed:
+            speedR = 0.95 + float(rng.random()) * 0.1
+            audR = int(round(aud * speedR))
+            wr = int(rng.integers(1, total - audR + 1))
+            z = O.resample(wav[wr - 1:wr - 1 + audR], int(round(fs / speedR)), fs)
+            assert abs(z.size - L) <= 1
+            z = np.concatenate([z, np.zeros(max(0, L - z.size))])[:L]
+            nlen = min(-(-audR * int(round(fs / speedR)) // fs), L)
+        else:
+            wd = total - L
+            wr = int(rng.integers(1, wd + 1)) if wd >= 1 else 1
+            z = wav[wr - 1:wr - 1 + L]
+            z = np.concatenate([z, np.zeros(L - z.size)])
+            nlen = L
+        if noisy:
+            nz = (-(-audR * int(round(fs / speedR)) // fs)) if chspeed else L
+            nir, nwr, ratio = int(rng.integers(1, imdb.noisenum + 1)), int(rng.integers(1, imdb.noiselen - nz + 1)), \
+                float(rng.random()) * imdb.noisevol
+            y = imdb.device_noise(nir, d["data"].device).cpu().numpy().astype(np.float64)[nwr - 1:nwr - 1 + nlen]
+            z[:nlen] = z[:nlen] + y * ratio
+        ref = O.spec_rownorm(O.run_spec(z.astype(np.float32)))
+        close(im[:, :, 0, k], ref[:, :, 0, 0], 2e-3, "%s sample %d" % (transformation, k))
+        s_, e_ = O.time2idx(wr / fs), min(O.time2idx((wr + aud - 1) / fs), imdb.wavLogits[ii].shape[0])
+        assert np.abs(lg[:, k] - O.aggregate_logits(imdb.wavLogits[ii], s_, e_, "max")).max() < 1e-6
+    with pytest.raises(ValueError):
+        batch.getBatchEmoVoxCeleb(imdb, idx, imageSize=(512, W), rng=rng, transformation="IS")   # needs the waveform
+
+
+def test_resample_kernel_vs_oracle(gpu):
+    import torch
+    from mcncrossmodalemotions_amd import batch
+    rng = np.random.default_rng(8)
+    for speed, n in ((0.95, 5000), (1.0499, 16384), (1.0, 777)):
+        x = rng.standard_normal(n).astype(np.float32)
+        y = batch.resample(torch.from_numpy(x).cuda(), int(round(16000 / speed)), 16000).cpu().numpy()
+        ref = O.resample(x, int(round(16000 / speed)), 16000)
+        assert y.shape == ref.shape
+        close(y, ref, 1e-5, "resample speed %.4f" % speed)
 
 
 def test_wgrad_side_stream_is_bit_identical(gpu):

@@ -771,6 +771,29 @@ def test_elementwise(gpu):
         close(vl.to_numpy(da), da_ref, 1e-5, "scale da")
 
 
+def test_dropout(gpu):
+    """vl_nndropout (dagnn.DropOut of emoVoxZoo.m:116-135): the mask is bit for bit the documented Philox stream
+    (oracle.dropout_mask; the generator itself is pinned on its published known-answer vector in tests/test_oracle.py),
+    Y = MASK .* X and DZDX = MASK .* DZDY exactly, for sizes that are / are not multiples of four and for several
+    rates, seeds and counter offsets; a given mask is applied as is."""
+    from mcncrossmodalemotions_amd import vl
+    rng = np.random.default_rng(11)
+    for shape, rate, seed, off in (((9, 8, 16, 4), 0.5, 1, 0), ((7, 3, 5, 3), 0.3, 2 ** 40 + 17, 5), ((1, 1, 1024, 32), 0.75, 7, 10 ** 6),
+                                   ((5,), 0.0, 3, 0)):
+        x = rnd(rng, *shape)
+        y, m = vl.vl_nndropout(vl.from_numpy(x), rate=rate, seed=seed, offset=off)
+        mref = O.dropout_mask(shape, rate, seed, off)
+        assert np.array_equal(vl.to_numpy(m), mref), (shape, rate)
+        assert np.array_equal(vl.to_numpy(y), O.vl_nndropout(x, mref))
+        dz = rnd(rng, *shape)
+        dx = vl.vl_nndropout(vl.from_numpy(x), vl.from_numpy(dz), mask=m)
+        assert np.array_equal(vl.to_numpy(dx), O.vl_nndropout(dz, mref))
+        y2, _ = vl.vl_nndropout(vl.from_numpy(x), mask=vl.from_numpy(mref))
+        assert np.array_equal(vl.to_numpy(y2), vl.to_numpy(y))
+    with pytest.raises(Exception):
+        vl.vl_nndropout(vl.from_numpy(rnd(rng, 4, 4)), rate=1.0)
+
+
 def test_losses(gpu):
     from mcncrossmodalemotions_amd import vl
     rng = np.random.default_rng(9)

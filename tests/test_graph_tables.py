@@ -33,6 +33,8 @@ def _describe(rec):
         return "relu", {}
     if isinstance(b, dagnn.Sigmoid):
         return "sigmoid", {}
+    if isinstance(b, dagnn.DropOut):
+        return "dropout", dict(rate=float(b.rate))
     if isinstance(b, dagnn.GlobalPooling):
         return "gpool", dict(method=b.method)
     if isinstance(b, dagnn.Pooling):
@@ -74,6 +76,19 @@ def test_student_graph_equals_oracle_table(width):
     assert_same_graph(net, G.vggvox_student(width))
     for k, v in G.make_params(G.vggvox_student(width), 0).items():
         assert tuple(net.params[k].value.shape) == tuple(v.shape), k
+
+
+def test_student_graph_with_dropout_equals_oracle_table():
+    """emoVoxZoo('dropout', r): configureForRegression puts a dagnn.DropOut behind the outputs of the third-last and
+    second-last convolution -- fc6 and fc7 -- and rewires their consumers (emoVoxZoo.m:116-135,272-277)."""
+    from mcncrossmodalemotions_amd import zoo
+    net = zoo.emoVoxZoo("emovoxceleb-student", scratch=1, lossType="hot-cross-ent", numSeconds=3, dropout=0.5)
+    assert_same_graph(net, G.vggvox_student(300, dropout=0.5))
+    names = [l.name for l in net.layers]
+    assert names.index("fc6_drop") == names.index("fc6") + 1 and names.index("fc7_drop") == names.index("fc7") + 1
+    assert net.layers[names.index("bn6")].inputs == ["fc6_drop"] and net.layers[names.index("bn7")].inputs == ["fc7_drop"]
+    # the default (opts.dropout = false, emoVoxZoo.m:18) has none
+    assert not any(l.type == "dropout" for l in G.vggvox_student(300))
 
 
 @pytest.mark.parametrize("se", [False, True])

@@ -305,3 +305,65 @@ def test_injected_gates_reproduce_the_oracles_own_backward():
         _, D1 = G.backward(g, V, {"objective": np.float32(1)}, P, mode="normal", acc64=True, gates=gates)
         for k in D0:
             assert np.abs(D0[k] - D1[k]).max() <= 1e-6 * max(1.0, np.abs(D0[k]).max()), k
+
+
+def test_dropout_restatement():
+    """vl_nndropout = mask .* x both ways; the product's mask stream (Philox4x32-10, include/xmodal.h) is pinned on the
+    generator's published known-answer vector (Random123 kat_vectors: counter 0, key 0), and the graph executor treats a
+    dropout layer as the identity in test mode and as the given mask in training mode."""
+    m = O.dropout_mask((4, 1, 1, 1), 0.0, 0, 0)          # rate 0: every element kept, scale 1
+    assert np.array_equal(m.ravel(), np.ones(4, np.float32))
+    # u = word >> 8: the first block of the stream for (seed 0, offset 0) is 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    words = np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], np.uint64)
+    u = (words >> np.uint64(8)).astype(np.float32) / np.float32(16777216.0)
+    for rate in (0.3, 0.5, 0.75, 0.9):
+        want = np.where(u >= np.float32(rate), np.float32(1) / (np.float32(1) - np.float32(rate)), 0).astype(np.float32)
+        assert np.array_equal(O.dropout_mask((4,), rate, 0, 0).ravel(), want), rate
+    big = O.dropout_mask((64, 50, 3, 2), 0.5, 7, 0)
+    assert set(np.unique(big)) == {0.0, 2.0} and abs(float((big > 0).mean()) - 0.5) < 0.02
+    assert np.array_equal(O.dropout_mask((64, 50, 3, 2), 0.5, 7, 0), big)
+    assert not np.array_equal(O.dropout_mask((64, 50, 3, 2), 0.5, 8, 0), big)
+    # offset g advances the stream by whole blocks of four elements
+    tail = O.dropout_mask((64 * 50 * 3 * 2 - 8,), 0.5, 7, 2)
+    assert np.array_equal(tail, big.ravel(order="F")[8:])
+    rng = np.random.default_rng(3)
+    x = O.F(rng.standard_normal((64, 50, 3, 2)))
+    assert np.array_equal(O.vl_nndropout(x, big), np.where(big > 0, 2 * x, 0))
+    from oracle import graphs as G
+    g = G.vggvox_student(100, dropout=0.5)
+    P = G.make_params(g, 3)
+    data, lgo, lab = G.spectrogram_batch(2, 100, 5)
+    ins = {"data": data, "logitTarget": lgo, "maxLabel": lab}
+    Vt = G.forward(g, ins, P, mode="test")
+    V0 = G.forward(G.vggvox_student(100), ins, P, mode="test")
+    assert np.array_equal(Vt["prediction"], V0["prediction"])
+    shp = G.shapes(g, (512, 100, 1))
+    masks = {"fc6_drop.mask": O.dropout_mask(shp["x_fc6"] + (2,), 0.5, 1), "fc7_drop.mask": O.dropout_mask(shp["x_fc7"] + (2,), 0.5, 2)}
+    Vm = G.forward(g, dict(ins, **masks), P, mode="normal")
+    assert np.array_equal(Vm["fc6_drop"], Vm["x_fc6"] * masks["fc6_drop.mask"])
+    D, DP = G.backward(g, Vm, {"objective": np.float32(1)}, P, mode="normal")
+    assert np.array_equal(D["x_fc7"], D["fc7_drop"] * masks["fc7_drop.mask"])
+
+
+def test_resample_restatement_vs_scipy():
+    """speed perturbation (getBatchEmoVoxCeleb.m:102-108): the restated resample(x, p, q) against scipy's
+    resample_poly with the same Kaiser(5) window -- an independent implementation of the same polyphase recipe -- and
+    against what a resampler must do: length ceil(Lx p / q), a band-limited tone comes out as the same tone on the new
+    grid, speed factors 0.95 ... 1.05 as the provider draws them."""
+    import scipy.signal
+    rng = np.random.default_rng(4)
+    for speed in (0.95, 0.9731, 1.0, 1.0417, 1.05):
+        p, q = int(round(16000 / speed)), 16000
+        x = rng.standard_normal(3000)
+        y = O.resample(x, p, q)
+        assert y.size == -(-x.size * p // q)
+        import math
+        g = math.gcd(p, q)
+        ys = scipy.signal.resample_poly(x, p // g, q // g, window=("kaiser", 5.0))
+        assert ys.size == y.size
+        assert np.abs(y - ys).max() <= 2e-3 * np.abs(ys).max(), (speed, np.abs(y - ys).max())
+        t = np.arange(4000)
+        tone = np.sin(2 * np.pi * 0.05 * t)
+        yt = O.resample(tone, p, q)
+        want = np.sin(2 * np.pi * 0.05 * np.arange(yt.size) * q / p)
+        assert np.abs(yt - want)[200:-200].max() < 2e-3, speed
