@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -256,6 +256,25 @@ int xm_nndropout_forward(const float *x, size_t n, float rate, unsigned long lon
                          float *y, float *mask_out, void *stream);
 /* Y = X .* MASK: DZDX = vl_nndropout(X, DZDY, 'mask', MASK), and the forward call with a given mask */
 int xm_nndropout_apply(const float *x, const float *mask, size_t n, float *y, void *stream);
+
+/* Extension: backward of the TAIL of an SE bottleneck block in training mode (the trainable SE-ResNet-50 teacher,
+ * teacher/ferplus_baselines.m:140-141; BASELINE config 5):
+ *     U -> vl_nnbnorm(G, B) -> X;   GP = mean_hw(X) -> fc1 -> relu -> fc2 -> sigmoid = A;   Y = vl_nnrelu(A .* X + S)
+ * Two calls replace vl_nnrelu / Axpy / GlobalPooling / vl_nnbnorm backward (13 passes over block-sized tensors -> 8):
+ *   xm_se_tail_backward_reduce  reads Y, DZDY, U;  leaves DA = dz/dA (1 x 1 x C x N, what the gate's backward consumes)
+ *                               and three sums per (channel, sample) plane in `plane_sums` (caller-owned, 3 C N doubles);
+ *   xm_se_tail_backward_apply   after the gate's backward has produced DGP = dz/dGP (1 x 1 x C x N): writes
+ *                               DZ = [Y > 0] .* DZDY (the derivative of the shortcut S) and DU = dz/dU, and the bnorm's
+ *                               DG / DB.  `moments` are the batch moments of U the forward pass used (train = 1) or
+ *                               the stored ones (train = 0).  Same formulas as the separate operators (the bnorm's
+ *                               per-element expression in fp64); X is recomputed from U where it is needed. */
+int xm_se_tail_backward_reduce(const float *y, const float *dzdy, const float *u, int H, int W, int C, int N,
+                               const float *g, const float *b, const float *moments, float *da_out, double *plane_sums,
+                               void *stream);
+int xm_se_tail_backward_apply(const float *y, const float *dzdy, const float *u, int H, int W, int C, int N,
+                              const float *gate, const float *dgp, const float *g, const float *moments, int train,
+                              const double *plane_sums, float *dz_out, float *du_out, float *dg_out, float *db_out,
+                              void *stream);
 
 /* ---- losses --------------------------------------------------------------------------------
  * vl_nnsoftmaxt(X, 'temperature', T): softmax(X / T) along dim 3; X is HW x C x N */

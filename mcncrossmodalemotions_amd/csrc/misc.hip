@@ -83,6 +83,122 @@ scale_axpy_kernel(const float *__restrict__ x, const float *__restrict__ a,
   }
 }
 
+// ---- backward of the tail of an SE bottleneck block in TRAINING mode (teacher/ferplus_baselines.m:140-141, config 5) ----
+//   u -> vl_nnbnorm -> x ;  gp = mean_hw(x) -> fc1 -> relu -> fc2 -> sigmoid = a ;  y = relu(a .* x + shortcut)
+// The separate operators make 13 passes over block-sized tensors on the way back (relu mask 3, scale backward 3,
+// squeeze backward at its fork 2, bnorm sums 2, bnorm apply 3).  Everything the gate's backward and the bnorm's sums
+// need from those tensors are three numbers per (channel, sample) plane:
+//   S0 = sum (u - mu),  S1 = sum dz,  S2 = sum dz (u - mu),      dz = [y > 0] dzdy
+//   da = g/sigma S2 + b S1                                        (x is recomputed from u: the forward direction)
+//   D  = a dz + dgp / (H W)   is the derivative that reaches x    (excite + squeeze), so per channel
+//   sum D = sum_n (a S1 + dgp),   sum D (u - mu) = sum_n (a S2 + dgp / (H W) S0)
+// se_tail_reduce_kernel (3 reads) leaves S0..S2 and da; after the gate's backward has produced dgp,
+// se_tail_apply_kernel (3 reads, 2 writes) writes dz (the shortcut's derivative) and du = g/sigma (D - c1 - (u - mu) c2)
+// with the bnorm's usual fp64 expression.  x itself is not read on the way back.
+// one wave per plane (4 planes per block): planes have 49 ... 3136 elements
+__global__ void __launch_bounds__(256)
+se_tail_reduce_kernel(const float *__restrict__ y, const float *__restrict__ dzdy, const float *__restrict__ u,
+                      const float *__restrict__ g, const float *__restrict__ b, const float *__restrict__ mom, int HW, int C,
+                      int planes, float *__restrict__ da, double *__restrict__ S) {
+  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= planes) return;
+  const int lane = threadIdx.x & 63, c = plane % C;
+  const size_t off = (size_t)plane * HW;
+  const double mu = (double)mom[c];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if ((HW & 3) == 0) {
+    for (int i = lane * 4; i < HW; i += 256) {
+      const float4 yv = *reinterpret_cast<const float4 *>(y + off + i), dv = *reinterpret_cast<const float4 *>(dzdy + off + i),
+                   uv = *reinterpret_cast<const float4 *>(u + off + i);
+      const double t0 = (double)uv.x - mu, t1 = (double)uv.y - mu, t2 = (double)uv.z - mu, t3 = (double)uv.w - mu;
+      const double d0 = yv.x > 0.f ? (double)dv.x : 0.0, d1 = yv.y > 0.f ? (double)dv.y : 0.0,
+                   d2 = yv.z > 0.f ? (double)dv.z : 0.0, d3 = yv.w > 0.f ? (double)dv.w : 0.0;
+      s0 += (t0 + t1) + (t2 + t3);
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * t0 + d1 * t1) + (d2 * t2 + d3 * t3);
+    }
+  } else {
+    for (int i = lane; i < HW; i += 64) {
+      const double t = (double)u[off + i] - mu, d = y[off + i] > 0.f ? (double)dzdy[off + i] : 0.0;
+      s0 += t;
+      s1 += d;
+      s2 += d * t;
+    }
+  }
+  s0 = xm_wave_sum_d(s0);
+  s1 = xm_wave_sum_d(s1);
+  s2 = xm_wave_sum_d(s2);
+  if (lane == 0) {
+    S[3 * (size_t)plane] = s0;
+    S[3 * (size_t)plane + 1] = s1;
+    S[3 * (size_t)plane + 2] = s2;
+    da[plane] = (float)((double)g[c] / (double)mom[C + c] * s2 + (double)b[c] * s1);
+  }
+}
+
+// one wave per channel: the bnorm's two sums over its N planes in fp64, dg / db
+__global__ void __launch_bounds__(256)
+se_tail_finalize_kernel(const double *__restrict__ S, const float *__restrict__ gate, const float *__restrict__ dgp,
+                        const float *__restrict__ mom, int HW, int C, int N, double *__restrict__ sums,
+                        float *__restrict__ dg, float *__restrict__ db) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double sd = 0.0, sx = 0.0;
+  for (int n = lane; n < N; n += 64) {
+    const size_t p = (size_t)c + (size_t)C * n;
+    const double a = (double)gate[p], k = (double)dgp[p] / (double)HW;
+    sd += a * S[3 * p + 1] + (double)dgp[p];
+    sx += a * S[3 * p + 2] + k * S[3 * p];
+  }
+  sd = xm_wave_sum_d(sd);
+  sx = xm_wave_sum_d(sx);
+  if (lane) return;
+  sums[c] = sd;
+  sums[C + c] = sx;
+  if (dg) dg[c] = (float)(sx / (double)mom[C + c]);
+  if (db) db[c] = (float)sd;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+se_tail_apply_kernel(const float *__restrict__ y, const float *__restrict__ dzdy, const float *__restrict__ u,
+                     const float *__restrict__ gate, const float *__restrict__ dgp, const float *__restrict__ g,
+                     const float *__restrict__ mom, const double *__restrict__ sums, FastDiv divHW, int C, size_t total,
+                     double m, int train, float *__restrict__ dz, float *__restrict__ du) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t cnt = VEC ? (total >> 2) : total;
+  const double ihw = 1.0 / (double)divHW.d;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < cnt; i += stride) {
+    const uint32_t plane = xm_div((uint32_t)(VEC ? (i << 2) : i), divHW);
+    const int c = plane % C;
+    const double sg = mom[C + c], mu = mom[c];
+    const double gs = (double)g[c] / sg;
+    const double c1 = train ? sums[c] / m : 0.0;
+    const double c2 = train ? sums[C + c] / (m * sg * sg) : 0.0;
+    const float a = gate[plane];
+    const double k = (double)dgp[plane] * ihw;
+    if (VEC) {
+      const float4 yv = reinterpret_cast<const float4 *>(y)[i], uv = reinterpret_cast<const float4 *>(u)[i];
+      float4 dv = reinterpret_cast<const float4 *>(dzdy)[i];
+      dv.x = yv.x > 0.f ? dv.x : 0.f;
+      dv.y = yv.y > 0.f ? dv.y : 0.f;
+      dv.z = yv.z > 0.f ? dv.z : 0.f;
+      dv.w = yv.w > 0.f ? dv.w : 0.f;
+      reinterpret_cast<float4 *>(dz)[i] = dv;
+      float4 o;   // D = fl(a dz) + k: the excite's derivative is a float product (xm_scale_backward), the squeeze's share is added to it
+      o.x = (float)(gs * (((double)(a * dv.x) + k) - c1 - ((double)uv.x - mu) * c2));
+      o.y = (float)(gs * (((double)(a * dv.y) + k) - c1 - ((double)uv.y - mu) * c2));
+      o.z = (float)(gs * (((double)(a * dv.z) + k) - c1 - ((double)uv.z - mu) * c2));
+      o.w = (float)(gs * (((double)(a * dv.w) + k) - c1 - ((double)uv.w - mu) * c2));
+      reinterpret_cast<float4 *>(du)[i] = o;
+    } else {
+      const float d = y[i] > 0.f ? dzdy[i] : 0.f;
+      dz[i] = d;
+      du[i] = (float)(gs * (((double)(a * d) + k) - c1 - ((double)u[i] - mu) * c2));
+    }
+  }
+}
+
 // one wave per plane: da = sum dy .* x ; dx = a .* dy
 __global__ void __launch_bounds__(256)
 scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a,
@@ -482,6 +598,51 @@ int xm_scale_axpy(const float *x, int HW, int CN, const float *a, const float *r
   size_t total = (size_t)HW * CN;
   hipLaunchKernelGGL(scale_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, a,
                      r, y, make_fastdiv((uint32_t)HW), total, (flags & XM_FUSE_RELU) ? 1 : 0);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_se_tail_backward_reduce(const float *y, const float *dzdy, const float *u, int H, int W, int C, int N,
+                               const float *g, const float *b, const float *moments, float *da_out, double *plane_sums,
+                               void *stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "SE tail backward: empty tensor");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "SE tail backward: tensor with >= 2^31 elements");
+  if (!y || !dzdy || !u || !g || !b || !moments || !da_out || !plane_sums) return fail(XM_EINVAL, "SE tail backward: NULL tensor");
+  const int planes = C * N;
+  hipLaunchKernelGGL(se_tail_reduce_kernel, dim3((planes + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, dzdy, u, g, b,
+                     moments, H * W, C, planes, da_out, plane_sums);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_se_tail_backward_apply(const float *y, const float *dzdy, const float *u, int H, int W, int C, int N,
+                              const float *gate, const float *dgp, const float *g, const float *moments, int train,
+                              const double *plane_sums, float *dz_out, float *du_out, float *dg_out, float *db_out,
+                              void *stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "SE tail backward: empty tensor");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "SE tail backward: tensor with >= 2^31 elements");
+  if (!y || !dzdy || !u || !gate || !dgp || !g || !moments || !plane_sums || !dz_out || !du_out)
+    return fail(XM_EINVAL, "SE tail backward: NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  WsCarver ws;
+  int rc = ws.init(WsCarver::need((size_t)2 * C, 8), st);
+  if (rc) return rc;
+  double *sums = ws.take<double>((size_t)2 * C);
+  const int HW = H * W;
+  hipLaunchKernelGGL(se_tail_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, plane_sums, gate, dgp, moments, HW, C, N,
+                     sums, dg_out, db_out);
+  XM_LAUNCH_CHECK();
+  const size_t total = (size_t)HW * C * N;
+  const double m = (double)HW * N;
+  const bool vec = (HW & 3) == 0 && ((((uintptr_t)y | (uintptr_t)dzdy | (uintptr_t)u | (uintptr_t)dz_out | (uintptr_t)du_out) & 15) == 0);
+  const size_t items = vec ? total / 4 : total;
+  const unsigned grid = (unsigned)std::min<size_t>((items + 255) / 256, (size_t)256 * 64);
+  if (vec)
+    hipLaunchKernelGGL(se_tail_apply_kernel<true>, dim3(grid), dim3(256), 0, st, y, dzdy, u, gate, dgp, g, moments, sums,
+                       make_fastdiv((uint32_t)HW), C, total, m, train, dz_out, du_out);
+  else
+    hipLaunchKernelGGL(se_tail_apply_kernel<false>, dim3(grid), dim3(256), 0, st, y, dzdy, u, gate, dgp, g, moments, sums,
+                       make_fastdiv((uint32_t)HW), C, total, m, train, dz_out, du_out);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -475,6 +475,8 @@ class DagNN:
         self.fuseStemBackward = os.environ.get("XM_NO_FUSED_STEM_BWD") is None
         self.fuseForkSums = os.environ.get("XM_NO_FORK_SUMS") is None   # global-avg backward adds the fork's other derivative
         self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
+        # training plans: relu mask + excite + squeeze + bnorm backward of an SE block's tail in two fused calls
+        self.fuseSETrain = os.environ.get("XM_NO_FUSED_SE_BWD") is None
         self.wgradStream = None  # optional side HIP stream for the filter / bias derivatives
         self.gradHook = None     # callable(layer name): called right after a conv layer's parameter
                                  # derivatives were enqueued, on the stream they were enqueued on
@@ -806,6 +808,7 @@ class _Step:
         self.moments_for = None  # _LayerRec of the train-mode BatchNorm this conv step computes the batch moments for
         self.bias_conv = None    # bnorm steps: _Step of the biased Conv that produced the input (its dzdb = sum of our dx)
         self.bias_conv_done = False
+        self.se_bn = None        # training plans: the _SEBnTrainStep whose fused backward covers this step (its squeeze / excite)
 
     def _bias_der_slot(self, net):
         """flat derivative slot of the producing convolution's bias when this bnorm step may fill it (sum of dx)"""
@@ -908,6 +911,14 @@ class _Step:
         elif isinstance(r.block, BatchNorm):
             dins, dpar = r.block.backward(ins, self._params(net), douts, der_out=net._direct_der(r),
                                           dxsum_out=self._bias_der_slot(net))
+        elif isinstance(r.block, GlobalPooling) and self.se_bn is not None and self.se_bn.stash is not None:
+            # the squeeze of a fused SE tail: its derivative is a per-plane constant that the bnorm's fused backward adds
+            self.se_bn.stash["dgp"] = douts[0]
+            if net.conserveMemory:
+                for v in r.outputs:
+                    if not net.vars[v].precious:
+                        net.vars[v].der = None
+            return
         elif isinstance(r.block, GlobalPooling) and r.block.method == "avg" and net.vars[r.inputs[0]].der is not None \
                 and net.fuseForkSums:
             # fork: the other consumer of X (the SE excite) already left its derivative -> one pass instead of a
@@ -979,6 +990,8 @@ class _AddReluStep(_Step):
         out = net.vars[self.relu_rec.outputs[0]]
         if out.der is None:
             return
+        if self.se_bn is not None and self.se_bn.begin(net, self, out):
+            return      # the fused SE-tail backward: da is out, everything else follows at the bnorm's position
         dz = vl.vl_nnrelu(out.value, out.der)  # y = relu(.) > 0  <=>  pre-activation > 0
         ins = [net.vars[v].value for v in r.inputs]
         dins, _ = r.block.backward(ins, [], [dz])
@@ -986,6 +999,61 @@ class _AddReluStep(_Step):
             net._set_var_der(v, d)
         if net.conserveMemory and not out.precious:
             out.der = None
+
+
+class _SEBnTrainStep(_Step):
+    """Training plans: the plain BatchNorm whose output X feeds exactly the squeeze (GlobalPooling 'avg') and the
+    excite (Axpy(gate, X, shortcut) -> ReLU) of an SE block.  Forward: unchanged.  Backward: two fused calls
+    (vl.se_tail_backward_reduce at the Axpy's position -> the gate's derivative; vl.se_tail_backward_apply here, once
+    the gate's backward has produced the squeeze's derivative) instead of relu mask, scale backward, squeeze backward
+    and bnorm backward over the block's widest tensors."""
+
+    def __init__(self, bn_rec, axpy_step, gp_step):
+        super().__init__(bn_rec)
+        self.axpy_step, self.gp_step = axpy_step, gp_step
+        self.stash = None
+        axpy_step.se_bn = self
+        gp_step.se_bn = self
+
+    def begin(self, net, axpy_step, out):
+        """called by the Axpy+ReLU step's backward; False = run the separate operators"""
+        self.stash = None
+        if not net.fuseSETrain:
+            return False
+        r, ax = self.rec, axpy_step.rec
+        gate_v, x_v, sc_v = (net.vars[v] for v in ax.inputs)
+        if x_v.precious or net.vars[r.outputs[0]] is not x_v:
+            return False
+        g, b, mom = self._params(net)
+        test = net.mode == "test"
+        moments = mom if test else r.block.moments
+        if moments is None:
+            return False
+        u = net.vars[r.inputs[0]].value
+        da, sums = vl.se_tail_backward_reduce(out.value, out.der, u, g, b, moments)
+        net._set_var_der(ax.inputs[0], da)
+        self.stash = {"y": out.value, "dzdy": out.der, "u": u, "sums": sums, "gate": gate_v.value, "moments": moments,
+                      "test": test, "shortcut": ax.inputs[2], "dgp": None}
+        if net.conserveMemory and not out.precious:
+            out.der = None
+        return True
+
+    def backward(self, net):
+        st, self.stash = self.stash, None
+        if st is None:
+            return super().backward(net)
+        r = self.rec
+        if st["dgp"] is None:
+            raise RuntimeError("fused SE tail: the squeeze's derivative never arrived (layer %s)" % r.name)
+        g, b, mom = self._params(net)
+        do = net._direct_der(r)
+        dz, du, dg, db = vl.se_tail_backward_apply(st["y"], st["dzdy"], st["u"], st["gate"], st["dgp"], g, st["moments"],
+                                                   st["sums"], train=not st["test"], dg_out=do[0] if do else None,
+                                                   db_out=do[1] if do else None)
+        net._set_var_der(st["shortcut"], dz)
+        net._set_var_der(r.inputs[0], du)
+        for p, d in zip(r.params, [dg, db, None if st["test"] else st["moments"]]):
+            net._set_param_der(p, d)
 
 
 class _BnReluPoolStep(_Step):
@@ -1191,9 +1259,10 @@ class _SEFoldStep(_ConvFoldStep):
         net.vars[self.out_name].value = y
 
 
-def _match_se_tail(net, recs, consumers, order, conv_rec, bn_rec):
+def _match_se_tail(net, recs, consumers, order, conv_rec, bn_rec, keep_values=False):
     """the SE tail behind a 1 x 1 / stride-1 projection + bnorm: {GlobalPooling('avg') -> Conv -> ReLU -> Conv -> Sigmoid}
-    and Axpy(gate, x, shortcut) [-> ReLU] as the only consumers of x, nothing precious in between"""
+    and Axpy(gate, x, shortcut) [-> ReLU] as the only consumers of x, nothing precious in between (`keep_values`: the
+    caller still materialises every variable of the gate path -- training plans -- so precious ones there are fine)"""
     blk = conv_rec.block
     if blk.size[0] != 1 or blk.size[1] != 1 or tuple(vl._pair(blk.stride, "STRIDE")) != (1, 1) or any(vl._pad4(blk.pad)):
         return None
@@ -1209,7 +1278,7 @@ def _match_se_tail(net, recs, consumers, order, conv_rec, bn_rec):
 
     def only(var, cls):
         c = consumers.get(var, [])
-        return c[0] if len(c) == 1 and isinstance(c[0].block, cls) and not net.vars[var].precious else None
+        return c[0] if len(c) == 1 and isinstance(c[0].block, cls) and (keep_values or not net.vars[var].precious) else None
     fc1 = only(gp.outputs[0], Conv)
     r1 = only(fc1.outputs[0], ReLU) if fc1 else None
     fc2 = only(r1.outputs[0], Conv) if r1 else None
@@ -1348,4 +1417,25 @@ def build_plan(net, training):
                     cs.moments_for = r
                     if type(st) is _BnReluPoolStep:
                         st.producer_conv = cs
+        # SE blocks: the plain bnorm behind the projection, its squeeze and its excite (+ relu) share one fused backward
+        by_rec = {id(st.rec): st for st in steps}
+        for i, st in enumerate(steps):
+            r = st.rec
+            if type(st) is not _Step or not isinstance(r.block, BatchNorm):
+                continue
+            cs = conv_of.get(r.inputs[0])
+            if cs is None or len(consumers.get(r.inputs[0], [])) != 1:
+                continue
+            se = _match_se_tail(net, recs, consumers, order, cs.rec, r, keep_values=True)
+            if se is None or se["relu"] is None:
+                continue
+            ax_step, gp_step = by_rec.get(id(se["axpy"])), by_rec.get(id(se["gp"]))
+            if type(ax_step) is not _AddReluStep or type(gp_step) is not _Step:
+                continue
+            new_st = _SEBnTrainStep(r, ax_step, gp_step)
+            new_st.bias_conv, new_st.bias_from, new_st.moments_for = st.bias_conv, st.bias_from, st.moments_for
+            for q in steps:
+                if q.bias_from is st:
+                    q.bias_from = new_st
+            steps[i] = new_st
     return steps

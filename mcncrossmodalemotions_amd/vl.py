@@ -475,6 +475,32 @@ def scale_axpy(x, a, r=None, relu=False):
     return y
 
 
+def se_tail_backward_reduce(y, dzdy, u, g, b, moments):
+    """first half of the fused SE-tail backward (xm_se_tail_backward_reduce): returns (da 1 x 1 x C x N, plane sums)"""
+    y, dzdy, u = _chk(y, "Y"), _chk(dzdy, "DZDY"), _chk(u, "U")
+    H, W, Cc, N = _shape4(u)
+    da = mat_empty(1, 1, Cc, N, device=u.device)
+    sums = torch.empty(3 * Cc * N, dtype=torch.float64, device=u.device)
+    _lib.check(_L().xm_se_tail_backward_reduce(_ptr(y), _ptr(dzdy), _ptr(u), H, W, Cc, N, _ptr(_chk(g, "G")), _ptr(_chk(b, "B")),
+                                               _ptr(_chk(moments, "MOMENTS")), _ptr(da), C.c_void_p(sums.data_ptr()), _stream()))
+    return da, sums
+
+
+def se_tail_backward_apply(y, dzdy, u, gate, dgp, g, moments, sums, train=True, dg_out=None, db_out=None):
+    """second half (xm_se_tail_backward_apply): returns (dz = the shortcut's derivative, du, dg, db)"""
+    y, dzdy, u = _chk(y, "Y"), _chk(dzdy, "DZDY"), _chk(u, "U")
+    H, W, Cc, N = _shape4(u)
+    dz = mat_empty(H, W, Cc, N, device=u.device)
+    du = mat_empty(H, W, Cc, N, device=u.device)
+    dg = dg_out if dg_out is not None else mat_empty(Cc, 1, device=u.device)
+    db = db_out if db_out is not None else mat_empty(Cc, 1, device=u.device)
+    _lib.check(_L().xm_se_tail_backward_apply(_ptr(y), _ptr(dzdy), _ptr(u), H, W, Cc, N, _ptr(_chk(gate, "A")),
+                                              _ptr(_chk(dgp, "DGP")), _ptr(_chk(g, "G")), _ptr(_chk(moments, "MOMENTS")),
+                                              1 if train else 0, C.c_void_p(sums.data_ptr()), _ptr(dz), _ptr(du), _ptr(dg),
+                                              _ptr(db), _stream()))
+    return dz, du, dg, db
+
+
 def scale_backward(x, a, dzdy, need_dx=True):
     x, a, dzdy = _chk(x, "X"), _chk(a, "A"), _chk(dzdy, "DZDY")
     H, W, Cc, N = _shape4(x)

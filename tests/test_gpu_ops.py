@@ -747,6 +747,39 @@ def test_fused_bnorm_relu_pool(gpu, case, train, pooled):
     close(vl.to_numpy(db).ravel(), db_ref, what="fused db")
 
 
+@pytest.mark.parametrize("shape", [(56, 56, 24, 3), (7, 7, 40, 5), (14, 13, 9, 2)])
+@pytest.mark.parametrize("train", [True, False])
+def test_se_tail_backward(gpu, shape, train):
+    """xm_se_tail_backward_reduce / _apply (training-mode SE block tail, ferplus_baselines.m:140-141) against the
+    oracle's composition of the separate operators: relu mask, Axpy backward (scale), GlobalPooling backward added at
+    the fork, vl_nnbnorm backward -- da, dz (the shortcut's derivative), du, dg, db."""
+    from mcncrossmodalemotions_amd import vl
+    H, W, C, N = shape
+    rng = np.random.default_rng(H * 7 + C + int(train))
+    u = O.F(rng.standard_normal(shape) * 1.3 + 0.4)
+    g, b = O.F(rng.uniform(0.5, 1.5, C) * rng.choice([-1, 1], C)), rnd(rng, C)
+    mom = None if train else O.F(np.stack([rng.standard_normal(C) * 0.3, rng.uniform(0.5, 1.5, C)], 1))
+    x, mref = O.vl_nnbnorm(u, g, b, moments=mom, acc64=True)
+    a = O.F(rng.uniform(0.05, 0.95, (1, 1, C, N)))
+    s = rnd(rng, *shape)
+    y = O.scale_axpy(x, a, s, relu=True)
+    dzdy, dgp = rnd(rng, *shape), rnd(rng, 1, 1, C, N)
+    dz_ref = O.vl_nnrelu(y, dzdy)                 # y > 0 <=> pre-activation > 0
+    dx1, da_ref = O.scale_backward(x, a, dz_ref)
+    dx = dx1 + O.vl_nnpool(x, (H, W), dgp, method="avg")
+    du_ref, dg_ref, db_ref, _ = O.vl_nnbnorm(u, g, b, O.F(dx), moments=mom, acc64=True)
+    d = vl.from_numpy
+    gd, bd = d(g.reshape(C, 1)), d(b.reshape(C, 1))
+    md = d(mref)
+    da, sums = vl.se_tail_backward_reduce(d(y), d(dzdy), d(u), gd, bd, md)
+    close(vl.to_numpy(da), da_ref, what="da")
+    dz, du, dg, db = vl.se_tail_backward_apply(d(y), d(dzdy), d(u), d(a), d(dgp), gd, md, sums, train=train)
+    assert np.array_equal(vl.to_numpy(dz), dz_ref)
+    close(vl.to_numpy(du), du_ref, what="du")
+    close(vl.to_numpy(dg).ravel(), dg_ref, what="dg")
+    close(vl.to_numpy(db).ravel(), db_ref, what="db")
+
+
 def test_elementwise(gpu):
     from mcncrossmodalemotions_amd import vl
     rng = np.random.default_rng(5)
