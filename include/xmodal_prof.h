@@ -4,6 +4,17 @@
  * the stream the kernel is launched on, and to attach the algorithmic FLOPs of every launch
  * (2 * M * pixels * taps, un-padded), so that roofline.achieved is measured live.
  */
+/*
+ * Environment the library reads (nothing else): every name is read once.
+ *   tuning table   XM_TUNE_FILE (path; "" disables), XM_AUTOTUNE=0 (analytic model only), XM_TUNE_REPS, XM_TUNE_VERBOSE,
+ *                  XM_HALO_MARGIN (a challenger kernel must win by this fraction, default 0.04)
+ *   workspace log  XM_WS_VERBOSE
+ *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
+ *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
+ *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED.
+ *                  Each chooses between two complete, parity-tested implementations of the same operator (tests cover
+ *                  the fallback arms through them, profiles/ holds the A/B lines); none changes what is computed.
+ */
 #ifndef XMODAL_PROF_H
 #define XMODAL_PROF_H
 #ifdef __cplusplus

@@ -9,6 +9,19 @@
 #include "xm_common.h"
 
 namespace xm {
+bool path_on(Path p) {
+  static const char *const kEnv[kPathCount] = {"XM_NO_HYBRID",      "XM_NO_HALO",        "XM_NO_SKINNY",     "XM_NO_SKINNY4",
+                                               "XM_NO_STEM",        "XM_NO_STEM_WGRAD",  "XM_NO_DMA",        "XM_NO_FUSED_STATS",
+                                               "XM_DGRAD_MERGE",    "XM_NO_FAST_TRANSPOSE", "XM_NO_POOL_LDS", "XM_NO_POOL_PATCH",
+                                               "XM_NO_POOL_POOLED"};
+  static bool on[kPathCount];
+  static bool read = false;
+  if (!read) {
+    for (int i = 0; i < kPathCount; ++i) on[i] = getenv(kEnv[i]) == nullptr;
+    read = true;
+  }
+  return on[p];
+}
 
 static char g_err[512] = "";
 char *err_buf() { return g_err; }

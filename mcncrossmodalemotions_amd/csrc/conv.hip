@@ -402,7 +402,7 @@ static const int kCfgOcc[kNumBaseCfg] = {2, 2, 2, 3, 4, 3, 4};
 // computes the full rounds tile by tile and splits the remaining tiles along the reduction so that they fill the last
 // round with short blocks -- 3.06 rounds cost 3.06 + 1/S instead of 4.  Returns the split count of the remainder (1: plain).
 static int hybrid_plan(const ConvGemmArgs &a, int ci, int *full_out) {
-  static const bool off = getenv("XM_NO_HYBRID") != nullptr;
+  const bool off = !path_on(kPathHybrid);
   *full_out = 0;
   if (off || is_dma_cfg(ci) || g_force_splits > 0) return 1;
   if (a.statPart && (!a.vecStore || a.relu || a.resid)) return 1;   // conv_splitk_epilogue_stats_kernel's case only
@@ -557,7 +557,7 @@ static const float kHaloMargin = getenv("XM_HALO_MARGIN") ? (float)atof(getenv("
 // the patch floats per channel the widest 128-pixel tile needs (0: the kernel cannot run this problem): taps in an
 // nU x nV <= 3 x 3 arrangement of 9 / 6 / 4, adjacent rows / columns, unit pixel stride, channels a multiple of 8.
 static int halo_setup(ConvGemmArgs &a, int nSamples) {
-  static const bool off = getenv("XM_NO_HALO") != nullptr;
+  const bool off = !path_on(kPathHalo);
   const int T = a.nU * a.nV;
   if (off || a.nU < 1 || a.nU > 3 || a.nV < 1 || a.nV > 3 || (T != 9 && T != 6 && T != 4)) return 0;
   if (a.gsy != 1 || a.gsx != 1 || std::abs(a.dus) != 1 || std::abs(a.dvs) != 1) return 0;
@@ -1096,7 +1096,7 @@ fc_skinny4_kernel(const float *__restrict__ x, const float *__restrict__ f, cons
   }
 }
 static bool fc_skinny_ok(const Geo &g) {
-  static const bool off = getenv("XM_NO_SKINNY") != nullptr;
+  const bool off = !path_on(kPathSkinny);
   if (off || g.FH != 1 || g.FW != 1 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.G != 1) return false;
   if (g.pt | g.pb | g.pl | g.pr) return false;
   const long long NP = (long long)g.Ho * g.Wo * g.N;
@@ -1110,7 +1110,7 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
   const bool vec = HW == 1 && (g.C & 3) == 0 && (((uintptr_t)x | (uintptr_t)f) & 15) == 0;
   const int units = vec ? g.C / 4 : g.C;   // k positions handed out per lane step
   const int nw = std::max(1, std::min(4, (units + 63) / 64));
-  static const bool no4 = getenv("XM_NO_SKINNY4") != nullptr;
+  const bool no4 = !path_on(kPathSkinny4);
   if (vec && (g.K & 3) == 0 && g.K >= 16 && !no4) {
     const int ch = (NP + 15) / 16;
     dim3 grid4((unsigned)(g.K / 4 * ch)), block4(64 * nw);
@@ -1149,7 +1149,7 @@ static int fc_skinny_forward(const float *x, const float *f, const float *b, flo
 // Forward convolutions over ONE input channel with <= 8 x 7 taps, stride 1 / 2 along H, <= 96 filters, source columns of
 // <= 512 rows (the student's conv1 over 512-bin spectrograms).  `f` is the caller's filter bank, unpadded.
 static bool stem_ok(const ConvGemmArgs &a, const Geo &g, const float *x, const float *f) {
-  static const bool off = getenv("XM_NO_STEM") != nullptr;
+  const bool off = !path_on(kPathStem);
   if (off || g_force_cfg >= 0 || g_force_splits > 0) return false;
   if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.Kg > 96) return false;
@@ -1217,8 +1217,8 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
   // 16-byte aligned operands
   const bool dma_ok = !need_pad && mode == 0 && g.FH == 1 && g.FW == 1 && g.sy == 1 && g.sx == 1 && g.dy == 1 &&
                       g.dx == 1 && (g.H * g.W) % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)f & 15) == 0 &&
-                      g.R % kBK == 0 && getenv("XM_NO_DMA") == nullptr;
-  static const bool no_fstats = getenv("XM_NO_FUSED_STATS") != nullptr;
+                      g.R % kBK == 0 && path_on(kPathDma);
+  const bool no_fstats = !path_on(kPathFusedStats);
   const bool want_stats = moments_out != nullptr && g.G == 1 && !no_fstats;
   // partial sums: one {sum, sum sq} pair per row and per pixel tile (>= 32 pixels), + 64 fp64 slabs for the reduction
   // (the persistent stem kernel leaves one row per block: stem_grid(NP) can exceed NP / 32 on small problems)
@@ -1535,7 +1535,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
   for (const Cls &c : cls) pair_total += (double)(foldH ? 1 : c.PI) * c.PJ * g.N * c.Rc;
   // merged launch: 2-4 classes, no filter groups, and enough tiles per class that none would be split
   bool merge = g.G == 1 && !foldH && cls.size() >= 2 && cls.size() <= 4 && g_force_splits == 0 &&
-               getenv("XM_DGRAD_MERGE") == nullptr;
+               path_on(kPathDgradMerge);
   {
     // the merged launch never splits K: it needs enough tiles in total to fill the chip by itself
     long long tiles = 0;
@@ -1572,7 +1572,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
       const int Rrows = g.FC * (foldH ? g.FH : 1);
       const bool pure_t = g.FW == 1 && ((foldH && c.nU == g.FH && c.nV == 1) || (g.FH == 1 && !foldH)) &&
                           c.Rp == g.Kg && (Rrows & 3) == 0 && (g.Kg & 3) == 0 && g.G == 1 &&
-                          (((uintptr_t)f | (uintptr_t)Ag) & 15) == 0 && getenv("XM_NO_FAST_TRANSPOSE") == nullptr;
+                          (((uintptr_t)f | (uintptr_t)Ag) & 15) == 0 && path_on(kPathFastTranspose);
       if (!have_prepared && pure_t) {
         hipLaunchKernelGGL(transpose_filter_kernel, dim3((Rrows + 63) / 64, (g.Kg + 63) / 64), dim3(256), 0, st, f, Ag,
                            g.Kg, Rrows, c.Rp);
@@ -1811,7 +1811,7 @@ static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g
 
 // ---- filter derivative of the single-channel stem (conv_stem_wgrad_kernel) ------------------------------------------
 static bool stem_wgrad_ok(const Geo &g, const float *x, const float *dzdy, bool structural_only = false) {
-  static const bool off = getenv("XM_NO_STEM") != nullptr || getenv("XM_NO_STEM_WGRAD") != nullptr;
+  const bool off = !path_on(kPathStem) || !path_on(kPathStemWgrad);
   if (!structural_only && (off || g_force_cfg >= 0 || g_force_splits > 0)) return false;
   if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.FH * g.FW > 64 || g.Kg > 96) return false;

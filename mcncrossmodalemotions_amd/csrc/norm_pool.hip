@@ -790,7 +790,7 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
   }
   // LDS-staged kernel: max pooling, 3x3 window, planes large enough to fill a block, 16-byte aligned tensor
   if (method == XM_POOL_MAX && ph == 3 && pw == 3 && ((uintptr_t)x & 15) == 0 && (long long)C * N <= 65535 &&
-      g.Ho * g.Wo >= 256 && !getenv("XM_NO_POOL_LDS")) {
+      g.Ho * g.Wo >= 256 && path_on(kPathPoolLds)) {
     const int maxcols = 16 * 256 / H;  // 16 KB of LDS per block: 10 blocks per CU, measured best of 8 / 16 / 32 / 64
     int wob = maxcols >= pw ? (maxcols - pw) / sx + 1 : 0;
     wob = std::min(wob, g.Wo);
@@ -1197,8 +1197,8 @@ static int bnrelupool_backward(const float *x, int H, int W, int C, int N, const
   if ((ph + sy - 1) / sy > 2 || (pw + sx - 1) / sx > 2)
     return fail(XM_ENOTSUP, "bnorm+relu+pool backward: more than 2x2 windows cover an element");
   if (dxsum_out && !dx_out) return fail(XM_EINVAL, "bnorm+relu+pool backward: dxsum needs dx");
-  static const bool no_patch = getenv("XM_NO_POOL_PATCH") != nullptr;
-  static const bool no_pooled = getenv("XM_NO_POOL_POOLED") != nullptr;
+  const bool no_patch = !path_on(kPathPoolPatch);
+  const bool no_pooled = !path_on(kPathPoolPooled);
   // element kernels: (bx, by) threads own (h, w); grid.y = channel; the N samples are split S ways
   int bx = pow2_ge(H, 256), by = 256 / bx;
   by = pow2_ge(W, by);

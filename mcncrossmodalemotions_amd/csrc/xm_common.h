@@ -56,6 +56,31 @@ struct WsCarver {
   static size_t need(size_t count, size_t elt) { return (count * elt + 255) & ~size_t(255); }
 };
 
+// ---- kernel-path selectors ----------------------------------------------------------------------------------------
+// Several operators have more than one implementation (an LDS-DMA kernel next to the register-staged one, a fused next
+// to a composed path ...).  Every arm is a complete, parity-tested implementation of the same operator -- tests cover the
+// fallback arms through these switches, profiles/ uses them for A/B lines -- and none of them changes what is computed,
+// only by which kernel.  They are read from the environment ONCE, in one place (context.cpp); nothing else in the
+// library looks at the environment except the tuning-table settings (XM_TUNE_*, XM_AUTOTUNE, XM_HALO_MARGIN) and the
+// workspace log (XM_WS_VERBOSE), all listed in include/xmodal_prof.h.
+enum Path {
+  kPathHybrid,          // XM_NO_HYBRID          partly filled last round split along the reduction (conv.hip hybrid_plan)
+  kPathHalo,            // XM_NO_HALO            halo-patch kernels for <= 3 x 3 unit-stride gathers
+  kPathSkinny,          // XM_NO_SKINNY          fc_skinny_kernel for 1 x 1 layers over few outputs
+  kPathSkinny4,         // XM_NO_SKINNY4         its four-rows-per-block variant
+  kPathStem,            // XM_NO_STEM            single-channel stem kernels (forward and filter derivative)
+  kPathStemWgrad,       // XM_NO_STEM_WGRAD      ... the filter derivative only
+  kPathDma,             // XM_NO_DMA             LDS-DMA kernel for 1 x 1 unit-stride layers
+  kPathFusedStats,      // XM_NO_FUSED_STATS     batch moments from the convolution epilogue
+  kPathDgradMerge,      // XM_DGRAD_MERGE (set = off)  all stride-parity classes of a strided dgrad in one launch
+  kPathFastTranspose,   // XM_NO_FAST_TRANSPOSE  FC-shaped dgrad operands as plain LDS-tiled transposes
+  kPathPoolLds,         // XM_NO_POOL_LDS        LDS-staged fused bnorm + relu + pool forward
+  kPathPoolPatch,       // XM_NO_POOL_PATCH      stride-cell variant of its backward apply
+  kPathPoolPooled,      // XM_NO_POOL_POOLED     backward sums from the pooled tensors
+  kPathCount
+};
+bool path_on(Path p);
+
 // persistent small device objects keyed by content (tap tables)
 const void *cached_device_table(const void *host, size_t bytes);
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence for profiles/<round>/ : run on the GPU box (gpurun), writes gpurun_out/<round>/.
 # usage: tools/collect_profiles.sh r02 [commit]
-R=${1:-r03}
+R=${1:-r04}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -23,6 +23,9 @@ $B --workload cpu-teacher                                   | tail -1 > $O/bench
 XM_DEBUG_DIST=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_capi_1rank.json
 XM_DEBUG_DIST=1 $B --parserv torch --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_torch_1rank.json
 XM_DEBUG_DIST=1 XM_PS_LATE=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_capi_late_init.json   # communicator created AFTER the nets: the 12 % trap (xmodal.h CALL ORDER)
+# round 4: `bench.py --gpus 2` with no launcher around it starts its two ranks itself (XM_DEBUG_DIST=gloo0: both on this box's one
+# GPU, exchange over gloo -- a functional run of the N > 1 path; the throughput means nothing)
+XM_DEBUG_DIST=gloo0 $B --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | grep "^{" | tail -1 > $O/bench_distill_gpus2_gloo0.json
 # round-3 experiments behind DESIGN.md 2.3b: where the main stream spends its time; scheduling variants that moved nothing
 NS="--no-cpu-baseline --no-roofline --north-star 0"
 {
@@ -32,16 +35,19 @@ NS="--no-cpu-baseline --no-roofline --north-star 0"
 {
   for tb in 0 64 128 256; do echo -n "--teacher-batch $tb: "; $B $NS --teacher-batch $tb 2>/dev/null | tail -1 | cut -c60-112; done
   for g in "" loss conv5 conv3 conv2 bn1; do echo -n "--teacher-gate '$g': "; $B $NS --teacher-gate "$g" 2>/dev/null | tail -1 | cut -c60-112; done
-  for e in "XM_X=1" "XM_WGRAD_AFTER_DGRAD=1" "XM_SIDE_PRIO=0 XM_MAIN_PRIO=-1" "XM_NO_FUSED_STATS=1" "XM_NO_FUSED_BIASDER=1" "XM_NO_FAST_TRANSPOSE=1" "XM_NO_HALO=1" "XM_NO_HYBRID=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1" "XM_NO_SKINNY4=1"; do
+  for e in "XM_X=1" "XM_NO_FUSED_STEM_BWD=1" "XM_WGRAD_AFTER_DGRAD=1" "XM_SIDE_PRIO=0 XM_MAIN_PRIO=-1" "XM_NO_FUSED_STATS=1" "XM_NO_FUSED_BIASDER=1" "XM_NO_FAST_TRANSPOSE=1" "XM_NO_HALO=1" "XM_NO_HYBRID=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1" "XM_NO_SKINNY4=1" "XM_TUNE_FILE= XM_HALO_MARGIN=0.04" "XM_TUNE_FILE= XM_HALO_MARGIN=0.015"; do
     echo -n "$e: "; env $e $B $NS 2>/dev/null | tail -1 | cut -c60-112; done
   for e in "XM_X=1" "XM_NO_HALO=1" "XM_NO_FUSED_STATS=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1"; do echo -n "student batch 64, $e: "; env $e $B $NS --workload student 2>/dev/null | tail -1 | cut -c50-100; done
   for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1"; do echo -n "config 3 (SE-ResNet50 fwd, 128), $e: "; env $e $B $NS --workload teacher 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done
-  for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1"; do echo -n "north_star batch 256 (SE-ResNet50), $e: "; env $e $B $NS --teacher senet50 --per-gpu-batch 256 --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c60-112; done
+  for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1" "XM_NO_FUSED_STEM_BWD=1" "XM_TUNE_FILE= XM_HALO_MARGIN=0.04" "XM_TUNE_FILE= XM_HALO_MARGIN=0.015"; do echo -n "north_star batch 256 (SE-ResNet50), $e: "; env $e $B $NS --teacher senet50 --per-gpu-batch 256 --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c60-112; done
+  for e in "XM_X=1" "XM_NO_FUSED_SE_BWD=1" "XM_NO_FUSED_STEM_BWD=1"; do echo -n "config-5 shard (joint, 64 pairs), $e: "; env $e $B $NS --workload joint 2>/dev/null | tail -1 | cut -c60-112; done
+  for c in 32 64 128; do echo -n "north_star batch 256, frozen teacher in slices of $c faces (--teacher-chunk): "; $B $NS --teacher senet50 --per-gpu-batch 256 --steps 10 --warmup 3 --teacher-chunk $c 2>/dev/null | tail -1 | cut -c60-112; done
 } > $O/schedule_experiments.txt
 for n in 32 64 256; do python tools/halo_bench.py $n 2>&1 | grep -v amdgpu; done > $O/halo_bench.txt
 { for n in 32 64; do python tools/stem_bench.py $n 2>&1 | grep -v amdgpu; done; hipcc --offload-arch=gfx950 -O3 tools/store_mfma_probe.hip -o /tmp/smp 2>/dev/null && /tmp/smp; } > $O/stem_bench.txt
 python tools/stats_bench.py 32 2>&1 | grep -v amdgpu > $O/stats_bench.txt
 python tools/bnbwd_bench.py 32 2>&1 | grep -v amdgpu > $O/bnbwd_bench.txt
+{ for n in 32 64 256; do python tools/stem_bwd_bench.py $n 2>&1 | grep -v amdgpu; done; python tools/mall_chunk_bench.py 32 2>&1 | grep -v amdgpu; } > $O/stem_bwd_bench.txt
 # per-kernel durations of the serial pass (what roofline.avg_launch_ms is compared with)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o run -- $B --serial --no-cpu-baseline --steps 60 --warmup 10 \
     > $O/bench_under_rocprof.json 2> $O/rocprof_kt.log
