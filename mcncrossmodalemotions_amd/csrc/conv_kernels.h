@@ -1753,37 +1753,66 @@ conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
     p.in = pq < (uint32_t)a.NP;
     return p;
   };
-  // The pair of a cell is (window row kh - 1, kh).  The first cell of a column (kh = 0) loads (0, 1) and the last one
-  // (kh = pHo: rows 2 pHo, 2 pHo + 1, covered by window row pHo - 1 only) loads (pHo - 2, pHo - 1) instead, so that every
-  // load of an EXISTING window lies inside its plane -- nothing depends on how the hardware range-checks an access
-  // that straddles the end of the tensor (a 2-byte load whose second byte is out of range returns zero for both).
-  // The decode picks the slot by pshift (four selects per loaded pair).
-  int pbase[2];          // per cell: element index of the loaded pair at window column j >> 1, channel row lc
-  int pshift[2];         // 0: normal, 1: first cell (window row kh arrives in slot 0), 2: last cell (kh - 1 arrives in slot 1)
-  unsigned pcode[2][2];  // per cell, per window column: expected codes (even row / window row kh - 1) | (even / kh) << 8 | (odd / kh) << 16
+  // Pooled operands: per lane and window-column slot s (s = 1: window column jA >> 1, s = 0: the one before it) ONE
+  // 12-byte load fetches the derivatives of three consecutive elements of the pooled plane and ONE 4-byte load their
+  // routing codes -- window rows (khA - 1, khA, khA + 1) for the two stride cells A, B of an ordinary quad.  Consecutive
+  // elements wrap into the next window column, which is exactly what a quad that straddles two image columns needs (its
+  // second cell is the first cell of the next column).  Where the triple starts is the only case analysis: at window
+  // row 0 for the first cell of a column, pHo - 3 when cell B is the last cell of its column (or A is and no further
+  // window column exists), pHo - 2 for a straddling quad -- always such that every load that carries an EXISTING window
+  // lies inside the tensor as a whole: a load that straddles either end of the buffer is dropped entirely (seen twice:
+  // a 2-byte load whose second byte is past the end returned zero for both; a 12-byte load that starts 8 bytes in
+  // front of the tensor returned zero for its third, in-range element -- the range check looks at the per-lane offset).  Which pixel takes
+  // what from which element follows from ONE coverage formula, evaluated per tile into expected codes
+  // (dh + 3 dw, or 255 = "this window does not cover this pixel / does not exist"): no per-case decode.
+  // The code dword is loaded one byte early (its unused byte in front) except for triples that start a column.
+  int pbase[2];          // per slot: element index of the triple's first element, channel row lc
+  int pcs[2];            // per slot: 8 * (bytes the code dword starts in front of the triple)
+  unsigned pexp[2][4];   // per slot and pixel: expected codes of the triple's three windows, one byte each
   bool pin = false;      // Prod::in of the tile these belong to
   bool pfull = false;    // wave-uniform: all 32 pixels and all 96 rows of the tile exist (no zeroing at the write)
   auto pooled_geometry = [&](const Cols &c, const Prod &pr, int tile) {
     const int q0 = c.iF + PI * c.jF + 4 * lk;
     pin = pr.in;
     pfull = (uint32_t)tile * 128u + 32u * wv + 32u <= (uint32_t)a.NP && a.M == 32 * TM;
-#pragma unroll
-    for (int cell = 0; cell < 2; ++cell) {
-      int qq = q0 + 2 * cell, n = c.nF;
+    int ci[2], cj[2], n = c.nF;                     // cells A, B: first row, column (quads never straddle samples)
+    {
+      int qq = q0;
       if (qq >= PIJ) qq -= PIJ, ++n;
-      const int j = (int)xm_div((uint32_t)qq, a.divPI), i = qq - PI * j, kh = i >> 1;
-      const int wo1 = j >> 1, dw1 = j & 1;
-      pshift[cell] = kh == 0 ? 1 : (kh >= a.pHo ? 2 : 0);
-      pbase[cell] = (kh - 1 + (kh == 0 ? 1 : (kh >= a.pHo ? -1 : 0))) + a.pHo * wo1 + (n * a.M + lc) * pHW;
-      const bool lo = kh >= 1 && kh - 1 < a.pHo, hi = kh < a.pHo;
-      const bool c0 = dw1 == 0 && wo1 >= 1 && wo1 - 1 < a.pWo, c1 = wo1 < a.pWo;
-      auto codes = [&](bool cv, int dw) {
-        const unsigned e_lo = (cv && lo) ? 2u + 3u * dw : 255u, e_hi = (cv && hi) ? 0u + 3u * dw : 255u,
-                       o_hi = (cv && hi) ? 1u + 3u * dw : 255u;
-        return e_lo | (e_hi << 8) | (o_hi << 16);
-      };
-      pcode[cell][0] = codes(c0, 2);
-      pcode[cell][1] = codes(c1, dw1);
+#pragma unroll
+      for (int cell = 0; cell < 2; ++cell) {
+        const int qc = qq + 2 * cell;
+        cj[cell] = (int)xm_div((uint32_t)qc, a.divPI);
+        ci[cell] = qc - PI * cj[cell];
+      }
+    }
+    const int khA = ci[0] >> 1, khB = ci[1] >> 1;
+    const bool straddle = cj[1] != cj[0];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      int wo = (cj[0] >> 1) - (sl ? 0 : 1);
+      int hb;
+      if (khA == 0) hb = 0;
+      else if (!straddle) hb = khB >= a.pHo ? a.pHo - 3 : khA - 1;
+      else if (wo < 0) hb = 0, wo += 1;      // (only cell B's window column exists: the triple starts AT it -- a load
+                                             // that starts in front of the tensor is dropped as a whole, see below)
+      else hb = wo + 1 < a.pWo ? a.pHo - 2 : a.pHo - 3;
+      pbase[sl] = hb + a.pHo * wo + (n * a.M + lc) * pHW;
+      pcs[sl] = hb == 0 ? 0 : 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pi = ci[e >> 1] + (e & 1), pj = cj[e >> 1];
+        unsigned packed = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int w = hb + t;
+          const int ho = w >= a.pHo ? w - a.pHo : w, wot = wo + (w >= a.pHo ? 1 : 0);
+          const int dh = pi - 2 * ho, dw = pj - 2 * wot;
+          const bool ok = (unsigned)dh <= 2u && (unsigned)dw <= 2u && wot >= 0 && wot < a.pWo;
+          packed |= (ok ? (unsigned)(dh + 3 * dw) : 255u) << (8 * t);
+        }
+        pexp[sl][e] = packed | 0xFF000000u;
+      }
     }
   };
   auto x_issue = [&](f32x4 (&xq)[4], const Prod &pr, int rt) {
@@ -1794,22 +1823,20 @@ conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
       xq[kk] = __builtin_bit_cast(f32x4, v);
     }
   };
-  f32x2 pd[2][2][2];     // [row group of the half][cell][window column]: derivatives of the loaded window-row pair
-  unsigned pa[2][2][2];  // their routing codes (2 bytes)
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  f32x3 pd[2][2];        // [row group of the half][slot]: derivatives of the triple
+  unsigned pa[2][2];     // their routing codes
   auto pooled_issue = [&](int rt, int h) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int mrow = (32 * rt + 8 * (2 * h + kk)) * pHW;     // scalar part of the channel row
 #pragma unroll
-      for (int cell = 0; cell < 2; ++cell)
-#pragma unroll
-        for (int wc = 0; wc < 2; ++wc) {
-          typedef unsigned u2 __attribute__((ext_vector_type(2)));
-          const int idx = pbase[cell] - (wc ? 0 : a.pHo);     // (may be negative in front of the tensor: out of range -> 0, code 255)
-          const u2 v = __builtin_amdgcn_raw_buffer_load_b64(dprsrc, idx * 4, mrow * 4, 0);
-          pd[kk][cell][wc] = __builtin_bit_cast(f32x2, v);
-          pa[kk][cell][wc] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(amrsrc, idx, mrow, 0);
-        }
+      for (int sl = 0; sl < 2; ++sl) {
+        typedef unsigned u3 __attribute__((ext_vector_type(3)));
+        const u3 v = __builtin_amdgcn_raw_buffer_load_b96(dprsrc, pbase[sl] * 4, mrow * 4, 0);
+        pd[kk][sl] = __builtin_bit_cast(f32x3, v);
+        pa[kk][sl] = __builtin_amdgcn_raw_buffer_load_b32(amrsrc, pbase[sl] - (pcs[sl] >> 3), mrow, 0);
+      }
     }
   };
   auto decode_write = [&](const f32x4 (&xq)[4], int rt, int h) {
@@ -1822,19 +1849,16 @@ conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
       const float2 rcc = *reinterpret_cast<const float2 *>(sRC + 6 * m + 4);    // k1 lo, k2
       float dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cell = 0; cell < 2; ++cell)
+      for (int sl = 0; sl < 2; ++sl) {     // (window column outer, window row inner: bnpool_bwd_apply_patch_kernel's order)
+        const unsigned cd = pa[kk][sl] >> pcs[sl];
 #pragma unroll
-        for (int wc = 0; wc < 2; ++wc) {
-          const unsigned x_ = pa[kk][cell][wc], e_ = pcode[cell][wc];
-          const unsigned b0_ = x_ & 255u, b1_ = (x_ >> 8) & 255u;
-          const unsigned chi = pshift[cell] == 1 ? b0_ : b1_, clo = pshift[cell] == 2 ? b1_ : b0_;
-          const float vhi = pshift[cell] == 1 ? pd[kk][cell][wc].x : pd[kk][cell][wc].y;
-          const float vlo = pshift[cell] == 2 ? pd[kk][cell][wc].y : pd[kk][cell][wc].x;
-          const bool m0 = clo == (e_ & 255u), m1 = chi == ((e_ >> 8) & 255u), m2 = chi == (e_ >> 16);
-          dz[2 * cell] += m0 ? vlo : 0.f;       // (window column outer, window row inner: bnpool_bwd_apply_patch_kernel's order)
-          dz[2 * cell] += m1 ? vhi : 0.f;
-          dz[2 * cell + 1] += m2 ? vhi : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const unsigned x_ = cd ^ pexp[sl][e];      // byte t == 0  <=>  window t routes to this pixel
+          dz[e] += (x_ & 0x000000FFu) == 0u ? pd[kk][sl].x : 0.f;
+          dz[e] += (x_ & 0x0000FF00u) == 0u ? pd[kk][sl].y : 0.f;
+          dz[e] += (x_ & 0x00FF0000u) == 0u ? pd[kk][sl].z : 0.f;
         }
+      }
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

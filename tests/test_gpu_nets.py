@@ -605,7 +605,25 @@ def test_profiler_names_are_the_kernels_that_exist(gpu):
         names.add(name)
         assert ("xm::%s(" % name) in syms, "%r (key %d) is not a kernel of %s" % (name, keys[i], _lib.SO_PATH)
     fam = {nm.split("<")[0] for nm in names}
-    assert {"conv_gemm_kernel", "conv_wgrad_kernel", "conv_gemm_multi_kernel"} <= fam or "conv_halo_multi_kernel" in fam, fam
+    assert {"conv_gemm_kernel", "conv_wgrad_kernel", "conv_stem_wgrad_bnp_kernel"} <= fam and len(fam) >= 5, fam
+    # the merged strided dgrad (the kernel whose key was mis-decoded): the student's conv2 geometry at 16 samples (the
+    # classes merge into one launch when they have >= 512 tiles together)
+    x = torch.randn((16, 96, 73, 126), device="cuda").permute(3, 2, 1, 0)
+    f = (torch.randn((256, 96, 5, 5), device="cuda") * 0.05).permute(3, 2, 1, 0)
+    dzdy = torch.randn((16, 256, 36, 62), device="cuda").permute(3, 2, 1, 0)
+    L.xm_prof_enable(1)
+    vl.vl_nnconv(x, f, None, dzdy, stride=2, pad=1, no_der_filters=True)
+    torch.cuda.synchronize()
+    L.xm_prof_enable(0)
+    n = L.xm_prof_collect(cap, keys, ms, fl, cnt)
+    merged = []
+    assert n <= cap
+    for i in range(n):
+        buf = C.create_string_buffer(128)
+        L.xm_prof_kernel_name(keys[i], buf, 128)
+        assert ("xm::%s(" % buf.value.decode()) in syms, buf.value.decode()
+        merged.append(buf.value.decode())
+    assert any("multi" in m for m in merged), merged
 
 
 def test_shipped_tuning_table_covers_the_bench_step(gpu):
