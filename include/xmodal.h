@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply, xm_se_squeeze_bn, xm_scale_axpy_bn (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -268,6 +268,13 @@ int xm_nndropout_apply(const float *x, const float *mask, size_t n, float *y, vo
  *                               DG / DB.  `moments` are the batch moments of U the forward pass used (train = 1) or
  *                               the stored ones (train = 0).  Same formulas as the separate operators (the bnorm's
  *                               per-element expression in fp64); X is recomputed from U where it is needed. */
+/* ... and its forward without materialising X: GP = mean_hw(vl_nnbnorm(U)) and Y = [relu](A .* vl_nnbnorm(U) + S) straight
+ * from U (the bnorm's own per-element expression: the same bits as vl_nnbnorm followed by vl_nnpool / Axpy), `moments`
+ * as above.  With the two backward calls X is never needed, so the bnorm's apply pass disappears. */
+int xm_se_squeeze_bn(const float *u, int H, int W, int C, int N, const float *g, const float *b, const float *moments,
+                     float *gp_out, void *stream);
+int xm_scale_axpy_bn(const float *u, int H, int W, int C, int N, const float *a, const float *r, const float *g,
+                     const float *b, const float *moments, int flags, float *y, void *stream);
 int xm_se_tail_backward_reduce(const float *y, const float *dzdy, const float *u, int H, int W, int C, int N,
                                const float *g, const float *b, const float *moments, float *da_out, double *plane_sums,
                                void *stream);

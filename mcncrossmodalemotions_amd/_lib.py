@@ -75,6 +75,8 @@ SIGNATURES = {
     "xm_sum2": [c_fp, c_fp, _sz, _i, c_fp, _vp],
     "xm_scale_axpy": [c_fp, _i, _i, c_fp, c_fp, _i, c_fp, _vp],
     "xm_scale_backward": [c_fp, _i, _i, c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_se_squeeze_bn": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_scale_axpy_bn": [c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp, c_fp, _i, c_fp, _vp],
     "xm_se_tail_backward_reduce": [c_fp, c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_se_tail_backward_apply": [c_fp, c_fp, c_fp] + [_i] * 4 + [c_fp, c_fp, c_fp, c_fp, _i, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
     "xm_nnsoftmaxt": [c_fp, _i, _i, _i, _f, c_fp, _vp],

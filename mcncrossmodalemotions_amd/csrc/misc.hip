@@ -83,6 +83,66 @@ scale_axpy_kernel(const float *__restrict__ x, const float *__restrict__ a,
   }
 }
 
+// ---- forward of the same tail without materialising the bnorm's output ------------------------------------------------
+// x = g/sigma (u - mu) + b is consumed by exactly two readers, the squeeze and the excite, and the fused backward above
+// never reads it: both readers recompute it from u with bn_apply_kernel's own expression (same bits), so the bnorm's
+// apply pass (read u, write x) disappears.  One wave per plane for the squeeze (pool_global_kernel's summation order).
+__global__ void __launch_bounds__(256)
+se_squeeze_bn_kernel(const float *__restrict__ u, const float *__restrict__ g, const float *__restrict__ b,
+                     const float *__restrict__ mom, int HW, int C, int planes, float *__restrict__ gp) {
+  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= planes) return;
+  const int lane = threadIdx.x & 63, c = plane % C;
+  const float *p = u + (size_t)plane * HW;
+  const float sc = g[c] / mom[C + c], mu = mom[c], bb = b[c];
+  float r = 0.f;
+  if ((HW & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll 4
+    for (int i = lane; i < (HW >> 2); i += 64) {
+      const float4 v = p4[i];
+      r += ((sc * (v.x - mu) + bb) + (sc * (v.y - mu) + bb)) + ((sc * (v.z - mu) + bb) + (sc * (v.w - mu) + bb));
+    }
+  } else {
+    for (int i = lane; i < HW; i += 64) r += sc * (p[i] - mu) + bb;
+  }
+  r = xm_wave_sum(r);
+  if (lane == 0) gp[plane] = r / (float)HW;
+}
+
+// y = [relu](a .* bn(u) + r)
+__global__ void __launch_bounds__(256)
+scale_axpy_bn_kernel(const float *__restrict__ u, const float *__restrict__ a, const float *__restrict__ r,
+                     const float *__restrict__ g, const float *__restrict__ b, const float *__restrict__ mom,
+                     float *__restrict__ y, FastDiv divHW, int C, size_t total, int relu) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool vec = (divHW.d & 3) == 0 && ((((uintptr_t)u | (uintptr_t)r | (uintptr_t)y) & 15) == 0);
+  if (vec) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < (total >> 2); i += stride) {
+      const uint32_t plane = xm_div((uint32_t)(i << 2), divHW);
+      const int c = plane % C;
+      const float sc = g[c] / mom[C + c], mu = mom[c], bb = b[c], av = a[plane];
+      const float4 v = reinterpret_cast<const float4 *>(u)[i];
+      const float4 s = r ? reinterpret_cast<const float4 *>(r)[i] : float4{0.f, 0.f, 0.f, 0.f};
+      float4 o;
+      o.x = av * (sc * (v.x - mu) + bb) + s.x;
+      o.y = av * (sc * (v.y - mu) + bb) + s.y;
+      o.z = av * (sc * (v.z - mu) + bb) + s.z;
+      o.w = av * (sc * (v.w - mu) + bb) + s.w;
+      if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+      reinterpret_cast<float4 *>(y)[i] = o;
+    }
+  } else {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += stride) {
+      const uint32_t plane = xm_div((uint32_t)i, divHW);
+      const int c = plane % C;
+      float v = a[plane] * (g[c] / mom[C + c] * (u[i] - mom[c]) + b[c]) + (r ? r[i] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      y[i] = v;
+    }
+  }
+}
+
 // ---- backward of the tail of an SE bottleneck block in TRAINING mode (teacher/ferplus_baselines.m:140-141, config 5) ----
 //   u -> vl_nnbnorm -> x ;  gp = mean_hw(x) -> fc1 -> relu -> fc2 -> sigmoid = a ;  y = relu(a .* x + shortcut)
 // The separate operators make 13 passes over block-sized tensors on the way back (relu mask 3, scale backward 3,
@@ -598,6 +658,31 @@ int xm_scale_axpy(const float *x, int HW, int CN, const float *a, const float *r
   size_t total = (size_t)HW * CN;
   hipLaunchKernelGGL(scale_axpy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, a,
                      r, y, make_fastdiv((uint32_t)HW), total, (flags & XM_FUSE_RELU) ? 1 : 0);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_se_squeeze_bn(const float *u, int H, int W, int C, int N, const float *g, const float *b, const float *moments,
+                     float *gp_out, void *stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "SE squeeze: empty tensor");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "SE squeeze: tensor with >= 2^31 elements");
+  if (!u || !g || !b || !moments || !gp_out) return fail(XM_EINVAL, "SE squeeze: NULL tensor");
+  const int planes = C * N;
+  hipLaunchKernelGGL(se_squeeze_bn_kernel, dim3((planes + 3) / 4), dim3(256), 0, (hipStream_t)stream, u, g, b, moments,
+                     H * W, C, planes, gp_out);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+int xm_scale_axpy_bn(const float *u, int H, int W, int C, int N, const float *a, const float *r, const float *g,
+                     const float *b, const float *moments, int flags, float *y, void *stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || N <= 0) return fail(XM_EINVAL, "scale: empty tensor");
+  if (too_big(H, W, C, N)) return fail(XM_ETOOBIG, "scale: tensor with >= 2^31 elements");
+  if (!u || !a || !g || !b || !moments || !y) return fail(XM_EINVAL, "scale: NULL tensor");
+  const size_t total = (size_t)H * W * C * N;
+  const unsigned grid = (unsigned)std::min<size_t>((total / 4 + 255) / 256 + 1, (size_t)256 * 64);
+  hipLaunchKernelGGL(scale_axpy_bn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, a, r, g, b, moments, y,
+                     make_fastdiv((uint32_t)(H * W)), C, total, (flags & XM_FUSE_RELU) ? 1 : 0);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }

@@ -832,6 +832,10 @@ class _Step:
 
     def forward(self, net):
         r = self.rec
+        if self.se_bn is not None and self.se_bn.fwd is not None and isinstance(r.block, GlobalPooling):
+            f = self.se_bn.fwd      # the squeeze of a fused SE tail: straight from the bnorm's input
+            net.vars[r.outputs[0]].value = vl.se_squeeze_bn(f["u"], f["g"], f["b"], f["moments"])
+            return
         ins = [net.vars[v].value for v in r.inputs]
         if net._training and net.wgradStream is not None and isinstance(r.block, Conv) and \
                 net.vars[r.inputs[0]].fanin > 0 and net.prepareBackward:
@@ -982,7 +986,11 @@ class _AddReluStep(_Step):
     def forward(self, net):
         r = self.rec
         ins = [net.vars[v].value for v in r.inputs]
-        y = r.block.forward(ins, [], relu=True)[0]
+        if self.se_bn is not None and self.se_bn.fwd is not None:
+            f = self.se_bn.fwd      # the excite of a fused SE tail: a .* bnorm(u) + shortcut, relu
+            y = vl.scale_axpy_bn(f["u"], ins[0], ins[2], f["g"], f["b"], f["moments"], relu=True)
+        else:
+            y = r.block.forward(ins, [], relu=True)[0]
         net.vars[self.relu_rec.outputs[0]].value = y
 
     def backward(self, net):
@@ -1012,17 +1020,40 @@ class _SEBnTrainStep(_Step):
         super().__init__(bn_rec)
         self.axpy_step, self.gp_step = axpy_step, gp_step
         self.stash = None
+        self.fwd = None
         axpy_step.se_bn = self
         gp_step.se_bn = self
+
+    def forward(self, net):
+        """X has exactly two readers, the squeeze and the excite, and the fused backward never reads it: both recompute
+        it from U (vl.se_squeeze_bn, vl.scale_axpy_bn -- the bnorm's own per-element expression), so the bnorm's apply
+        pass is skipped and X is never written.  Needs the batch moments the producing convolution's epilogue left."""
+        r = self.rec
+        self.fwd = None
+        xv = net.vars[r.outputs[0]]
+        if net.fuseSETrain and net._training and not xv.precious:
+            g, b, mom = self._params(net)
+            test = net.mode == "test"
+            moments = mom if test else r.block.take_pre_moments()
+            if moments is not None:
+                r.block.moments = None if test else moments
+                self.fwd = {"u": net.vars[r.inputs[0]].value, "g": g, "b": b, "moments": moments}
+                xv.value = None
+                return
+        super().forward(net)
 
     def begin(self, net, axpy_step, out):
         """called by the Axpy+ReLU step's backward; False = run the separate operators"""
         self.stash = None
         if not net.fuseSETrain:
+            if self.fwd is not None:
+                raise RuntimeError("fused SE tail: fuseSETrain was switched off between the forward and the backward pass")
             return False
         r, ax = self.rec, axpy_step.rec
         gate_v, x_v, sc_v = (net.vars[v] for v in ax.inputs)
         if x_v.precious or net.vars[r.outputs[0]] is not x_v:
+            if self.fwd is not None:
+                raise RuntimeError("fused SE tail: the forward pass skipped X but the fused backward cannot run (%s)" % r.name)
             return False
         g, b, mom = self._params(net)
         test = net.mode == "test"

@@ -475,6 +475,29 @@ def scale_axpy(x, a, r=None, relu=False):
     return y
 
 
+def se_squeeze_bn(u, g, b, moments):
+    """gp = mean_hw(vl_nnbnorm(u, g, b, 'moments', moments)) without materialising the bnorm's output (xm_se_squeeze_bn)"""
+    u = _chk(u, "U")
+    H, W, Cc, N = _shape4(u)
+    gp = mat_empty(1, 1, Cc, N, device=u.device)
+    _lib.check(_L().xm_se_squeeze_bn(_ptr(u), H, W, Cc, N, _ptr(_chk(g, "G")), _ptr(_chk(b, "B")),
+                                     _ptr(_chk(moments, "MOMENTS")), _ptr(gp), _stream()))
+    return gp
+
+
+def scale_axpy_bn(u, a, r, g, b, moments, relu=False):
+    """y = [relu](a .* vl_nnbnorm(u, g, b, 'moments', moments) + r) (xm_scale_axpy_bn)"""
+    u, a = _chk(u, "U"), _chk(a, "A")
+    H, W, Cc, N = _shape4(u)
+    if a.numel() != Cc * N:
+        raise ValueError("scale: A must be 1 x 1 x %d x %d" % (Cc, N))
+    y = mat_empty(H, W, Cc, N, device=u.device)
+    _lib.check(_L().xm_scale_axpy_bn(_ptr(u), H, W, Cc, N, _ptr(a), _ptr(None if r is None else _chk(r, "R")),
+                                     _ptr(_chk(g, "G")), _ptr(_chk(b, "B")), _ptr(_chk(moments, "MOMENTS")),
+                                     1 if relu else 0, _ptr(y), _stream()))
+    return y
+
+
 def se_tail_backward_reduce(y, dzdy, u, g, b, moments):
     """first half of the fused SE-tail backward (xm_se_tail_backward_reduce): returns (da 1 x 1 x C x N, plane sums)"""
     y, dzdy, u = _chk(y, "Y"), _chk(dzdy, "DZDY"), _chk(u, "U")

@@ -776,6 +776,13 @@ def test_se_tail_backward(gpu, shape, train):
     d = vl.from_numpy
     gd, bd = d(g.reshape(C, 1)), d(b.reshape(C, 1))
     md = d(mref)
+    # forward halves: squeeze and excite straight from u (the bnorm's output is never materialised)
+    gp = vl.se_squeeze_bn(d(u), gd, bd, md)
+    close(vl.to_numpy(gp), O.vl_nnpool(x, (H, W), method="avg"), 2e-5, "squeeze of bnorm(u)")
+    yd = vl.scale_axpy_bn(d(u), d(a), d(s), gd, bd, md, relu=True)
+    close(vl.to_numpy(yd), y, 2e-5, "excite of bnorm(u)")
+    x_hip, _ = vl.vl_nnbnorm(d(u), gd, bd, moments=md)
+    assert np.array_equal(vl.to_numpy(yd), vl.to_numpy(vl.scale_axpy(x_hip, d(a), d(s), relu=True)))   # the same bits
     da, sums = vl.se_tail_backward_reduce(d(y), d(dzdy), d(u), gd, bd, md)
     close(vl.to_numpy(da), da_ref, what="da")
     dz, du, dg, db = vl.se_tail_backward_apply(d(y), d(dzdy), d(u), d(a), d(dgp), gd, md, sums, train=train)
