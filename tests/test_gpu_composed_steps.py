@@ -9,7 +9,7 @@ assertion):
 
 The oracle (fp64 accumulate, oracle/graphs.py) runs on the GPU box's host cores; derivatives are the identification
 test of tests/test_gpu_nets_full.py (decisions of the HIP pass compared with the oracle's, oracle backward re-run with
-them injected, every sampled entry within 5e-4 * max|ref| + 4 x the fp32 floor of the reference's own arithmetic), and
+them injected, every sampled entry within 1e-4 * max|ref| + 4 x the fp32 floor of the reference's own arithmetic), and
 the parameters AFTER the update are compared with oracle.sgd_update / average_update applied to the oracle's
 derivatives."""
 import os

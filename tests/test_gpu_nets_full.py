@@ -16,10 +16,11 @@ of tolerating them (check_gates / masked_reference): the discrete decisions of t
 the layer outputs, the fused bnorm+relu+pool steps' routing tables) are compared with the oracle's own -- every
 difference must sit at an oracle value within the forward tolerance of the decision boundary -- and the oracle's
 backward pass is then re-run with the HIP path's decisions injected (oracle.graphs.backward(gates=...)).  Against
-that reference EVERY sampled derivative entry must be within 5e-4 of the largest entry plus 4 x the deviation of the
+that reference EVERY sampled derivative entry must be within 1e-4 of the largest entry (north_star's own figure; 5e-4
+until round 4 -- the measured worst case is 0.27 of this allowance) plus 4 x the deviation of the
 reference's own fp32 CPU arithmetic from the fp64 values (make_golden_nets.fp32_deviation: cancellation-dominated
 sums such as conv1's filter derivative, or the exactly-zero bias derivatives in front of a train-mode BatchNorm, sit
-below 5e-4 in any fp32 summation order).  No percentile, no outlier clause."""
+below any relative bound in any fp32 summation order).  No percentile, no outlier clause."""
 import importlib.util
 import os
 
@@ -148,7 +149,7 @@ def check_gates(graph, V, gates, tolf=1e-4):
     return total, flips
 
 
-def check_derivatives(Z, prefix, net, DPm, tol=5e-4, DP32=None):
+def check_derivatives(Z, prefix, net, DPm, tol=1e-4, DP32=None):
     """HIP parameter derivatives against the mask-matched oracle pass: EVERY one of the fixture's sample positions
     within tol * max|ref| + 4 * dev32 (dev32: how far the reference's own fp32 CPU arithmetic is from the fp64 values
     on those positions -- from the fixture, or from `DP32`, the same mask-matched pass in the oracle's fp32 path), and
