@@ -78,3 +78,65 @@ def test_shard_batch_is_interleaved():
     from mcncrossmodalemotions_amd import train
     assert train.shard_batch(range(8), 0, 2) == [0, 2, 4, 6] and train.shard_batch(range(8), 1, 2) == [1, 3, 5, 7]
     assert sorted(sum((train.shard_batch(range(10), r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def _agree_worker(rank, world, port, out):
+    """ParameterServer.start_agreed over 2 gloo workers: the communicator's id travels through the store, and when ONE
+    worker cannot start the library's communicator every worker ends up on torch.distributed (none is left waiting in a
+    collective the others never enter)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcncrossmodalemotions_amd import _lib, train
+    L = _lib.load()
+    ids = []
+    real_id, real_init = L.xm_comm_unique_id, L.xm_comm_init
+
+    class FakeLib:
+        """the library with a communicator that comes up on rank 0 only (no GPU / RCCL in this test)"""
+        def __getattr__(self, name):
+            return getattr(L, name)
+
+        def xm_comm_unique_id(self, buf):
+            for i in range(128):
+                buf[i] = bytes([65 + (i % 26)])
+            return 0
+
+        def xm_comm_init(self, raw, r, w):
+            ids.append(bytes(raw.value if hasattr(raw, "value") else raw)[:16])
+            return 0 if r == 0 else 3        # XM_EHIP on rank 1
+
+        def xm_comm_destroy(self):
+            return 0
+
+        def xm_debug_comm_force_single(self, on):
+            return 0
+
+        def xm_last_error(self):
+            return b"simulated communicator failure"
+    fake = FakeLib()
+    _lib._lib = fake                               # what _lib.load() hands out from now on
+    try:
+        ps = train.ParameterServer.start_agreed("rccl-capi")
+        backend = ps.backend
+        flat = torch.full((4,), float(rank + 1))
+        ps.allreduce_(flat)
+        ps.stop()
+    finally:
+        _lib._lib = L
+    np.save(out + ".%d.npy" % rank, np.array([1.0 if backend == "torch" else 0.0, float(flat[0]), float(len(ids))]))
+    dist.destroy_process_group()
+    assert real_id is not None and real_init is not None
+
+
+def test_start_agreed_falls_back_on_every_worker(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "agree")
+    mp.start_processes(_agree_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        backend_is_torch, summed, inits = np.load(out + ".%d.npy" % r)
+        assert backend_is_torch == 1.0, "worker %d stayed on the failed backend" % r
+        assert summed == 3.0                      # 1 + 2 through the fallback's all-reduce
+        assert inits == 1.0                       # every worker tried the library's communicator exactly once
