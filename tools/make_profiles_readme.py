@@ -2,7 +2,7 @@
 """Regenerates profiles/README.md from the JSON / text evidence under profiles/<round>/.
 usage: python tools/make_profiles_readme.py r02"""
 import json, os, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(root, "profiles", R)
 def L(n): return json.loads(open(os.path.join(P, n + ".json")).read().strip().splitlines()[-1])
@@ -28,7 +28,7 @@ txt = f"""# profiles/ — measured evidence, round {int(R[1:])} (MI355X, 1 GPU, 
 
 Everything under `{R}/` comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
 `bash tools/collect_profiles.sh {R} <commit>` (the script lists every command); this file is generated from
-those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the previous rounds' evidence, unchanged.
+those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r03/` are the previous rounds' evidence, unchanged.
 
 | file | what |
 |---|---|
@@ -48,6 +48,8 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the prev
 | `{R}/phase_marks.txt` | `XM_BENCH_MARKS=1`: timing events on the main stream at the phase boundaries of the student step (forward / backward / join / update / gap to the next step) for the default line and its one-stream / no-side-stream / no-teacher-overlap variants |
 | `{R}/stem_bench.txt` | the student's conv1 through `conv_stem_kernel` and through the implicit-GEMM kernel, with / without batch moments; `tools/store_mfma_probe.hip`: stores / MFMAs / both for the same tile shape, three output layouts, two tile orders (DESIGN.md 2.1e) |
 | `{R}/schedule_experiments.txt` | A/B lines behind DESIGN.md 2.3b: teacher pass over 64 / 128 / 256 faces, `--teacher-gate`, wgrad deferred behind dgrad, stream priorities, and every round-3 kernel change switched off by its environment variable |
+| `{R}/stem_bwd_bench.txt` | round 4: `tools/stem_bwd_bench.py` (conv1's backward chain at 32 / 64 / 256 spectrograms: bnorm + relu + pool backward and the filter derivative as two passes against `xm_nnconv_backward_filter_bnrelupool`, DESIGN.md 2.2e) and `tools/mall_chunk_bench.py` (the same pair in sample chunks that would fit the Infinity Cache: no gain) |
+| `{R}/bench_distill_gpus2_gloo0.json` | round 4: `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it: the command starts its two ranks itself (both on this box's one GPU, exchange over gloo: a functional run of the N > 1 path, `n_gpus` 2 / `rccl_ranks` 2 in the line; the throughput means nothing) |
 | `{R}/halo_bench.txt`, `stats_bench.txt`, `bnbwd_bench.txt` | `tools/halo_bench.py` (halo-patch variants vs the best implicit-GEMM configuration, 32 / 64 / 256 samples), `tools/stats_bench.py` (conv with / without fused batch moments), `tools/bnbwd_bench.py` (bnorm backward chains) |
 | `{R}/kernel_stats_senet50_b256.txt` | rocprofv3 per-kernel summary of north_star's configuration (SE-ResNet50 teacher, 256 pairs, serial mode) |
 | `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` (+ the commit) from the JSON |
@@ -88,16 +90,15 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/`, `r02/` are the prev
 | 8f-1: 13 frames/pair, SE-ResNet50 teacher + student step | 32 pairs (416 faces) | {mf['value']} pairs/s | {mf['ms_per_step']} | {pct(mf['model_frac_of_fp32_mfma_peak'])} |
 | 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
-Round 2 -> round 3 on the default line: 3812 -> {d['value']} pairs/s; student batch 64: 5373 -> {st['value']} samples/s; north_star batch 256
-(SE-ResNet50): 3903 -> {se256['value']} pairs/s; one stream: 3415 -> {ds['value']}.  Where it came from: bnorm batch
-moments from the convolution epilogue (no second pass over the conv output; +0.9 % / +3.5 % at 64); the FC-shaped dgrad
-filter operands as plain LDS-tiled transposes (+0.4 %); halo-patch kernels for 3x3 layers (student batch 64 +1.4...2.3 %, nothing at 32);
-the SE tail of the frozen teachers fused algebraically (2.2d: config 3 11044 -> {te['value']} img/s, every SE-ResNet50 line); the hybrid
-schedule for partly filled last rounds (within +-1 % in this collection's A/B lines); the persistent single-channel stem kernel for the
-student's conv1 (2.1e, `stem_bench.txt`: conv1 + batch moments 298 -> 191 us at 32 spectrograms, its filter derivative 236 -> 167 us); four-row skinny
-fully-connected kernel for fc7 and the SE gates (forward and dgrad).
-What did NOT move the step is in `schedule_experiments.txt`: the step is work-conserving (serial sum 9.2 ms -> {d['ms_per_step']} ms overlapped),
-its main stream never waits (`phase_marks.txt`), and only work removed from the main stream shows up one to one.
+Round 3 -> round 4 on the default line: 3924 -> {d['value']} pairs/s; student batch 64: 5818 -> {st['value']} samples/s; north_star batch 256
+(SE-ResNet50): 4197 -> {se256['value']} pairs/s; config-5 shard: 1750 -> {jo['value']} pairs/s; one stream: 3574 -> {ds['value']}.  Where it came from
+(DESIGN.md 2.2e, 2.2f): conv1's filter derivative computed straight through bnorm + relu + pool (`conv_stem_wgrad_bnp_kernel`: the 462 MB
+derivative of the student's first layer is neither written nor read: chain 0.49 -> 0.38 ms at 32 spectrograms, 3.6 -> 2.8 ms at 256,
+`stem_bwd_bench.txt`); the SE tail of a TRAINED teacher fused in both directions (backward 13 -> 8 passes over the block's tensors, forward
+6 -> 4: every line of config 5).  `schedule_experiments.txt` has every switch of this and the previous round as an A/B line, the halo
+selection margin at 4 / 1.5 / 0 % (lower margins lose 0.8 ... 1.5 %), and the frozen teacher in slices (`--teacher-chunk`: slower).
+The step is work-conserving (serial sum -> {d['ms_per_step']} ms overlapped), its main stream never waits (`phase_marks.txt`), and only
+work removed from the main stream shows up one to one.
 
 ## How the numbers were taken
 ```
