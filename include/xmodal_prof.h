@@ -11,7 +11,8 @@
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
- *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED.
+ *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
+ *                  XM_NO_W8.
  *                  Each chooses between two complete, parity-tested implementations of the same operator (tests cover
  *                  the fallback arms through them, profiles/ holds the A/B lines); none changes what is computed.
  */

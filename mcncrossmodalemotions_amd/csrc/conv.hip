@@ -261,17 +261,39 @@ static const Cfg kCfgs[] = {
     {1, 1, 2, 2},  //  64 x  64
     {1, 1, 4, 1},  // 128 x  32
     {1, 1, 1, 4},  //  32 x 128
+    // EIGHT waves per block: the 128 x 128 tile by waves of 32 x 64 -- 128 VGPRs, so two blocks per CU are four waves per
+    // SIMD instead of two: +3 ... 4 % on the long-reduction forward / dgrad layers (the filter derivative is
+    // 2 % slower with it, 64 x 256 by eight waves is no faster than 64 x 128 by four, 96 x 256 by waves of 96 x 32 spills,
+    // 96 x 128 by six waves stages 512 gather units with 384 threads: 75 against 117 TFLOP/s)
+    {1, 2, 4, 2},  //  7
     // LDS-DMA variants (conv_gemm_dma_kernel): forward / dgrad GEMMs of 1x1 unit-stride layers only
-    {2, 2, 2, 2},  //  7: 128 x 128, 3 LDS stages
-    {2, 2, 1, 4},  //  8:  64 x 256, 3 stages
-    {1, 2, 2, 2},  //  9:  64 x 128, 4 stages
-    {1, 1, 2, 2},  // 10:  64 x  64, 4 stages
+    {2, 2, 2, 2},  //  8: 128 x 128, 3 LDS stages
+    {2, 2, 1, 4},  //  9:  64 x 256, 3 stages
+    {1, 2, 2, 2},  // 10:  64 x 128, 4 stages
+    {1, 1, 2, 2},  // 11:  64 x  64, 4 stages
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kNumBaseCfg = 7;                       // configurations every direction / geometry can run
+constexpr int kNumBaseCfg = 8;                       // configurations every forward / dgrad geometry can run
+constexpr int kCfgW8 = 7;                            // the eight-wave configuration (XM_NO_W8 runs configuration 0 in its place)
+constexpr int kNumWgradCfg = 7;                      // ... and the filter derivative (four-wave configurations only)
 static const int kDmaBase[] = {0, 1, 3, 4};          // the register-staged configuration of the same tile shape
 static inline bool is_dma_cfg(int ci) { return ci >= kNumBaseCfg; }
 static inline int base_cfg(int ci) { return is_dma_cfg(ci) ? kDmaBase[ci - kNumBaseCfg] : ci; }
+static inline int wgrad_cfg(int ci) { ci = base_cfg(ci); return ci >= kNumWgradCfg ? 0 : ci; }
+// The eight-wave configuration is a candidate for launches of at least XM_W8_MIN_TILES 128 x 128 tiles (default: two rounds
+// of the chip).  Measured (profiles/r04/schedule_experiments.txt): alone it is 3 ... 4 % faster at every size, but next to the
+// filter derivatives of the side stream the shorter launches lose more than that (student step at 64 spectrograms - 3 %).
+static inline bool w8_ok(long long M, long long NP) {
+  static const long long min_tiles = getenv("XM_W8_MIN_TILES") ? atoll(getenv("XM_W8_MIN_TILES")) : 1024;
+  return path_on(kPathW8) && ((M + 127) / 128) * ((NP + 127) / 128) >= min_tiles;
+}
+static inline unsigned w8_skip(long long M, long long NP) { return w8_ok(M, NP) ? 0u : 1u << 7; }
+static inline unsigned cfg_threads(int ci) { return 64u * kCfgs[ci].wgm * kCfgs[ci].wgn; }
+// analytic model: relative cost per multiply-add of a configuration (32 x 32 MFMA tiles per block; measured ordering)
+static inline double cfg_eff(const Cfg &c) {
+  const int t = c.tm * c.tn * c.wgm * c.wgn;
+  return c.wgm * c.wgn == 8 ? 0.97 : (t >= 16 ? 1.0 : (t >= 8 ? 1.12 : 1.3));
+}
 
 static int g_force_splits = 0;  // test hook
 
@@ -294,10 +316,11 @@ static int pick_cfg(long long M, long long NP, int nkt) {
   double best = 1e300;
   int bi = 0;
   for (int i = 0; i < kNumBaseCfg; ++i) {
+    if (i == kCfgW8 && !w8_ok(M, NP)) continue;
     const Cfg &c = kCfgs[i];
     long long tiles = ((M + c.bm() - 1) / c.bm()) * ((NP + c.bn() - 1) / c.bn());
     int s = pick_splits((int)std::min<long long>(tiles, 1 << 20), nkt);
-    double eff = (c.tm * c.tn >= 4) ? 1.0 : (c.tm * c.tn >= 2 ? 1.12 : 1.3);
+    double eff = cfg_eff(c);
     double stages = (double)((nkt + s - 1) / s) + 3.0;  // + prologue / epilogue
     double t_block = 2.0 * c.bm() * c.bn() * 16.0 * stages * eff / (157.3e12 / 256.0);
     double blocks = (double)tiles * s;
@@ -327,17 +350,18 @@ static int pick_cfg(long long M, long long NP, int nkt) {
 static void launch_gemm_dma(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_t st) {
   dim3 block(256);
   switch (ci) {
-    case 7: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 2, 2, XM_DMA_NST7>), grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 1, 4, 3>), grid, block, 0, st, a); break;
-    case 9: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 2, 2, 2, XM_DMA_NST9>), grid, block, 0, st, a); break;
+    case kNumBaseCfg + 0: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 2, 2, XM_DMA_NST7>), grid, block, 0, st, a); break;
+    case kNumBaseCfg + 1: hipLaunchKernelGGL((conv_gemm_dma_kernel<2, 2, 1, 4, 3>), grid, block, 0, st, a); break;
+    case kNumBaseCfg + 2: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 2, 2, 2, XM_DMA_NST9>), grid, block, 0, st, a); break;
     default: hipLaunchKernelGGL((conv_gemm_dma_kernel<1, 1, 2, 2, XM_DMA_NST10>), grid, block, 0, st, a); break;
   }
 }
 
 template <int MODE>
 static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_t st) {
-  dim3 block(256);
+  dim3 block(cfg_threads(ci));
   switch (ci) {
+    case 7: hipLaunchKernelGGL((conv_gemm_kernel<1, 2, 4, 2, MODE>), grid, block, 0, st, a); break;
     case 0: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 2, MODE>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 4, MODE>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((conv_gemm_kernel<3, 1, 1, 4, MODE>), grid, block, 0, st, a); break;
@@ -395,8 +419,9 @@ struct ProfScope {
 };
 
 
-// co-resident blocks per CU of the register-staged configurations (VGPR-limited: 222 / 232 / 186 / 140 / 116 / 134 / 122)
-static const int kCfgOcc[kNumBaseCfg] = {2, 2, 2, 3, 4, 3, 4};
+// co-resident blocks per CU of the register-staged configurations (VGPR-limited: 222 / 232 / 186 / 140 / 116 / 134 / 122 /
+// 128 with eight waves)
+static const int kCfgOcc[kNumBaseCfg] = {2, 2, 2, 3, 4, 3, 4, 2};
 
 // Hybrid schedule (ConvGemmArgs::hyS): a launch of more than one round of the chip whose LAST round is partly filled
 // computes the full rounds tile by tile and splits the remaining tiles along the reduction so that they fill the last
@@ -438,6 +463,7 @@ static size_t gemm_slab_floats(const ConvGemmArgs &a, int ci, int *splits_out) {
 
 static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *slab, hipStream_t st) {
   if (is_dma_cfg(ci) && !a.dmaOk) ci = base_cfg(ci);   // forced configuration on a geometry it cannot run
+  if (ci == kCfgW8 && !path_on(kPathW8)) ci = 0;
   const Cfg &c = kCfgs[ci];
   a.nbm = (a.M + c.bm() - 1) / c.bm();
   a.nbn = (a.NP + c.bn() - 1) / c.bn();
@@ -504,8 +530,9 @@ static int launch_gemm(ConvGemmArgs &a, int mode, int ci, int splits, float *sla
 }
 
 static void launch_gemm_multi_cfg(int ci, const ConvGemmMulti &m, dim3 grid, hipStream_t st) {
-  dim3 block(256);
+  dim3 block(cfg_threads(ci));
   switch (ci) {
+    case 7: hipLaunchKernelGGL((conv_gemm_multi_kernel<1, 2, 4, 2>), grid, block, 0, st, m); break;
     case 0: hipLaunchKernelGGL((conv_gemm_multi_kernel<2, 2, 2, 2>), grid, block, 0, st, m); break;
     case 1: hipLaunchKernelGGL((conv_gemm_multi_kernel<2, 2, 1, 4>), grid, block, 0, st, m); break;
     case 2: hipLaunchKernelGGL((conv_gemm_multi_kernel<3, 1, 1, 4>), grid, block, 0, st, m); break;
@@ -519,6 +546,7 @@ static void launch_gemm_multi_cfg(int ci, const ConvGemmMulti &m, dim3 grid, hip
 // up to 4 masked (MODE 1) implicit GEMMs without split-K in one launch, same tile configuration
 static int launch_gemm_multi(const std::vector<ConvGemmArgs> &args, int ci, hipStream_t st) {
   ci = base_cfg(ci);
+  if (ci == kCfgW8 && !path_on(kPathW8)) ci = 0;
   const Cfg &c = kCfgs[ci];
   ConvGemmMulti m{};
   int maxTiles = 0;
@@ -723,7 +751,7 @@ static std::map<TuneKey, int> g_tuned;
 // are then the same in every process, and shapes already in the table pay no timed launches on the caller's
 // stream.  Shapes that are not in the table are still measured once per process (and written back by
 // xm_tune_save).  The header carries XM_TUNE_REV, bumped whenever the kernels or the configuration list change.
-constexpr int XM_TUNE_REV = 6;   // 6: launches with fused batch statistics are their own entries (mode + 4)
+constexpr int XM_TUNE_REV = 7;   // 7: configuration 7 = 128 x 128 by eight waves (the LDS-DMA ones moved to 8 ... 11); 6: fused-statistics launches are their own entries (mode + 4)
 static bool g_tune_loaded = false;
 static int g_tune_new = 0;  // entries measured in this process (not yet saved)
 
@@ -772,7 +800,8 @@ static int autotune_enabled() {
   return on;
 }
 template <class F>
-static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch, int ncfg = kNumBaseCfg) {
+static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch, int ncfg = kNumBaseCfg,
+                    unsigned skip = 0 /* bit ci: configuration not eligible for this launch */) {
   if (g_force_cfg >= 0) return g_force_cfg < ncfg ? g_force_cfg : base_cfg(g_force_cfg);
   if (!autotune_enabled()) return fallback;
   tune_load_once();
@@ -786,7 +815,12 @@ static int tune_cfg(const TuneKey &key, int fallback, hipStream_t st, F &&launch
   static const int reps = getenv("XM_TUNE_REPS") ? std::max(1, atoi(getenv("XM_TUNE_REPS"))) : 2;
   float best = 1e30f;
   int bi = fallback;
+  // The candidates are timed on an otherwise idle device: whatever the other streams of the step had queued is drained first
+  // (the host thread is in here, so nothing new arrives).  Timed next to a neighbour's kernels the choice depended on what
+  // happened to be running -- the shipped table differed from one generation to the next.
+  (void)hipDeviceSynchronize();
   for (int ci = 0; ci < ncfg; ++ci) {
+    if (skip >> ci & 1u) continue;
     float tmin = 1e30f;
     for (int rep = 0; rep < reps; ++rep) {
       (void)hipEventRecord(e0, st);
@@ -831,6 +865,7 @@ static int tune_challengers(const TuneKey &key, hipStream_t st, F &&launch, int 
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
   float tmin[8];
   for (int i = 0; i < 8; ++i) tmin[i] = 1e30f;
+  (void)hipDeviceSynchronize();   // see tune_cfg: the candidates are timed on an otherwise idle device
   for (int rep = 0; rep < 4; ++rep)
     for (int ci = 0; ci < n && ci < 8; ++ci) {
       if (ci > 0 && !ok[ci]) continue;
@@ -1321,7 +1356,7 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
     // longer epilogue, so whichever variant reached a shape first must not fix the choice for the other
     const int tmode = mode + (stats_ok ? 4 : 0);
     TuneKey key{0, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg);
+    int ci = tune_cfg(key, pick_cfg(a.M, a.NP, Rp / kBK), st, run, a.dmaOk ? kNumCfg : kNumBaseCfg, w8_skip(a.M, a.NP));
     if (stem_ok(a, g, x, f)) {
       // the single-channel stem kernel against the best implicit-GEMM configuration (measured once per shape)
       auto run3 = [&](int h) {
@@ -1668,7 +1703,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         return launch_gemm(aa, 1, ci, sp, slab, st);
       };
       TuneKey key{1, a.M, a.NP, c.Rp, c.nU * 64 + c.nV, g.sy * 16 + g.sx, a.PI, c.PJ, g.Ho};
-      int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run);
+      int ci = tune_cfg(key, pick_cfg(a.M, a.NP, c.Rp / kBK), st, run, kNumBaseCfg, w8_skip(a.M, a.NP));
       ConvGemmArgs ah = a;
       const int hneed = (g_force_cfg < 0 && g_force_splits == 0 && !foldH) ? halo_setup_padded(ah, g.N) : 0;
       bool hok[4] = {true, halo_var_ok(ah, hneed, 0), halo_var_ok(ah, hneed, 1), halo_var_ok(ah, hneed, 2)};
@@ -1703,7 +1738,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
     }
     TuneKey key{3, merged[0].M, (int)std::min<long long>(npSum, 1 << 30), rpMax, (int)merged.size(),
                 g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-    int ci = tune_cfg(key, pick_cfg(merged[0].M, npSum, rpMax / kBK), st, run);
+    int ci = tune_cfg(key, pick_cfg(merged[0].M, npSum, rpMax / kBK), st, run, kNumBaseCfg, w8_skip(merged[0].M, npSum));
     // every class a halo-patch problem (unit-stride gathers of <= 3 x 3 taps in dY space)?  Then the same variant for all
     std::vector<ConvGemmArgs> mh = merged;
     bool hok[4] = {true, g_force_cfg < 0, g_force_cfg < 0, g_force_cfg < 0};
@@ -1742,7 +1777,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
 // one wgrad launch (+ split reduction) with tile configuration ci; `part` has room for 1024 slabs
 static int wgrad_run(const float *x, const float *dzdy, float *dfo, const Geo &g, int ci, float *part,
                      hipStream_t st) {
-  ci = base_cfg(ci);
+  ci = wgrad_cfg(ci);
   const Cfg &c = kCfgs[ci];
   const int NP = g.Ho * g.Wo * g.N;
   const int nkt = (NP + kBK - 1) / kBK;
@@ -1912,9 +1947,9 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   int fb = 0;
   {
     double best = 1e300;
-    for (int i = 0; i < kNumBaseCfg; ++i) {
+    for (int i = 0; i < kNumWgradCfg; ++i) {
       const Cfg &cc = kCfgs[i];
-      double eff = (cc.tm * cc.tn >= 4) ? 1.0 : (cc.tm * cc.tn >= 2 ? 1.12 : 1.3);
+      double eff = cfg_eff(cc);
       double cost = (double)((g.Kg + cc.bm() - 1) / cc.bm() * cc.bm()) *
                     ((g.R + cc.bn() - 1) / cc.bn() * cc.bn()) * eff;
       if (cost < best) {
@@ -1936,7 +1971,7 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   float *spart = stem ? ws.take<float>((size_t)stem_grid_ * 96 * 64) : nullptr;
   auto run = [&](int ci) { return wgrad_run(x, dzdy, dfo, g, ci, part, st); };
   TuneKey key{2, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
-  int ci = tune_cfg(key, fb, st, run);
+  int ci = tune_cfg(key, fb, st, run, kNumWgradCfg);
   if (stem) {
     // the single-channel stem's own wgrad kernel against the best generic configuration (measured once per shape)
     auto run2 = [&](int h) { return h ? launch_stem_wgrad(x, dzdy, dfo, g, spart, stem_grid_, st) : run(ci); };
@@ -2108,7 +2143,7 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   const Cfg &c = kCfgs[ci];
   if (kind == 0 && is_dma_cfg(ci))
     snprintf(buf, len, "conv_gemm_dma_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn,
-             ci == 7 ? XM_DMA_NST7 : ci == 8 ? 3 : ci == 9 ? XM_DMA_NST9 : XM_DMA_NST10);
+             ci == kNumBaseCfg ? XM_DMA_NST7 : ci == kNumBaseCfg + 1 ? 3 : ci == kNumBaseCfg + 2 ? XM_DMA_NST9 : XM_DMA_NST10);
   else if (kind == 0)
     snprintf(buf, len, "conv_gemm_kernel<%d, %d, %d, %d, %d>", c.tm, c.tn, c.wgm, c.wgn, key % 2);
   else if (kind == 2)

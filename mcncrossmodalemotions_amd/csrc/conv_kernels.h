@@ -459,11 +459,12 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs &a, f32x16
 template <int TM, int TN, int WGM, int WGN, int MODE>
 __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  static_assert(WGM * WGN == 4, "4 waves per block");
-  static_assert(BN == 32 || BN == 64 || BN == 128 || BN == 256, "BN must divide 256");
+  constexpr int NT = 64 * WGM * WGN;                 // 4 waves per block; 8 in the low-register configuration (kCfgs[7])
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
+  static_assert(BN == 32 || BN == 64 || BN == 128 || BN == 256, "BN must divide the block");
   constexpr int PLA = BM * 4 + 4, PLB = BN * 4 + 4;  // plane strides (floats), 16-B multiples
-  constexpr int NUA = (kNG * BM + 255) / 256;        // float4 units per thread, A
-  constexpr int NUB = (kNG * BN + 255) / 256;        // float4 units per thread, B
+  constexpr int NUA = (kNG * BM + NT - 1) / NT;        // float4 units per thread, A
+  constexpr int NUB = (kNG * BN + NT - 1) / NT;        // float4 units per thread, B
   constexpr bool UNIFORM = BN >= 64;                 // tap group is wave-uniform
   __shared__ __attribute__((aligned(16))) float smem[2 * kNG * (PLA + PLB)];
   float *sA = smem;
@@ -533,8 +534,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   const float *aptr[NUA];
 #pragma unroll
   for (int i = 0; i < NUA; ++i) {
-    int u = t + 256 * i;
-    if (kNG * BM % 256 != 0 && u >= kNG * BM) u = kNG * BM - 1;
+    int u = t + NT * i;
+    if (kNG * BM % NT != 0 && u >= kNG * BM) u = kNG * BM - 1;
     int g = u % kNG, m = u / kNG;
     int gm = min(bm * BM + m, a.M - 1);
     aptr[i] = a.A + (size_t)gm * a.lda + g * 4;
@@ -543,13 +544,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
   float *sAw[NUA], *sBw[NUB];
 #pragma unroll
   for (int i = 0; i < NUA; ++i) {
-    int u = t + 256 * i;
+    int u = t + NT * i;
     int g = u % kNG, m = u / kNG;
     sAw[i] = sA + g * PLA + m * 4;
   }
 #pragma unroll
   for (int i = 0; i < NUB; ++i) {
-    int g = gB0 + i * (256 / BN);
+    int g = gB0 + i * (NT / BN);
     sBw[i] = sB + g * PLB + pl * 4;
   }
   const int half = lane >> 5, l31 = lane & 31;
@@ -564,8 +565,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 
 #define XM_FETCH_TAPS(KT)                                                      \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
-    int g_ = gB0 + i * (256 / BN);                                             \
-    if (kNG * BN % 256 != 0) g_ = min(g_, kNG - 1);                            \
+    int g_ = gB0 + i * (NT / BN);                                             \
+    if (kNG * BN % NT != 0) g_ = min(g_, kNG - 1);                            \
     int r0_ = (KT) * kBK + g_ * 4;                                             \
     if (UNIFORM) r0_ = __builtin_amdgcn_readfirstlane(r0_);                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
@@ -596,10 +597,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 
 #define XM_STORE_TILE(BUF, RA, RB)                                             \
   _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
-    if (kNG * BM % 256 == 0 || t + 256 * i < kNG * BM)                         \
+    if (kNG * BM % NT == 0 || t + NT * i < kNG * BM)                         \
       *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = RA[i];          \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
-    if (kNG * BN % 256 == 0 || gB0 + i * (256 / BN) < kNG)                     \
+    if (kNG * BN % NT == 0 || gB0 + i * (NT / BN) < kNG)                     \
       *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = RB[i];
 
   // One pipeline stage on LDS buffer CUR.  The MFMA operands are double-buffered in REGISTERS: the
@@ -697,7 +698,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 }
 
 template <int TM, int TN, int WGM, int WGN, int MODE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2)   // (threads, waves per SIMD): two blocks per CU
 conv_gemm_kernel(const ConvGemmArgs a) {
 #ifdef XM_DEBUG_CYCLES
   // per-block shader-clock trace (tools/conv_bench.py --cycles).  Compile-time only: even as a never-taken
@@ -1151,7 +1152,7 @@ struct ConvGemmMulti {
   ConvGemmArgs c[4];
 };
 template <int TM, int TN, int WGM, int WGN>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2)
 conv_gemm_multi_kernel(const ConvGemmMulti m) {
   const ConvGemmArgs &a = m.c[blockIdx.z];
   if ((int)blockIdx.x >= a.nbm * a.nbn) return;

@@ -77,6 +77,7 @@ enum Path {
   kPathPoolLds,         // XM_NO_POOL_LDS        LDS-staged fused bnorm + relu + pool forward
   kPathPoolPatch,       // XM_NO_POOL_PATCH      stride-cell variant of its backward apply
   kPathPoolPooled,      // XM_NO_POOL_POOLED     backward sums from the pooled tensors
+  kPathW8,              // XM_NO_W8              128 x 128 tiles by eight waves of 128 VGPRs (conv.hip kCfgs[7]); off = four waves of 222
   kPathCount
 };
 bool path_on(Path p);

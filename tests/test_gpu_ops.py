@@ -572,7 +572,7 @@ def test_conv_hybrid_schedule(gpu, geom):
     _, m_ref = O.vl_nnbnorm(y_ref, O.F(np.ones(K)), O.F(np.zeros(K)), acc64=True)
     old = L.xm_debug_force_conv_halo(0)
     try:
-        for cfg in range(7):
+        for cfg in range(L.xm_debug_num_conv_cfgs() - 4):     # the register-staged ones (the last four are LDS-DMA)
             L.xm_debug_force_conv_cfg(cfg)
             close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=pad)), y_ref, what="hybrid cfg %d" % cfg)
             close(vl.to_numpy(vl.vl_nnconv(xd, fd, bd, pad=pad, **kw)), ref2, what="hybrid cfg %d, fused epilogue" % cfg)
@@ -1046,9 +1046,9 @@ def test_lds_dma_conv_configs(gpu, geom):
     xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(-1, 1))
     scd, shd, rd = vl.from_numpy(sc.reshape(-1, 1)), vl.from_numpy(sh.reshape(-1, 1)), vl.from_numpy(res)
     ncfg = L.xm_debug_num_conv_cfgs()
-    assert ncfg >= 11
+    assert ncfg >= 12
     try:
-        for cfg in range(7, ncfg):
+        for cfg in range(ncfg - 4, ncfg):
             for splits in (0, 3):
                 L.xm_debug_force_conv_cfg(cfg)
                 L.xm_debug_force_conv_splits(splits)

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dirs", default="fwd,dgrad,wgrad")
     ap.add_argument("--scan", action="store_true", help="time every tile configuration (forced)")
+    ap.add_argument("--cfg", type=int, default=-1, help="force ONE tile configuration")
     ap.add_argument("--cycles", action="store_true",
                     help="fwd only: shader clocks spent by block 0 (cycles per 16-k stage, effective clock)")
     args = ap.parse_args()
@@ -73,7 +74,7 @@ def main():
         flops = 2.0 * Ho * Wo * N * K * FH * FW * C
         from mcncrossmodalemotions_amd import _lib
         L = _lib.load()
-        cfgs = list(range(L.xm_debug_num_conv_cfgs())) if args.scan else [-1]
+        cfgs = list(range(L.xm_debug_num_conv_cfgs())) if args.scan else [args.cfg]
         for d, cfg in [(dd, cc) for dd in args.dirs.split(",") for cc in cfgs]:
             L.xm_debug_force_conv_cfg(cfg)
             if d == "fwd":
