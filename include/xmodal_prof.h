@@ -7,14 +7,17 @@
 /*
  * Environment the library reads (nothing else): every name is read once.
  *   tuning table   XM_TUNE_FILE (path; "" disables), XM_AUTOTUNE=0 (analytic model only), XM_TUNE_REPS, XM_TUNE_VERBOSE,
- *                  XM_HALO_MARGIN (a challenger kernel must win by this fraction, default 0.04)
+ *                  XM_HALO_MARGIN (a challenger kernel must win by this fraction, default 0.04), XM_W8_MIN_TILES (the
+ *                  eight-wave configuration is a candidate for launches of at least this many 128 x 128 tiles, default 1024)
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
  *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
  *                  XM_NO_W8.
- *                  Each chooses between two complete, parity-tested implementations of the same operator (tests cover
- *                  the fallback arms through them, profiles/ holds the A/B lines); none changes what is computed.
+ *                  Each chooses between two complete, parity-tested implementations of the same operator (the operator tests
+ *                  force both arms through the xm_debug_force_* hooks; tests/test_gpu_path_switches.py runs whole passes
+ *                  with every selector set, in fresh processes, against the default; profiles/ holds the A/B lines);
+ *                  none changes what is computed.
  */
 #ifndef XMODAL_PROF_H
 #define XMODAL_PROF_H
