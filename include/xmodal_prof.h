@@ -8,12 +8,14 @@
  * Environment the library reads (nothing else): every name is read once.
  *   tuning table   XM_TUNE_FILE (path; "" disables), XM_AUTOTUNE=0 (analytic model only), XM_TUNE_REPS, XM_TUNE_VERBOSE,
  *                  XM_HALO_MARGIN (a challenger kernel must win by this fraction, default 0.04), XM_W8_MIN_TILES (the
- *                  eight-wave configuration is a candidate for launches of at least this many 128 x 128 tiles, default 1024)
+ *                  eight-wave configuration is a candidate for launches of at least this many 128 x 128 tiles, default 1024),
+ *                  XM_WGRAD_PATCH_ANY_STREAM (conv_wgrad_patch_kernel also for calls that arrive on another stream than the
+ *                  forward convolutions: DESIGN.md 2.1g), XM_WGRAD_PATCH_SLOTS (its grid: blocks per round, default 768)
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
  *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
- *                  XM_NO_W8.
+ *                  XM_NO_W8, XM_NO_WGRAD_PATCH.
  *                  Each chooses between two complete, parity-tested implementations of the same operator (the operator tests
  *                  force both arms through the xm_debug_force_* hooks; tests/test_gpu_path_switches.py runs whole passes
  *                  with every selector set, in fresh processes, against the default; profiles/ holds the A/B lines);
@@ -40,6 +42,9 @@ int xm_debug_num_conv_cfgs(void);
 int xm_debug_force_conv_halo(int on);
 /* 1: the single-channel stem kernel (conv_stem_kernel) wherever it can run; 0: never; -1: measured choice (default) */
 int xm_debug_force_conv_stem(int on);
+/* 1: the patch kernel for the filter derivative of 3 x 3 / stride 1 / pad 1 layers (conv_wgrad_patch_kernel) wherever it
+ * can run; 0: never; -1: measured choice (default) */
+int xm_debug_force_wgrad_patch(int on);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);
 /* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,

@@ -113,6 +113,7 @@ _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           # include/xmodal_prof.h
           "xm_debug_force_conv_halo": [_i],
           "xm_debug_force_conv_stem": [_i],
+          "xm_debug_force_wgrad_patch": [_i],
           "xm_prof_enable": [_i],
           "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_longlong)],

@@ -374,6 +374,8 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
 static int g_force_stem = -1; // test hook (xm_debug_force_conv_stem): 1 = conv_stem_kernel wherever it can run, 0 = never
+static int g_force_wgrad_patch = -1; // test hook (xm_debug_force_wgrad_patch)
+static hipStream_t g_last_fwd_stream = nullptr;   // stream of the most recent forward convolution (wgrad_patch_ok)
 static int g_force_halo = -1; // test hook (xm_debug_force_conv_halo): 1 = halo-patch kernel wherever it can run, 0 = never
 static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
@@ -1221,6 +1223,7 @@ static int launch_stem(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
+  g_last_fwd_stream = st;
   // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
   // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
   const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
@@ -1942,6 +1945,58 @@ static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, cons
   return XM_OK;
 }
 
+// ---- filter derivative of 3 x 3 / stride 1 / pad 1 layers from an input patch (conv_wgrad_patch_kernel) -------------------
+// One-stream callers only (the reference's own call sequence, cnn_train_dag -> vl_nnconv one after the other; bench.py
+// --serial): alone the kernel is 11 ... 22 % faster than the generic one (profiles/r04/wgrad_patch_bench.txt), a step on one
+// stream 1.7 %; launched on a side stream next to the dgrad of the same layer it fills the chip with three 48 KB blocks per CU
+// for its whole life and the pair takes LONGER than with the generic kernel (student step at 64: - 1.5 %).
+// "Side stream" = not the stream of the most recent forward convolution; XM_WGRAD_PATCH_ANY_STREAM lifts the restriction.
+static bool wgrad_patch_ok(const Geo &g, const float *x, const float *dzdy, hipStream_t st) {
+  static const bool any_stream = getenv("XM_WGRAD_PATCH_ANY_STREAM") != nullptr;
+  if (!path_on(kPathWgradPatch) || g_force_cfg >= 0 || g_force_splits > 0) return false;
+  if (g_force_wgrad_patch < 0 && !any_stream && st != g_last_fwd_stream) return false;
+  if (g.G != 1 || g.FH != 3 || g.FW != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1) return false;
+  if (g.pt != 1 || g.pb != 1 || g.pl != 1 || g.pr != 1) return false;
+  if (g.H != 30 || g.Ho != g.H || g.Wo != g.W) return false;          // instantiated row counts (HH)
+  if ((((uintptr_t)x | (uintptr_t)dzdy) & 7) != 0) return false;
+  return (long long)g.N * g.W >= 64;                                    // enough stages to split
+}
+static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int max_splits,
+                              hipStream_t st) {
+  WgradPatchArgs a{};
+  a.dY = dzdy;
+  a.X = x;
+  a.xBytes = (unsigned)((size_t)g.H * g.W * g.C * g.N * 4);
+  a.dyBytes = (unsigned)((size_t)g.Ho * g.Wo * g.K * g.N * 4);
+  a.M = g.Kg;
+  a.R = g.R;
+  a.ldo = g.R;
+  a.C = g.C;
+  a.W = g.W;
+  a.K = g.K;
+  a.nStages = g.N * g.W;
+  a.nbm = (g.Kg + 127) / 128;
+  a.nbn = (g.R + 127) / 128;
+  const int tiles = a.nbm * a.nbn;
+  static const int slots = getenv("XM_WGRAD_PATCH_SLOTS") ? std::max(64, atoi(getenv("XM_WGRAD_PATCH_SLOTS"))) : 768;   // one round of 3 blocks per CU
+  int splits = std::max(1, std::min(std::min(a.nStages / 8, slots / std::max(1, tiles)), max_splits));
+  a.stagesPerSplit = (a.nStages + splits - 1) / splits;
+  splits = (a.nStages + a.stagesPerSplit - 1) / a.stagesPerSplit;
+  const size_t slab = (size_t)g.Kg * g.R;
+  a.splitStride = slab;
+  a.out = splits > 1 ? part : dfo;
+  {
+    ProfScope ps(9 * 100, 2.0 * g.Kg * (double)g.Ho * g.Wo * g.N * g.R, st, (double)a.xBytes + (double)a.dyBytes + 4.0 * slab);
+    hipLaunchKernelGGL(conv_wgrad_patch_kernel<30>, dim3(tiles, splits), dim3(256), 0, st, a);
+  }
+  XM_LAUNCH_CHECK();
+  if (splits > 1) {
+    launch_reduce_splits(part, dfo, slab, splits, slab, st);
+    XM_LAUNCH_CHECK();
+  }
+  return XM_OK;
+}
+
 static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
   // analytic fallback: minimal padded work (split-K supplies the parallelism)
   int fb = 0;
@@ -1980,6 +2035,15 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
     const int pick = g_force_stem >= 0 ? g_force_stem : tune_challengers(skey, st, run2, 2, sok, kHaloMargin);
     return run2(pick);
   }
+  if (wgrad_patch_ok(g, x, dzdy, st)) {
+    // the patch kernel against the best generic configuration (measured once per shape; it removes work -- gathers and
+    // address arithmetic -- so it does not have to clear the margin the equal-work challengers need: DESIGN.md 2.1f)
+    auto run3 = [&](int h) { return h ? launch_wgrad_patch(x, dzdy, dfo, g, part, max_splits, st) : run(ci); };
+    bool pok[2] = {true, true};
+    TuneKey pkey{9, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    const int pick = g_force_wgrad_patch >= 0 ? g_force_wgrad_patch : tune_challengers(pkey, st, run3, 2, pok, 0.01f);
+    return run3(pick);
+  }
   return run(ci);
 }
 
@@ -1998,6 +2062,12 @@ int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
 int xm_debug_force_conv_halo(int on) {
   int old = g_force_halo;
   g_force_halo = on < 0 ? -1 : std::min(on, 3);
+  return old;
+}
+
+int xm_debug_force_wgrad_patch(int on) {
+  int old = g_force_wgrad_patch;
+  g_force_wgrad_patch = on < 0 ? -1 : (on ? 1 : 0);
   return old;
 }
 
@@ -2132,6 +2202,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     const int v = key % 100;
     snprintf(buf, len, "%s<%s, %d>", kind == 3 ? "conv_halo_kernel" : "conv_halo_multi_kernel",
              v == 0 ? "2, 2, 2, 2" : "3, 1, 1, 4", v == 2 ? 1024 : 512);
+    return XM_OK;
+  }
+  if (kind == 9) {
+    snprintf(buf, len, "conv_wgrad_patch_kernel<30>");
     return XM_OK;
   }
   if (kind == 5 || kind == 6) {

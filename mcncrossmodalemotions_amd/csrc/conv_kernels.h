@@ -2291,4 +2291,186 @@ conv_wgrad_kernel(const WgradArgs a) {
 #undef XM_MFMA_E
 #undef XM_INTERLEAVE
 
+// ---- filter derivative of a 3 x 3 / stride 1 / pad 1 layer from an input PATCH (round 4) -----------------------------------
+// conv_wgrad_kernel gathers its im2col operand tap by tap: for a 3 x 3 layer every input element is fetched nine times
+// (dword loads, each with its padding test and address arithmetic) and parked with nine ds_write_b32.  Here a stage is ONE
+// output column of one sample (HH pixels = the reduction indices of the stage):
+//   * the dY tile [128 filters][HH pixels]: 8-byte loads of contiguous rows (per-thread offsets fixed for the whole kernel,
+//     the column rides in the scalar offset), LDS image [k/4][row][k%4] as in conv_wgrad_kernel (one ds_read_b128 = 4 k);
+//   * the input patch under the column: 3 input columns x HH rows of the <= 16 channels the block's 128 (tap, channel)
+//     columns touch, each element loaded ONCE (8-byte loads; columns outside the image are out-of-range loads = zeros) into
+//     [channel][column][row] with 6 zero rows between columns -- the rows above / below the image -- so that tap (u, v) of
+//     pixel k is at lane base + k: ds_read_b32 with immediate offsets, no masks, no VALU in the loop.
+// HH pixels = HH / 2 MFMA 32x32x2 steps per tile pair, no padded reduction steps: full 8-k chunks pair k = 8c + e (lanes
+// 0-31) with 8c + 4 + e (lanes 32-63) as everywhere else; the tail (HH % 8 = 6: k = 24 ... 29) pairs (24, 28), (25, 29),
+// (26, 27).  Double-buffered LDS, one barrier per stage (60 MFMAs per wave at HH = 30), split over the stage range.
+struct WgradPatchArgs {
+  const float *dY, *X;
+  float *out;                       // [splits][M][ldo]
+  unsigned xBytes, dyBytes;
+  int M, R, ldo, C;                 // filters, 9 * C columns, row pitch of out, input channels
+  int W, K;                         // image columns (= output columns), filters of the whole tensor (sample stride of dY)
+  int nStages, stagesPerSplit;      // stages = N * W
+  int nbm, nbn;
+  size_t splitStride;
+};
+
+template <int HH>
+__global__ void __launch_bounds__(256, 3)
+conv_wgrad_patch_kernel(const WgradPatchArgs a) {
+  static_assert(HH % 2 == 0 && HH % 8 == 6 && HH <= 30, "rows per column: pairs, a 6-pixel tail, LDS budget");
+  constexpr int BM = 128, BN = 128, NCK = HH / 8, G = (HH + 7) / 8 * 2;   // full 8-k chunks, float4 groups per stage
+  constexpr int PLA = BM * 4 + 16;                                          // plane pitch of the dY image (floats)
+  constexpr int CS = HH + 6, PC = 3 * CS + 4, NCHN = 16, PGUARD = 4;        // patch: column / channel pitch, channels, guard
+  constexpr int SA = G * PLA, SP = PGUARD + NCHN * PC + 4, STG = SA + SP;   // floats per stage buffer (the last 4: spare)
+  constexpr int HP = HH / 2;                                                // pixel pairs per column
+  constexpr int NLA = (BM * HP + 255) / 256, NLB = (NCHN * 3 * HP + 255) / 256;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float smem[2 * STG];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, a.nbm * a.nbn);
+  const int bm = tile % a.nbm, bn = tile / a.nbm;
+  const int s0 = blockIdx.y * a.stagesPerSplit, s1 = min(a.nStages, s0 + a.stagesPerSplit);
+  const int ci0 = (bn * BN) / 9;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
+
+  for (int i = t; i < 2 * STG / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging maps (fixed for the whole kernel)
+  unsigned voA[NLA], voB[NLB];
+  int ldA[NLA], ldB[NLB], colB[NLB];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int idx = t + 256 * j;
+    const int row = idx / HP, pr = idx - row * HP;
+    const bool ok = idx < BM * HP;
+    const int gm = min(bm * BM + row, a.M - 1);
+    voA[j] = ok ? (unsigned)((gm * a.W * HH + 2 * pr) * 4) : 0xFFFFFFFFu;
+    ldA[j] = ok ? (pr >> 1) * PLA + row * 4 + 2 * (pr & 1) : STG - 4;      // (the spare floats at the end of a buffer)
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int idx = t + 256 * j;
+    const int ch = idx / (3 * HP), rem = idx - ch * (3 * HP), col = rem / HP, pr = rem - col * HP;
+    const bool ok = idx < NCHN * 3 * HP && ci0 + ch < a.C;
+    voB[j] = ok ? (unsigned)((((ci0 + ch) * a.W + col - 1) * HH + 2 * pr) * 4) : 0xFFFFFFFFu;   // + the stage's column below
+    colB[j] = ok ? col - 1 : -(1 << 20);
+    ldB[j] = idx < NCHN * 3 * HP ? SA + PGUARD + ch * PC + col * CS + 2 * pr : STG - 2;
+  }
+  // fragment addresses
+  const float *sAr = smem + half * PLA + (wm * 64 + l31) * 4;
+  int bB[2], bT[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = min(bn * BN + (wn * 2 + j) * 32 + l31, a.R - 1);
+    const int ci = r / 9, tap = r - ci * 9, v = tap / 3, u = tap - v * 3;
+    bB[j] = SA + PGUARD + (ci - ci0) * PC + v * CS + (u - 1) + 4 * half;   // k = 8 c + e (+ 4 for lanes 32-63)
+    bT[j] = bB[j] - 3 * half;                                               // tail pair (26, 27): k = 26 + half
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x2 ra[NLA], rb[NLB];
+#define XM_WP_LOAD()   /* the stage (ln, lc), then on to the next column */                          \
+  {                                                                                                 \
+    const int n_ = ln, c_ = lc;                                                                     \
+    if (++lc == a.W) lc = 0, ++ln;                                                                  \
+    const unsigned sA_ = (unsigned)(((n_ * a.K) * a.W + c_) * HH * 4);                              \
+    const unsigned sB_ = (unsigned)(((n_ * a.C) * a.W + c_) * HH * 4);                              \
+    _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                 \
+      ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dyrsrc, (int)voA[j], (int)sA_, 0)); \
+    _Pragma("unroll") for (int j = 0; j < NLB; ++j) {                                               \
+      const bool okc_ = (unsigned)(c_ + colB[j]) < (unsigned)a.W;                                   \
+      rb[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)(okc_ ? voB[j] + sB_ : 0xFFFFFFFFu), 0, 0)); \
+    }                                                                                               \
+  }
+#define XM_WP_STORE(BUF)                                                                            \
+  _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                   \
+    *reinterpret_cast<f32x2 *>(smem + (BUF) * STG + ldA[j]) = ra[j];                                \
+  _Pragma("unroll") for (int j = 0; j < NLB; ++j)                                                   \
+    *reinterpret_cast<f32x2 *>(smem + (BUF) * STG + ldB[j]) = rb[j];
+
+  __syncthreads();   // the zero fill
+  if (s0 < s1) {
+    int ln = s0 / a.W, lc = s0 - ln * a.W;
+    XM_WP_LOAD()
+    XM_WP_STORE(0)
+    __syncthreads();
+    if (s0 + 1 < s1) XM_WP_LOAD()
+    int cur = 0;
+    for (int s = s0; s < s1; ++s) {
+      // registers hold stage s + 1 (requested a whole stage ago): park it in the buffer the previous barrier freed, request
+      // stage s + 2, multiply stage s -- the LDS stores and the loads sit next to the first MFMAs, nothing is exposed
+      if (s + 1 < s1) {
+        XM_WP_STORE(cur ^ 1)
+      }
+      if (s + 2 < s1) XM_WP_LOAD()
+      const float *A = sAr + cur * STG;
+      const float *P = smem + cur * STG;
+#pragma unroll
+      for (int c = 0; c <= NCK; ++c) {
+        f32x4 af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4 *>(A + 2 * c * PLA + i * 128);
+        if (c < NCK) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = P[bB[j] + 8 * c + e];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
+          // tail: k = 8 c ... 8 c + 5.  (8c, 8c + 4), (8c + 1, 8c + 5) as in a full chunk, then (8c + 2, 8c + 3): lanes 32-63
+          // take their dY value from the chunk's first group as well
+          f32x4 as[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) as[i] = *reinterpret_cast<const f32x4 *>(A - half * PLA + 2 * c * PLA + i * 128);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            float bf[2], av[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = e < 2 ? P[bB[j] + 8 * c + e] : P[bT[j] + 8 * c + 2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = e < 2 ? af[i][e] : (half ? as[i][3] : as[i][2]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bf[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef XM_WP_LOAD
+#undef XM_WP_STORE
+  float *out = a.out + (size_t)blockIdx.y * a.splitStride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = bn * BN + (wn * 2 + j) * 32 + l31;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = bm * BM + (wm * 2 + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        if (m < a.M) out[(size_t)m * a.ldo + r] = acc[i][j][rr];
+      }
+  }
+}
+
 }  // namespace xm

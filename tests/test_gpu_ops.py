@@ -116,6 +116,48 @@ def test_conv_fused_sigmoid_general_path(gpu):
 
 
 # (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
+WGRAD_PATCH_CASES = [  # W, C, N, K
+    (17, 20, 5, 70),      # the student's 30-row grid; channels / filters that fill neither a tile nor a 9-tap group
+    (17, 128, 8, 192),    # the narrow student's conv3: two filter-row tiles, nine column tiles, split over the columns
+    (9, 16, 8, 130),      # ragged filter tile (130 = 128 + 2), few columns per sample
+    (40, 3, 2, 8),        # wide, three channels (27 columns of the derivative)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PATCH_CASES)
+def test_conv_wgrad_patch_kernel(gpu, case):
+    """Filter derivative of 3 x 3 / stride 1 / pad 1 layers over 30-row grids through conv_wgrad_patch_kernel (one output
+    column per stage, the input patch under it staged once in LDS, the nine taps read from it) against the oracle, next to
+    the generic kernel on the same operands; the profiler hooks prove which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    W, C, N, K = case
+    rng = np.random.default_rng(W * 7 + C * 3 + N + K)
+    x, f, b = rnd(rng, 30, W, C, N), rnd(rng, 3, 3, C, K), rnd(rng, K)
+    dzdy = rnd(rng, 30, W, K, N)
+    dzdy[rng.random(dzdy.shape) < 0.3] = 0                     # a ReLU mask's zeros
+    _, df_ref, db_ref = O.vl_nnconv(x, f, b, dzdy, pad=1, acc64=True)
+    xd, fd, bd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), vl.from_numpy(dzdy)
+    old = L.xm_debug_force_wgrad_patch(1)
+    try:
+        (_, df, db), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, dd, pad=1, no_der_data=True))
+        assert ("conv_wgrad_patch_kernel<30>" in names) == (N * W >= 64), names
+        close(vl.to_numpy(df), df_ref, what="patch wgrad")
+        close(vl.to_numpy(db).ravel(), db_ref.ravel(), what="dzdb next to it")
+        L.xm_debug_force_wgrad_patch(0)
+        (_, df0, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, dd, pad=1, no_der_data=True))
+        assert not any("patch" in n for n in names), names
+        close(vl.to_numpy(df0), df_ref, what="generic wgrad")
+        # other geometries never take it: 28 rows, stride 2, pad 0
+        L.xm_debug_force_wgrad_patch(1)
+        x2 = vl.from_numpy(rnd(rng, 28, W, C, N))
+        y2 = vl.vl_nnconv(x2, fd, bd, pad=1)
+        _, names = _kernels_run(L, lambda: vl.vl_nnconv(x2, fd, bd, vl.from_numpy(rnd(rng, *y2.shape)), pad=1, no_der_data=True))
+        assert not any("patch" in n for n in names), names
+    finally:
+        L.xm_debug_force_wgrad_patch(old)
+
+
 STEM_CASES = [(512, 60, 2, 96, (1, 1, 1, 1)), (131, 45, 3, 96, (1, 1, 1, 1)), (64, 33, 2, 64, (3, 3, 3, 3)),
               (40, 41, 2, 33, (0, 0, 0, 0)), (29, 23, 1, 7, (2, 1, 0, 3)), (300, 18, 1, 96, (1, 0, 1, 0))]
 

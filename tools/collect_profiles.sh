@@ -42,6 +42,11 @@ NS="--no-cpu-baseline --no-roofline --north-star 0"
   for w in "default (>= 1024 tiles), shipped table|XM_X=1" "never|XM_TUNE_FILE= XM_NO_W8=1" "default, tuned in the process|XM_TUNE_FILE= XM_X=1" "always|XM_TUNE_FILE= XM_W8_MIN_TILES=0"; do
     for wl in "" "--per-gpu-batch 256 --steps 10 --warmup 3" "--workload student" "--workload joint"; do
       echo -n "eight-wave configuration ${w%%|*}, bench.py $wl: "; env ${w##*|} $B $NS $wl 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done; done
+  # round 4: conv_wgrad_patch_kernel inside the step: one stream (where it is taken) and two streams (where it is not, and forced)
+  for e in "XM_X=1" "XM_NO_WGRAD_PATCH=1"; do for wl in "--serial" "--workload student --wgrad-stream 0" "--serial --per-gpu-batch 256 --steps 10 --warmup 3"; do
+    echo -n "one stream, $e, bench.py $wl: "; env $e $B $NS $wl 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done; done
+  for e in "XM_X=1" "XM_WGRAD_PATCH_ANY_STREAM=1" "XM_WGRAD_PATCH_ANY_STREAM=1 XM_WGRAD_PATCH_SLOTS=384"; do for wl in "" "--workload student" "--per-gpu-batch 256 --steps 10 --warmup 3"; do
+    echo -n "two streams, $e, bench.py $wl: "; env $e $B $NS $wl 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done; done
   for e in "XM_X=1" "XM_NO_HALO=1" "XM_NO_FUSED_STATS=1" "XM_NO_STEM=1" "XM_NO_STEM_WGRAD=1"; do echo -n "student batch 64, $e: "; env $e $B $NS --workload student 2>/dev/null | tail -1 | cut -c50-100; done
   for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1"; do echo -n "config 3 (SE-ResNet50 fwd, 128), $e: "; env $e $B $NS --workload teacher 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*, "unit": "[a-z/]*"'; done
   for e in "XM_X=1" "XM_NO_FUSED_SE=1" "XM_NO_HYBRID=1" "XM_NO_FUSED_STEM_BWD=1" "XM_TUNE_FILE= XM_HALO_MARGIN=0.04" "XM_TUNE_FILE= XM_HALO_MARGIN=0.015"; do echo -n "north_star batch 256 (SE-ResNet50), $e: "; env $e $B $NS --teacher senet50 --per-gpu-batch 256 --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c60-112; done
@@ -52,6 +57,8 @@ for n in 32 64 256; do python tools/halo_bench.py $n 2>&1 | grep -v amdgpu; done
 { for n in 32 64; do python tools/stem_bench.py $n 2>&1 | grep -v amdgpu; done; hipcc --offload-arch=gfx950 -O3 tools/store_mfma_probe.hip -o /tmp/smp 2>/dev/null && /tmp/smp; } > $O/stem_bench.txt
 # round 4: configuration 0 (four waves of 222 VGPRs) against configuration 7 (eight waves of 128) on an idle device
 { for n in 32 64 256; do for c in 0 7; do echo "== $n samples, forced configuration $c"; python tools/conv_bench.py --cfg $c --n $n --reps 30 --dirs fwd,dgrad s_conv2 s_conv3 s_conv4 s_conv5 t_res3_3x3 t_res4_3x3 x_fill3x3 x_fill1x1 2>&1 | grep -v amdgpu; done; done; } > $O/w8_bench.txt
+# round 4: filter derivative of the student's 3 x 3 layers, generic kernel against conv_wgrad_patch_kernel, idle device
+{ for n in 32 64 256; do for e in "XM_NO_WGRAD_PATCH=1" "XM_X=1"; do echo "== $n spectrograms, $e"; env XM_TUNE_FILE= $e python tools/conv_bench.py --n $n --reps 30 --dirs wgrad s_conv3 s_conv4 s_conv5 2>&1 | grep -v amdgpu; done; done; } > $O/wgrad_patch_bench.txt
 python tools/stats_bench.py 32 2>&1 | grep -v amdgpu > $O/stats_bench.txt
 python tools/bnbwd_bench.py 32 2>&1 | grep -v amdgpu > $O/bnbwd_bench.txt
 { for n in 32 64 256; do python tools/stem_bwd_bench.py $n 2>&1 | grep -v amdgpu; done; python tools/mall_chunk_bench.py 32 2>&1 | grep -v amdgpu; } > $O/stem_bwd_bench.txt
