@@ -375,7 +375,17 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
 static int g_force_stem = -1; // test hook (xm_debug_force_conv_stem): 1 = conv_stem_kernel wherever it can run, 0 = never
 static int g_force_wgrad_patch = -1; // test hook (xm_debug_force_wgrad_patch)
-static hipStream_t g_last_fwd_stream = nullptr;   // stream of the most recent forward convolution (wgrad_patch_ok)
+// Streams of the last 64 convolution calls (any direction): a caller all of whose calls arrive on ONE stream has nothing
+// running next to a kernel (the reference's own call sequence); wgrad_patch_ok asks.
+static hipStream_t g_conv_streams[64];
+static unsigned g_conv_calls = 0;
+static inline void note_conv_stream(hipStream_t st) { g_conv_streams[g_conv_calls++ & 63] = st; }
+static inline bool single_stream_caller(hipStream_t st) {
+  const unsigned n = std::min(g_conv_calls, 64u);
+  for (unsigned i = 0; i < n; ++i)
+    if (g_conv_streams[i] != st) return false;
+  return true;
+}
 static int g_force_halo = -1; // test hook (xm_debug_force_conv_halo): 1 = halo-patch kernel wherever it can run, 0 = never
 static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
@@ -1223,7 +1233,7 @@ static int launch_stem(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
-  g_last_fwd_stream = st;
+  note_conv_stream(st);
   // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
   // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
   const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
@@ -1459,6 +1469,7 @@ static PrepKey prep_key(const float *f, const Geo &g, bool fold) {
 // prepare_only: run just the filter transpositions into the persistent cache (xm_nnconv_prepare_backward)
 static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st,
                       const float *accum = nullptr, bool prepare_only = false) {
+  note_conv_stream(st);
   struct Cls {
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
@@ -1950,11 +1961,11 @@ static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, cons
 // --serial): alone the kernel is 11 ... 22 % faster than the generic one (profiles/r04/wgrad_patch_bench.txt), a step on one
 // stream 1.7 %; launched on a side stream next to the dgrad of the same layer it fills the chip with three 48 KB blocks per CU
 // for its whole life and the pair takes LONGER than with the generic kernel (student step at 64: - 1.5 %).
-// "Side stream" = not the stream of the most recent forward convolution; XM_WGRAD_PATCH_ANY_STREAM lifts the restriction.
+// One-stream caller = the last 64 convolution calls all arrived on this stream; XM_WGRAD_PATCH_ANY_STREAM lifts the restriction.
 static bool wgrad_patch_ok(const Geo &g, const float *x, const float *dzdy, hipStream_t st) {
   static const bool any_stream = getenv("XM_WGRAD_PATCH_ANY_STREAM") != nullptr;
   if (!path_on(kPathWgradPatch) || g_force_cfg >= 0 || g_force_splits > 0) return false;
-  if (g_force_wgrad_patch < 0 && !any_stream && st != g_last_fwd_stream) return false;
+  if (g_force_wgrad_patch < 0 && !any_stream && !single_stream_caller(st)) return false;
   if (g.G != 1 || g.FH != 3 || g.FW != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.pt != 1 || g.pb != 1 || g.pl != 1 || g.pr != 1) return false;
   if (g.H != 30 || g.Ho != g.H || g.Wo != g.W) return false;          // instantiated row counts (HH)
@@ -1998,6 +2009,7 @@ static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, con
 }
 
 static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
+  note_conv_stream(st);
   // analytic fallback: minimal padded work (split-K supplies the parallelism)
   int fb = 0;
   {
