@@ -8,12 +8,14 @@ A="--no-cpu-baseline --no-roofline --steps 20 --warmup 3"
 python bench.py $A > /dev/null
 python bench.py --serial $A > /dev/null
 python bench.py --workload student $A > /dev/null
+python bench.py --workload student --wgrad-stream 0 $A > /dev/null      # one-stream callers: conv_wgrad_patch_kernel's entries
 python bench.py --workload teacher $A > /dev/null
 python bench.py --workload teacher --serial $A > /dev/null
 python bench.py --workload joint $A > /dev/null
 python bench.py --teacher senet50 $A > /dev/null
 python bench.py --teacher senet50 --serial $A > /dev/null
 python bench.py --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
+python bench.py --serial --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
 python bench.py --teacher senet50 --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
 python bench.py --frames 13 --teacher senet50 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
 python - <<PY
