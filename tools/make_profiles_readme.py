@@ -50,6 +50,9 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r03/` are the p
 | `{R}/schedule_experiments.txt` | A/B lines behind DESIGN.md 2.3b: teacher pass over 64 / 128 / 256 faces, `--teacher-gate`, wgrad deferred behind dgrad, stream priorities, and every round-3 kernel change switched off by its environment variable |
 | `{R}/stem_bwd_bench.txt` | round 4: `tools/stem_bwd_bench.py` (conv1's backward chain at 32 / 64 / 256 spectrograms: bnorm + relu + pool backward and the filter derivative as two passes against `xm_nnconv_backward_filter_bnrelupool`, DESIGN.md 2.2e) and `tools/mall_chunk_bench.py` (the same pair in sample chunks that would fit the Infinity Cache: no gain) |
 | `{R}/bench_distill_gpus2_gloo0.json` | round 4: `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it: the command starts its two ranks itself (both on this box's one GPU, exchange over gloo: a functional run of the N > 1 path, `n_gpus` 2 / `rccl_ranks` 2 in the line; the throughput means nothing) |
+| `{R}/w8_bench.txt` | round 4: `tools/conv_bench.py --cfg 0 / --cfg 7`: the 128 x 128 tile by four waves of 222 VGPRs against eight waves of 128 (DESIGN.md 2.1f), forward and dgrad, 32 / 64 / 256 samples, idle device |
+| `{R}/wgrad_patch_bench.txt` | round 4: filter derivative of the student's 3 x 3 layers, generic kernel (`XM_NO_WGRAD_PATCH=1`) against `conv_wgrad_patch_kernel<30>` (DESIGN.md 2.1g), 32 / 64 / 256 spectrograms, idle device |
+| `{R}/timeline_student64_generic_wgrad.csv`, `timeline_student64_patch_wgrad_on_side_stream.csv` | round 4: `rocprofv3 --kernel-trace` of `bench.py --workload student` (last 40 ms: start ns, end ns, queue, stream, kernel) with the generic filter-derivative kernel and with the patch kernel forced onto the side stream: what runs next to what (DESIGN.md 2.1g; taken at `0da31f7` + the kernel, before the one-stream rule) |
 | `{R}/halo_bench.txt`, `stats_bench.txt`, `bnbwd_bench.txt` | `tools/halo_bench.py` (halo-patch variants vs the best implicit-GEMM configuration, 32 / 64 / 256 samples), `tools/stats_bench.py` (conv with / without fused batch moments), `tools/bnbwd_bench.py` (bnorm backward chains) |
 | `{R}/kernel_stats_senet50_b256.txt` | rocprofv3 per-kernel summary of north_star's configuration (SE-ResNet50 teacher, 256 pairs, serial mode) |
 | `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` (+ the commit) from the JSON |
@@ -92,13 +95,16 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r03/` are the p
 
 Round 3 -> round 4 on the default line: 3924 -> {d['value']} pairs/s; student batch 64: 5818 -> {st['value']} samples/s; north_star batch 256
 (SE-ResNet50): 4197 -> {se256['value']} pairs/s; config-5 shard: 1750 -> {jo['value']} pairs/s; one stream: 3574 -> {ds['value']}.  Where it came from
-(DESIGN.md 2.2e, 2.2f): conv1's filter derivative computed straight through bnorm + relu + pool (`conv_stem_wgrad_bnp_kernel`: the 462 MB
-derivative of the student's first layer is neither written nor read: chain 0.49 -> 0.38 ms at 32 spectrograms, 3.6 -> 2.8 ms at 256,
+(DESIGN.md 2.2e, 2.2f, 2.1f, 2.1g): conv1's filter derivative computed straight through bnorm + relu + pool (`conv_stem_wgrad_bnp_kernel`: the
+462 MB derivative of the student's first layer is neither written nor read: chain 0.49 -> 0.38 ms at 32 spectrograms, 3.6 -> 2.8 ms at 256,
 `stem_bwd_bench.txt`); the SE tail of a TRAINED teacher fused in both directions (backward 13 -> 8 passes over the block's tensors, forward
-6 -> 4: every line of config 5).  `schedule_experiments.txt` has every switch of this and the previous round as an A/B line, the halo
-selection margin at 4 / 1.5 / 0 % (lower margins lose 0.8 ... 1.5 %), and the frozen teacher in slices (`--teacher-chunk`: slower).
-The step is work-conserving (serial sum -> {d['ms_per_step']} ms overlapped), its main stream never waits (`phase_marks.txt`), and only
-work removed from the main stream shows up one to one.
+6 -> 4: every line of config 5); the 128 x 128 tile by eight waves of 128 VGPRs for launches of >= 1024 tiles (`w8_bench.txt`: +3 ... 4 % alone);
+the filter derivative of the student's 3 x 3 layers from an input patch for one-stream callers (`wgrad_patch_bench.txt`: 104 -> 126 TFLOP/s
+at 256 spectrograms; the one-stream line above).  `schedule_experiments.txt` has every switch of this and the previous round as an A/B
+line: the eight-wave configuration never / from 1024 tiles / always, the patch kernel on one and on two streams, the halo selection margin
+at 4 / 1.5 / 0 %, the frozen teacher in slices.  What the A/Bs and the two timelines say (DESIGN.md 2.1f, 2.1g): MFMA-bound kernels side by side
+take the sum of their times, so inside the two-stream step a kernel that is faster alone is worth nothing unless it removes work from the main
+stream; the step is work-conserving (serial sum -> {d['ms_per_step']} ms overlapped) and its main stream never waits (`phase_marks.txt`).
 
 ## How the numbers were taken
 ```
