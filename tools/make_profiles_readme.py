@@ -26,7 +26,7 @@ rows = "\n".join("| `%s` | %.3f | %.1f | %d |" % (k["kernel"], k["ms_per_step"],
                  for k in r["per_kernel"])
 txt = f"""# profiles/ — measured evidence, round {int(R[1:])} (MI355X, 1 GPU, ROCm 7.2)
 
-Everything under `{R}/` comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
+Everything under `{R}/` (except the three files marked below) comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
 `bash tools/collect_profiles.sh {R} <commit>` (the script lists every command); this file is generated from
 those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r03/` are the previous rounds' evidence, unchanged.
 
@@ -51,6 +51,7 @@ those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r03/` are the p
 | `{R}/stem_bwd_bench.txt` | round 4: `tools/stem_bwd_bench.py` (conv1's backward chain at 32 / 64 / 256 spectrograms: bnorm + relu + pool backward and the filter derivative as two passes against `xm_nnconv_backward_filter_bnrelupool`, DESIGN.md 2.2e) and `tools/mall_chunk_bench.py` (the same pair in sample chunks that would fit the Infinity Cache: no gain) |
 | `{R}/bench_distill_gpus2_gloo0.json` | round 4: `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it: the command starts its two ranks itself (both on this box's one GPU, exchange over gloo: a functional run of the N > 1 path, `n_gpus` 2 / `rccl_ranks` 2 in the line; the throughput means nothing) |
 | `{R}/w8_bench.txt` | round 4: `tools/conv_bench.py --cfg 0 / --cfg 7`: the 128 x 128 tile by four waves of 222 VGPRs against eight waves of 128 (DESIGN.md 2.1f), forward and dgrad, 32 / 64 / 256 samples, idle device |
+| `{R}/w8_threshold_tables.txt` | round 4, ANOTHER gpurun call (another box, before the main collection): the bench lines with a tuning table generated for each `XM_W8_MIN_TILES` setting (from 1024 tiles / always / never), DESIGN.md 2.1f |
 | `{R}/wgrad_patch_bench.txt` | round 4: filter derivative of the student's 3 x 3 layers, generic kernel (`XM_NO_WGRAD_PATCH=1`) against `conv_wgrad_patch_kernel<30>` (DESIGN.md 2.1g), 32 / 64 / 256 spectrograms, idle device |
 | `{R}/timeline_student64_generic_wgrad.csv`, `timeline_student64_patch_wgrad_on_side_stream.csv` | round 4: `rocprofv3 --kernel-trace` of `bench.py --workload student` (last 40 ms: start ns, end ns, queue, stream, kernel) with the generic filter-derivative kernel and with the patch kernel forced onto the side stream: what runs next to what (DESIGN.md 2.1g; taken at `0da31f7` + the kernel, before the one-stream rule) |
 | `{R}/halo_bench.txt`, `stats_bench.txt`, `bnbwd_bench.txt` | `tools/halo_bench.py` (halo-patch variants vs the best implicit-GEMM configuration, 32 / 64 / 256 samples), `tools/stats_bench.py` (conv with / without fused batch moments), `tools/bnbwd_bench.py` (bnorm backward chains) |
