@@ -565,8 +565,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 
 #define XM_FETCH_TAPS(KT)                                                      \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i) {                            \
-    int g_ = gB0 + i * (NT / BN);                                             \
-    if (kNG * BN % NT != 0) g_ = min(g_, kNG - 1);                            \
+    int g_ = gB0 + i * (NT / BN);                                              \
+    if (kNG * BN % NT != 0) g_ = min(g_, kNG - 1);                             \
     int r0_ = (KT) * kBK + g_ * 4;                                             \
     if (UNIFORM) r0_ = __builtin_amdgcn_readfirstlane(r0_);                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
@@ -597,10 +597,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs &a) {
 
 #define XM_STORE_TILE(BUF, RA, RB)                                             \
   _Pragma("unroll") for (int i = 0; i < NUA; ++i)                              \
-    if (kNG * BM % NT == 0 || t + NT * i < kNG * BM)                         \
+    if (kNG * BM % NT == 0 || t + NT * i < kNG * BM)                           \
       *reinterpret_cast<f32x4 *>(sAw[i] + (BUF) * kNG * PLA) = RA[i];          \
   _Pragma("unroll") for (int i = 0; i < NUB; ++i)                              \
-    if (kNG * BN % NT == 0 || gB0 + i * (NT / BN) < kNG)                     \
+    if (kNG * BN % NT == 0 || gB0 + i * (NT / BN) < kNG)                       \
       *reinterpret_cast<f32x4 *>(sBw[i] + (BUF) * kNG * PLB) = RB[i];
 
   // One pipeline stage on LDS buffer CUR.  The MFMA operands are double-buffered in REGISTERS: the
