@@ -115,7 +115,6 @@ def test_conv_fused_sigmoid_general_path(gpu):
     close(vl.to_numpy(y), y_ref, 1e-5, what="conv + sigmoid")
 
 
-# (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
 WGRAD_PATCH_CASES = [  # W, C, N, K
     (17, 20, 5, 70),      # the student's 30-row grid; channels / filters that fill neither a tile nor a 9-tap group
     (17, 128, 8, 192),    # the narrow student's conv3: two filter-row tiles, nine column tiles, split over the columns
@@ -158,6 +157,7 @@ def test_conv_wgrad_patch_kernel(gpu, case):
         L.xm_debug_force_wgrad_patch(old)
 
 
+# (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
 STEM_CASES = [(512, 60, 2, 96, (1, 1, 1, 1)), (131, 45, 3, 96, (1, 1, 1, 1)), (64, 33, 2, 64, (3, 3, 3, 3)),
               (40, 41, 2, 33, (0, 0, 0, 0)), (29, 23, 1, 7, (2, 1, 0, 3)), (300, 18, 1, 96, (1, 0, 1, 0))]
 
@@ -193,6 +193,30 @@ MERGED_DGRAD_CASES = [
 @pytest.mark.parametrize("case", MERGED_DGRAD_CASES)
 def test_conv_strided_dgrad_large(gpu, case):
     test_conv_forward_backward(gpu, case)
+
+
+def test_conv_strided_dgrad_merged_all_configs(gpu):
+    """the merged strided dgrad (all stride-parity classes in one launch, conv_gemm_multi_kernel) with every register-staged
+    tile configuration forced, incl. the eight-wave one, against the oracle"""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, FH, FW, FC, K, stride, pad, _ = MERGED_DGRAD_CASES[1]
+    rng = np.random.default_rng(5)
+    x, f = rnd(rng, H, W, C, N), rnd(rng, FH, FW, FC, K)
+    y_ref = O.vl_nnconv(x, f, None, stride=stride, pad=pad, acc64=True)
+    dzdy = rnd(rng, *y_ref.shape)
+    dx_ref, _, _ = O.vl_nnconv(x, f, None, dzdy, stride=stride, pad=pad, acc64=True, no_der_filters=True)
+    xd, fd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(dzdy)
+    old_h = L.xm_debug_force_conv_halo(0)
+    try:
+        for cfg in range(L.xm_debug_num_conv_cfgs() - 4):
+            L.xm_debug_force_conv_cfg(cfg)
+            (dx, _, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, None, dd, stride=stride, pad=pad, no_der_filters=True))
+            assert any(n.startswith("conv_gemm_multi_kernel") for n in names), (cfg, names)
+            close(vl.to_numpy(dx), dx_ref, what="merged dgrad, cfg %d" % cfg)
+    finally:
+        L.xm_debug_force_conv_cfg(-1)
+        L.xm_debug_force_conv_halo(old_h)
 
 
 def test_conv_random_geometries(gpu):
