@@ -105,7 +105,7 @@ at 256 spectrograms; the one-stream line above).  `schedule_experiments.txt` has
 line: the eight-wave configuration never / from 1024 tiles / always, the patch kernel on one and on two streams, the halo selection margin
 at 4 / 1.5 / 0 %, the frozen teacher in slices.  What the A/Bs and the two timelines say (DESIGN.md 2.1f, 2.1g): MFMA-bound kernels side by side
 take the sum of their times, so inside the two-stream step a kernel that is faster alone is worth nothing unless it removes work from the main
-stream; the step is work-conserving (serial sum -> {d['ms_per_step']} ms overlapped) and its main stream never waits (`phase_marks.txt`).
+stream; the step is work-conserving (one stream {ds['ms_per_step']} ms -> {d['ms_per_step']} ms overlapped) and its main stream never waits (`phase_marks.txt`).
 
 ## How the numbers were taken
 ```
