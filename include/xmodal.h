@@ -61,7 +61,9 @@ int xm_device_upload(void *dst_device, const void *src_host, size_t bytes);
 int xm_device_download(void *dst_host, const void *src_device, size_t bytes);
 int xm_device_synchronize(void);
 /* Tile-configuration table of vl_nnconv ("find mode": the first time a (direction, geometry) is seen every tile
- * configuration is timed on the caller's stream and the winner kept).  The table persists in a text file next to the
+ * configuration is timed on the caller's stream and the winner kept; the device is drained first -- hipDeviceSynchronize --
+ * so that the candidates run alone: do not meet a new shape while ANY stream of the process is being captured into a graph;
+ * a stream that is itself being captured gets the analytic choice instead).  The table persists in a text file next to the
  * library (tune_gfx950.txt; $XM_TUNE_FILE overrides, XM_TUNE_FILE="" disables): loaded before the first lookup,
  * written by xm_tune_save.  With the shipped table the tile choice -- hence the summation order and the bits of every
  * result -- is the same in every process, and known shapes cost no timed launches on first use
