@@ -531,6 +531,9 @@ def main():
         # not the kernel's own speed
         was_serial = mode["serial"]
         set_serial(True)
+        # the kernels of the timed region: a one-stream caller would also be given conv_wgrad_patch_kernel,
+        # which the multi-stream step above did not run
+        old_patch = None if was_serial else L.xm_debug_force_wgrad_patch(0)
         step(args.warmup + args.steps)   # shapes of the serial path (full-batch teacher) get tuned
         torch.cuda.synchronize()
         rsteps = min(args.steps, 60)
@@ -543,6 +546,8 @@ def main():
         torch.cuda.synchronize()
         L.xm_prof_enable(0)
         set_serial(was_serial)
+        if old_patch is not None:
+            L.xm_debug_force_wgrad_patch(old_patch)
         cap = 64
         keys = (C.c_int * cap)()
         ms = (C.c_double * cap)()
@@ -573,7 +578,7 @@ def main():
                         # PMC `traffic` (same unit) is to be compared with
                         "algorithmic_bytes": int(d["bytes"] / max(1, d["launches"])),
                         "traffic_source": tsrc, "traffic_profile_commit": tcommit,
-                        "mode": "serial pass (one stream): launch durations of isolated kernels",
+                        "mode": "serial pass (one stream): launch durations of isolated kernels, the kernel choices of the timed region",
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "flop_per_launch": d["flops"] / d["launches"],
                         "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
