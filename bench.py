@@ -58,8 +58,8 @@ def parse():
     ap.add_argument("--width", type=int, default=300, help="spectrogram width (3 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = scaled to the host: ~cores/4, "
-                    "at least 16)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = scaled to the host: ~cores/16, "
+                    "at least 8)")
     ap.add_argument("--parserv", default="auto", choices=["auto", "torch", "rccl-capi"],
                     help="gradient exchange: the library's own communicator behind the C ABI (xm_parserv_push / sync -- "
                          "what a MATLAB host binds; the default whenever an exchange happens) or torch.distributed")
@@ -74,6 +74,10 @@ def parse():
                          "their logits per pair (getBatchEmoVoxCeleb.m:145-158,179-185; SURVEY 8f row 1)")
     ap.add_argument("--overlap-allreduce", type=int, default=1,
                     help="1: fc6-8 gradient bucket all-reduced while the rest of the backward pass runs (N > 1)")
+    ap.add_argument("--exec-hint", default="auto", choices=["auto", "0", "1"],
+                    help="xm_set_exec_hint: 1 = XM_EXEC_SINGLE_STREAM (the library may pick kernels that assume nothing "
+                         "else is resident), 0 = none; auto = 1 with --serial, 0 otherwise.  `--serial --exec-hint 0` "
+                         "runs the kernels of the overlapped timed region one after the other (profiles/)")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream, no overlap anywhere (what the roofline leg and the rocprof profile use: "
                          "kernel durations are then those of isolated kernels)")
@@ -189,14 +193,32 @@ def main():
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("XM_DEBUG_DIST") in ("1", "2", "3")   # exercise the RCCL path with a single rank
     # "3": the library's own communicator only, no torch process group next to it
+    if args.parserv == "auto":
+        args.parserv = "torch" if shared_gpu else "rccl-capi"      # gloo debug runs have no RCCL communicator
+    # ONE RCCL communicator per rank: with the library's own communicator doing the exchange, the torch
+    # process group is only the control plane -- rendezvous store, barrier, agreeing on K -- all host-side, so it
+    # runs on gloo and never creates a second RCCL communicator next to the library's.  --parserv torch is the
+    # other arrangement: torch's nccl group IS the exchange path and the library creates none.
+    ctl_backend = "gloo" if (shared_gpu or args.parserv == "rccl-capi") else "nccl"
     if world > 1 or (force_dist and os.environ.get("XM_DEBUG_DIST") != "3"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if shared_gpu:
+        if ctl_backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     L = _lib.load()
+    # HOW this host calls the library, stated once and before the first operator call (include/xmodal.h): the kernel a
+    # shape gets depends on (shape, table, this hint) only -- the roofline leg below runs on one stream but keeps the
+    # hint of the timed region, so both run the same kernels
+    exec_hint = int(args.exec_hint) if args.exec_hint != "auto" else (1 if args.serial else 0)
+    vl.set_exec_hint(vl.EXEC_SINGLE_STREAM if exec_hint else 0)
+
+    def ctl_max(x, dtype):
+        """MAX over the workers of one host number, through the control group (host tensors on gloo)"""
+        t = torch.tensor([x], dtype=dtype, device=dev if ctl_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
 
     wl = args.workload
     nb = args.per_gpu_batch or {"distill": 32, "student": 64, "teacher": 128, "joint": 64}[wl]
@@ -206,8 +228,6 @@ def main():
     # ParameterServer FIRST -- before any network, buffer or side stream exists.  A communicator created after the
     # operator streams were in use cost 12 % of the step on this stack (3365 vs 3842 pairs/s at one rank, the whole
     # backward phase 0.8 ms longer even when no collective was ever issued; moving xm_comm_init here removed it).
-    if args.parserv == "auto":
-        args.parserv = "torch" if shared_gpu else "rccl-capi"      # gloo debug runs have no RCCL communicator
     force_ps = bool(force_dist and os.environ.get("XM_DEBUG_DIST") in ("1", "3"))
     if os.environ.get("XM_PS_LATE"):         # experiment: communicator created AFTER the networks (the call-order trap)
         parserv = train.ParameterServer(args.parserv)
@@ -215,6 +235,11 @@ def main():
     else:
         # every worker ends up on the same backend: the library's communicator, or torch.distributed if any failed
         parserv = train.ParameterServer.start_agreed(args.parserv, force=force_ps)
+        if parserv.backend == "torch" and args.parserv != "torch" and ctl_backend == "gloo" and not shared_gpu \
+                and dist.is_initialized():
+            # agreed fallback: the library's communicator is gone (destroyed on every worker), so torch's nccl group
+            # is again the only RCCL communicator of the rank; the gloo group stays the control plane
+            parserv.group = dist.new_group(backend="nccl", device_id=dev)
         args.parserv = parserv.backend
     # ---- networks ------------------------------------------------------------------------
     teacher = student = None
@@ -462,9 +487,7 @@ def main():
     settle = 3
     more = max(0, int(np.ceil((1.5 - (time.perf_counter() - tw)) / max(est, 1e-6))))
     if world > 1:   # same count on every rank: each step contains collectives
-        t = torch.tensor([more], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        more = int(t.item())
+        more = int(ctl_max(more, torch.int64))
     for j in range(more):
         throttled_step(Wm + settle + j)
     settle += more
@@ -474,9 +497,7 @@ def main():
         # time EXACTLY K steps with K >= min_seconds / (step time estimated above)
         K = max(20, int(np.ceil(args.min_seconds / max(est, 1e-6))))
         if world > 1:   # every rank must time the same K
-            t = torch.tensor([K], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            K = int(t.item())
+            K = int(ctl_max(K, torch.int64))
     args.steps, args.warmup = K, Wm
     Wm = Wm + settle   # step counter offset only
     # the timed region: exactly K steps between barrier + synchronize on both sides.  Window marks are HIP events
@@ -498,9 +519,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(ctl_max(dt, torch.float64))
     ms_per_step = dt / args.steps * 1e3
     if marks_log:
         student.markHook = None
@@ -531,9 +550,7 @@ def main():
         # not the kernel's own speed
         was_serial = mode["serial"]
         set_serial(True)
-        # the kernels of the timed region: a one-stream caller would also be given conv_wgrad_patch_kernel,
-        # which the multi-stream step above did not run
-        old_patch = None if was_serial else L.xm_debug_force_wgrad_patch(0)
+        # (the execution hint is unchanged: the kernels are those of the timed region)
         step(args.warmup + args.steps)   # shapes of the serial path (full-batch teacher) get tuned
         torch.cuda.synchronize()
         rsteps = min(args.steps, 60)
@@ -546,8 +563,6 @@ def main():
         torch.cuda.synchronize()
         L.xm_prof_enable(0)
         set_serial(was_serial)
-        if old_patch is not None:
-            L.xm_debug_force_wgrad_patch(old_patch)
         cap = 64
         keys = (C.c_int * cap)()
         ms = (C.c_double * cap)()
@@ -610,10 +625,10 @@ def main():
     else:
         gflop_unit = GFLOP["senet50_fwd_bwd"] + GFLOP["student_fwd_bwd_300"]
 
-    # proof of N ranks: the communicator's own rank count (ncclCommCount through the library, or the process group)
-    rccl_ranks = None
-    if dist.is_initialized():
-        rccl_ranks = parserv.comm_count()
+    # proof of N RCCL ranks: ncclCommCount of the communicator the exchange runs on (the library's through
+    # xm_comm_count, or torch's nccl group); null when the exchange does not run over RCCL (gloo debug runs, N = 1
+    # without XM_DEBUG_DIST).  `world` is the launcher's process count -- a different fact.
+    rccl_ranks = parserv.rccl_count()
     if rank == 0:
         out = {
             "metric": "distillation-step samples/sec (face+audio pair)" if wl in ("distill", "joint")
@@ -639,7 +654,8 @@ def main():
                                    "teacher": "%d sample-slice lanes" % args.teacher_lanes}[wl]},
             "model_tflops_per_gpu": round(value / world * gflop_unit / 1e3, 2),
             "model_frac_of_fp32_mfma_peak": round(value / world * gflop_unit / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "settle_steps": settle, "windows": windows, "rccl_ranks": rccl_ranks,
+            "settle_steps": settle, "windows": windows, "rccl_ranks": rccl_ranks, "world": world,
+            "control_group": ctl_backend if dist.is_initialized() else None, "exec_hint": exec_hint,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if north is not None:
@@ -733,18 +749,32 @@ def _cpu_pass(wl, pairs, W):
     return t_total, gflop
 
 
-def cpu_baseline(wl, pairs, W, passes=3):
+def cpu_baseline(wl, pairs, W, passes=3, budget_s=10.0):
     """MatConvNet-CPU-equivalent restatement (oracle fp32 path: im2row + vectorised SGEMM, images in parallel,
-    OpenMP, one thread pinned to each physical core by oracle.pin_threads) on a bounded sample of the same workload: `passes` timed passes, the MEDIAN is the value,
-    min / max are in the line (a shared host moved single passes by 30 % between boxes).  Checker code used as a timed
-    baseline only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv would be faster still
-    (this SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an upper bound."""
+    OpenMP, one thread pinned to each physical core by oracle.pin_threads -- no more threads than the cgroup's CPU
+    quota pays for) on a bounded sample of the same workload: up to `passes` timed passes inside ~`budget_s` seconds
+    of CPU work (always at least one), the MEDIAN is the value, min / max, the quota and the host's load average are
+    in the line (a shared host moved single passes by 2.4 x between boxes in round 4: other tenants' load).  Checker
+    code used as a timed baseline only; a "port", NOT MatConvNet itself: a tuned BLAS behind the real vl_nnconv
+    would be faster still (this SGEMM reaches a fraction of the cores' peak), so read the GPU / CPU ratio as an
+    upper bound."""
     from oracle import oracle as O
+    quota = O.cpu_quota()
+    try:
+        load1 = os.getloadavg()[0]
+    except OSError:
+        load1 = None
     cores, restore = O.pin_threads()     # one thread per physical core this process may use, pinned to it
     if pairs <= 0:
-        pairs = max(16, cores // 8)
+        pairs = max(8, cores // 16)      # ~3 s per pass on an idle 128-core host
+    runs = []
     try:
-        runs = [_cpu_pass(wl, pairs, W) for _ in range(max(1, passes))]
+        t_all = time.perf_counter()
+        for _ in range(max(1, passes)):
+            runs.append(_cpu_pass(wl, pairs, W))
+            spent = time.perf_counter() - t_all
+            if spent + spent / len(runs) > budget_s:      # the next pass would not fit
+                break
     finally:
         restore()
     ts = sorted(t for t, _ in runs)
@@ -752,9 +782,10 @@ def cpu_baseline(wl, pairs, W, passes=3):
     return {"value": round(pairs / med, 4), "unit": "pairs/s" if wl in ("distill", "joint") else "samples/s",
             "cores": cores, "kind": "port", "cpu": host_info(), "gflops": round(gflop / med, 1),
             "passes": len(ts), "min": round(pairs / ts[-1], 4), "max": round(pairs / ts[0], 4),
-            "sample": "median of %d passes over %d unit(s) of the same workload (%.1f s in all), oracle fp32 path: "
-                      "im2row + vectorised SGEMM, OpenMP x %d pinned to physical cores; a restatement, not MatConvNet"
-                      % (len(ts), pairs, sum(ts), cores)}
+            "quota": None if quota is None else round(quota, 2), "loadavg_1m": None if load1 is None else round(load1, 1),
+            "sample": "median of %d pass(es) over %d unit(s) of the same workload (%.1f s in all), oracle fp32 path: "
+                      "im2row + vectorised SGEMM, OpenMP x %d pinned to physical cores (min(affinity, cgroup quota)); "
+                      "a restatement, not MatConvNet" % (len(ts), pairs, sum(ts), cores)}
 
 
 def cpu_teacher_line(args):

@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply, xm_se_squeeze_bn, xm_scale_axpy_bn (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply, xm_se_squeeze_bn, xm_scale_axpy_bn; 105 = + xm_set_exec_hint / xm_get_exec_hint (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -65,9 +65,22 @@ int xm_device_synchronize(void);
  * so that the candidates run alone: do not meet a new shape while ANY stream of the process is being captured into a graph;
  * a stream that is itself being captured gets the analytic choice instead).  The table persists in a text file next to the
  * library (tune_gfx950.txt; $XM_TUNE_FILE overrides, XM_TUNE_FILE="" disables): loaded before the first lookup,
- * written by xm_tune_save.  With the shipped table the tile choice -- hence the summation order and the bits of every
- * result -- is the same in every process, and known shapes cost no timed launches on first use
+ * written by xm_tune_save.  With the shipped table the kernel and tile choice -- hence the summation order and the bits of
+ * every result -- is a function of (shape, table, execution hint below) and of NOTHING else: the same in every process,
+ * whatever it called before, on whatever streams; known shapes cost no timed launches on first use
  * (external/compute_audio_feats.m:116-136 walks ten width buckets).  XM_AUTOTUNE=0 uses the analytic model instead. */
+/* Execution hint, an explicit statement of the host about HOW it calls (process-wide; default 0):
+ *   XM_EXEC_SINGLE_STREAM  every operator call of this process arrives on ONE stream (MatConvNet's own sequence:
+ *                          cnn_train_dag -> net.eval -> vl_nn* one after the other, run_distillation.m:170-182; what the
+ *                          MEX binding does), so a kernel never shares the chip with another stream's kernel.  Kernels
+ *                          that are faster alone but poor neighbours (conv_wgrad_patch_kernel: 48 KB of LDS x 3 blocks per
+ *                          CU) become candidates.  A host that overlaps streams (dagnn.DagNN.wgradStream, bench.py's
+ *                          default) leaves it 0.
+ * Same results within the operator tolerance either way; another kernel is another summation order, so set the hint once,
+ * before the first operator call, and identically on every worker.  Unknown bits: XM_EINVAL. */
+enum { XM_EXEC_SINGLE_STREAM = 1 };
+int xm_set_exec_hint(unsigned flags);
+unsigned xm_get_exec_hint(void);
 int xm_tune_load(const char *path);   /* NULL / "" = the default file; returns the number of entries read */
 int xm_tune_save(const char *path);   /* merges with the file on disk, writes atomically */
 int xm_tune_entries(int *total, int *unsaved);

@@ -9,8 +9,8 @@
  *   tuning table   XM_TUNE_FILE (path; "" disables), XM_AUTOTUNE=0 (analytic model only), XM_TUNE_REPS, XM_TUNE_VERBOSE,
  *                  XM_HALO_MARGIN (a challenger kernel must win by this fraction, default 0.04), XM_W8_MIN_TILES (the
  *                  eight-wave configuration is a candidate for launches of at least this many 128 x 128 tiles, default 1024),
- *                  XM_WGRAD_PATCH_ANY_STREAM (conv_wgrad_patch_kernel also for calls that arrive on another stream than the
- *                  forward convolutions: DESIGN.md 2.1g), XM_WGRAD_PATCH_SLOTS (its grid: blocks per round, default 768)
+ *                  XM_WGRAD_PATCH_SLOTS (conv_wgrad_patch_kernel's grid: blocks per round, default 768; WHETHER that kernel
+ *                  is a candidate is the host's xm_set_exec_hint(XM_EXEC_SINGLE_STREAM), not an environment setting)
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,

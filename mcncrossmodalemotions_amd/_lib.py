@@ -27,6 +27,8 @@ SIGNATURES = {
     "xm_tune_load": [C.c_char_p],
     "xm_tune_save": [C.c_char_p],
     "xm_tune_entries": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "xm_set_exec_hint": [C.c_uint],
+    "xm_get_exec_hint": [],
     "xm_workspace_reserve": [_sz],
     "xm_workspace_bytes": [],
     "xm_workspace_reserve_stream": [_sz, _vp],
@@ -103,7 +105,7 @@ SIGNATURES = {
     "xm_normalize_face": [c_fp, _i, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
     "xm_crop_resize_face": [c_fp, _i, _i, _i, _f, _i, _i, C.POINTER(C.c_float), c_fp, _vp],
 }
-_RESTYPES = {"xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t,
+_RESTYPES = {"xm_get_exec_hint": C.c_uint, "xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t,
              "xm_workspace_generation": C.c_ulonglong}
 # test hooks (not part of include/xmodal.h)
 _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],

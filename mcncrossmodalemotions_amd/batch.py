@@ -255,7 +255,9 @@ def getBatchEmoVoxCeleb(imdb, batch, imageSize=(512, 300), numPredEmotions=8, lo
             z[k, :w.numel()].copy_(w)                                    # zero padding when short (:117)
             if mix is not None:
                 nir, nwr, ratio = mix
-                nzlen = int(w.numel())
+                # z + y .* Nratio runs over numel(z) (:128-134): a short clip was zero-padded to audSamp BEFORE the mix, so
+                # its padded tail receives noise too; the resampled window of 'S' is not padded (its own length, cut to L)
+                nzlen = int(w.numel()) if speedR is not None else L
                 y = imdb.device_noise(nir, device)[nwr - 1:nwr - 1 + nzlen]
                 a = vl.mat_empty(1, 1, 1, 1, device=device)
                 a.fill_(ratio)

@@ -23,6 +23,15 @@ bool path_on(Path p) {
   return on[p];
 }
 
+long long env_int(const char *name, long long dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoll(e) : dflt;
+}
+double env_double(const char *name, double dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atof(e) : dflt;
+}
+
 static char g_err[512] = "";
 char *err_buf() { return g_err; }
 
@@ -89,7 +98,7 @@ const void *cached_device_table(const void *host, size_t bytes) {
 
 extern "C" {
 
-int xm_version(void) { return 104; }   // 101: xm_nnbnorm_relu_pool_backward takes y_pool (round 2 signature)
+int xm_version(void) { return 105; }   // 101: xm_nnbnorm_relu_pool_backward takes y_pool (round 2 signature)
 const char *xm_last_error(void) { return xm::err_buf(); }
 
 int xm_workspace_reserve(size_t bytes) {

@@ -284,7 +284,7 @@ static inline int wgrad_cfg(int ci) { ci = base_cfg(ci); return ci >= kNumWgradC
 // of the chip).  Measured (profiles/r04/schedule_experiments.txt): alone it is 3 ... 4 % faster at every size, but next to the
 // filter derivatives of the side stream the shorter launches lose more than that (student step at 64 spectrograms - 3 %).
 static inline bool w8_ok(long long M, long long NP) {
-  static const long long min_tiles = getenv("XM_W8_MIN_TILES") ? atoll(getenv("XM_W8_MIN_TILES")) : 1024;
+  static const long long min_tiles = env_int("XM_W8_MIN_TILES", 1024);
   return path_on(kPathW8) && ((M + 127) / 128) * ((NP + 127) / 128) >= min_tiles;
 }
 static inline unsigned w8_skip(long long M, long long NP) { return w8_ok(M, NP) ? 0u : 1u << 7; }
@@ -375,17 +375,12 @@ static void launch_gemm_cfg(int ci, const ConvGemmArgs &a, dim3 grid, hipStream_
 static int g_force_cfg = -1;  // test hook (xm_debug_force_conv_cfg)
 static int g_force_stem = -1; // test hook (xm_debug_force_conv_stem): 1 = conv_stem_kernel wherever it can run, 0 = never
 static int g_force_wgrad_patch = -1; // test hook (xm_debug_force_wgrad_patch)
-// Streams of the last 64 convolution calls (any direction): a caller all of whose calls arrive on ONE stream has nothing
-// running next to a kernel (the reference's own call sequence); wgrad_patch_ok asks.
-static hipStream_t g_conv_streams[64];
-static unsigned g_conv_calls = 0;
-static inline void note_conv_stream(hipStream_t st) { g_conv_streams[g_conv_calls++ & 63] = st; }
-static inline bool single_stream_caller(hipStream_t st) {
-  const unsigned n = std::min(g_conv_calls, 64u);
-  for (unsigned i = 0; i < n; ++i)
-    if (g_conv_streams[i] != st) return false;
-  return true;
-}
+// Execution hint of the HOST (xm_set_exec_hint, include/xmodal.h): XM_EXEC_SINGLE_STREAM = every operator call of the
+// process arrives on one stream, so a kernel has the chip to itself -- conv_wgrad_patch_kernel (48 KB of LDS per block,
+// three blocks per CU for its whole life) is a candidate only then (next to another stream's kernels it
+// loses).  An explicit statement of the caller, never inferred: the kernel a shape gets is a function of (shape, table,
+// hint) and of nothing the process did before.
+static unsigned g_exec_hint = 0;
 static int g_force_halo = -1; // test hook (xm_debug_force_conv_halo): 1 = halo-patch kernel wherever it can run, 0 = never
 static unsigned long long *g_dbg_cycles = nullptr;  // device buffer, set by xm_debug_conv_cycles(1)
 
@@ -591,7 +586,7 @@ struct HaloVar {
   int bm, ps;
 };
 static const HaloVar kHaloVars[] = {{128, 512}, {96, 512}, {96, 1024}};
-static const float kHaloMargin = getenv("XM_HALO_MARGIN") ? (float)atof(getenv("XM_HALO_MARGIN")) : 0.04f;
+static const float kHaloMargin = (float)env_double("XM_HALO_MARGIN", 0.04);
 
 // fills the patch geometry of `a` (an implicit-GEMM problem already described by its tap / gather fields) and returns
 // the patch floats per channel the widest 128-pixel tile needs (0: the kernel cannot run this problem): taps in an
@@ -1233,7 +1228,6 @@ static int launch_stem(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
-  note_conv_stream(st);
   // The (u,v) validity mask has 63 bits.  Without spatial padding every tap is inside the image, so
   // larger filters (the 1 x 401 STFT bank of batch.runSpec) simply do not use it.
   const bool padded = (g.pt | g.pb | g.pl | g.pr) != 0;
@@ -1469,7 +1463,6 @@ static PrepKey prep_key(const float *f, const Geo &g, bool fold) {
 // prepare_only: run just the filter transpositions into the persistent cache (xm_nnconv_prepare_backward)
 static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st,
                       const float *accum = nullptr, bool prepare_only = false) {
-  note_conv_stream(st);
   struct Cls {
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
@@ -1957,15 +1950,14 @@ static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, cons
 }
 
 // ---- filter derivative of 3 x 3 / stride 1 / pad 1 layers from an input patch (conv_wgrad_patch_kernel) -------------------
-// One-stream callers only (the reference's own call sequence, cnn_train_dag -> vl_nnconv one after the other; bench.py
-// --serial): alone the kernel is 11 ... 22 % faster than the generic one (profiles/r04/wgrad_patch_bench.txt), a step on one
+// Hosts that declared XM_EXEC_SINGLE_STREAM only (xm_set_exec_hint; the reference's own call sequence, cnn_train_dag ->
+// vl_nnconv one after the other -- the MEX binding sets it; bench.py --serial): alone the kernel is 11 ... 22 % faster than the generic one (profiles/r04/wgrad_patch_bench.txt), a step on one
 // stream 1.7 %; launched on a side stream next to the dgrad of the same layer it fills the chip with three 48 KB blocks per CU
 // for its whole life and the pair takes LONGER than with the generic kernel (student step at 64: - 1.5 %).
-// One-stream caller = the last 64 convolution calls all arrived on this stream; XM_WGRAD_PATCH_ANY_STREAM lifts the restriction.
+// The choice depends on the shape, the tuning table and that explicit hint -- never on what the process called before.
 static bool wgrad_patch_ok(const Geo &g, const float *x, const float *dzdy, hipStream_t st) {
-  static const bool any_stream = getenv("XM_WGRAD_PATCH_ANY_STREAM") != nullptr;
   if (!path_on(kPathWgradPatch) || g_force_cfg >= 0 || g_force_splits > 0) return false;
-  if (g_force_wgrad_patch < 0 && !any_stream && !single_stream_caller(st)) return false;
+  if (g_force_wgrad_patch < 0 && !(g_exec_hint & XM_EXEC_SINGLE_STREAM)) return false;
   if (g.G != 1 || g.FH != 3 || g.FW != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.pt != 1 || g.pb != 1 || g.pl != 1 || g.pr != 1) return false;
   if (g.H != 30 || g.Ho != g.H || g.Wo != g.W) return false;          // instantiated row counts (HH)
@@ -1989,7 +1981,7 @@ static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, con
   a.nbm = (g.Kg + 127) / 128;
   a.nbn = (g.R + 127) / 128;
   const int tiles = a.nbm * a.nbn;
-  static const int slots = getenv("XM_WGRAD_PATCH_SLOTS") ? std::max(64, atoi(getenv("XM_WGRAD_PATCH_SLOTS"))) : 768;   // one round of 3 blocks per CU
+  static const int slots = std::max(64, (int)env_int("XM_WGRAD_PATCH_SLOTS", 768));   // one round of 3 blocks per CU
   int splits = std::max(1, std::min(std::min(a.nStages / 8, slots / std::max(1, tiles)), max_splits));
   a.stagesPerSplit = (a.nStages + splits - 1) / splits;
   splits = (a.nStages + a.stagesPerSplit - 1) / a.stagesPerSplit;
@@ -2009,7 +2001,6 @@ static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, con
 }
 
 static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &g, hipStream_t st) {
-  note_conv_stream(st);
   // analytic fallback: minimal padded work (split-K supplies the parallelism)
   int fb = 0;
   {
@@ -2076,6 +2067,13 @@ int xm_debug_force_conv_halo(int on) {
   g_force_halo = on < 0 ? -1 : std::min(on, 3);
   return old;
 }
+
+int xm_set_exec_hint(unsigned flags) {
+  if (flags & ~(unsigned)XM_EXEC_SINGLE_STREAM) return fail(XM_EINVAL, "xm_set_exec_hint: unknown flag bits 0x%x", flags);
+  g_exec_hint = flags;
+  return XM_OK;
+}
+unsigned xm_get_exec_hint(void) { return g_exec_hint; }
 
 int xm_debug_force_wgrad_patch(int on) {
   int old = g_force_wgrad_patch;

@@ -82,6 +82,9 @@ enum Path {
   kPathCount
 };
 bool path_on(Path p);
+// numeric settings from the environment (tuning-table knobs listed in include/xmodal_prof.h): read through context.cpp
+long long env_int(const char *name, long long dflt);
+double env_double(const char *name, double dflt);
 
 // persistent small device objects keyed by content (tap tables)
 const void *cached_device_table(const void *host, size_t bytes);

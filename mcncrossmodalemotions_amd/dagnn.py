@@ -253,7 +253,9 @@ class DropOut(Layer):
     """dagnn.DropOut [EXT]: identity in test mode; in training mode Y = MASK .* X with a fresh mask per call
     (vl_nndropout), the backward pass multiplies by the same mask.  emoVoxZoo.m:116-135,272-277 inserts it behind fc6
     and fc7 when opts.dropout > 0.  Masks come from the library's stateless Philox stream: `seed` per layer, the
-    counter offset advances by ceil(numel / 4) per call."""
+    counter offset advances by ceil(numel / 4) per call.  The offset is training state: train.save_checkpoint stores it and
+    `cont` restores it, so a resumed run continues the mask sequence instead of repeating it; data-parallel workers fold
+    their rank into the seed (DagNN.workerRank, set by train.process_epoch) so that the shards do not share masks."""
 
     def __init__(self, rate=0.5, seed=0):
         super().__init__()
@@ -267,7 +269,8 @@ class DropOut(Layer):
         if self.net is None or self.net.mode == "test" or self.frozen or self.rate <= 0:
             self.mask = None
             return [inputs[0]]
-        y, self.mask = vl.vl_nndropout(inputs[0], rate=self.rate, seed=self.seed, offset=self._offset)
+        seed = (self.seed + 0x9E3779B1 * int(getattr(self.net, "workerRank", 0))) & 0x7FFFFFFF
+        y, self.mask = vl.vl_nndropout(inputs[0], rate=self.rate, seed=seed, offset=self._offset)
         self._offset += (int(inputs[0].numel()) + 3) // 4
         return [y]
 
@@ -1045,6 +1048,9 @@ class _SEBnTrainStep(_Step):
     def begin(self, net, axpy_step, out):
         """called by the Axpy+ReLU step's backward; False = run the separate operators"""
         self.stash = None
+        # the fused backward writes no bias-derivative slot: a value left from an unfused pass (fuseSETrain toggled
+        # between steps) must not make the producing Conv skip its own dzdb (round-4 advisor)
+        self.bias_conv_done = False
         if not net.fuseSETrain:
             if self.fwd is not None:
                 raise RuntimeError("fused SE tail: fuseSETrain was switched off between the forward and the backward pass")

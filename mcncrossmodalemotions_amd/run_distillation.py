@@ -43,11 +43,17 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
         expDir += "-temp%d" % temperature
     # ParameterServer before the first device allocation / kernel of the process (xmodal.h "CALL ORDER": a communicator
     # created later slows every step); 'tmove' (run_distillation.m:88) = the library's communicator when there is
-    # more than one worker and RCCL can carry it, torch.distributed otherwise (gloo test groups)
+    # more than one worker and RCCL can carry it -- every worker of the node on its own device --, torch.distributed
+    # otherwise (gloo test groups on CPU / on one shared GPU).  ONE RCCL communicator per worker: a multi-GPU host
+    # initialises torch.distributed on GLOO (it is only the control plane: store, barriers) and the library's
+    # communicator carries the exchange; an nccl process group is accepted but is a second communicator.
+    import torch
     import torch.distributed as dist
     if parameterServer == "tmove":
-        parameterServer = "rccl-capi" if (dist.is_available() and dist.is_initialized() and
-                                          dist.get_backend() == "nccl" and dist.get_world_size() > 1) else "torch"
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        own_device = (multi and torch.cuda.is_available() and os.environ.get("XM_DEBUG_DIST") != "gloo0" and
+                      torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size())))
+        parameterServer = "rccl-capi" if (multi and (dist.get_backend() == "nccl" or own_device)) else "torch"
     if isinstance(parameterServer, train.ParameterServer):
         parserv = parameterServer
         parserv.start()

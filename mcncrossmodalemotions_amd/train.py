@@ -49,13 +49,26 @@ class ParameterServer:
         self.rank = 0
         self._started = False
         self._handles = []
+        self.group = None     # backend 'torch': the process group the exchange runs on (None = the default group)
 
-    _generation = 0      # start() calls of this process so far (store keys; every worker makes the same calls)
+    _generation = 0      # id exchanges of this process so far (store keys; every worker makes the same calls)
+    _agreement = 0       # start_agreed() rounds of this process so far (its own counter: see start_agreed)
+    store_timeout_s = 120.0   # how long a worker waits for another worker's key before it counts it as failed
 
     @staticmethod
     def _store():
         from torch.distributed.distributed_c10d import _get_default_store
         return _get_default_store()
+
+    @classmethod
+    def _wait_keys(cls, store, keys):
+        """True when every key is there within store_timeout_s (a worker that died never writes its own)"""
+        import datetime
+        try:
+            store.wait(list(keys), datetime.timedelta(seconds=cls.store_timeout_s))
+            return True
+        except Exception:   # noqa: BLE001 -- torch raises RuntimeError / DistStoreError depending on the store
+            return False
 
     def start(self):
         if self._started:
@@ -64,27 +77,36 @@ class ParameterServer:
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(), dist.get_rank()
         if (self.world > 1 or self.force) and self.backend == "rccl-capi":
-            L = _lib.load()
             buf = (C.c_char * 128)()
-            if self.world == 1:
-                _lib.check(L.xm_debug_comm_force_single(1))
             raw = None
             if self.world > 1:
                 # the 128-byte id travels through the process group's key-value store (labBroadcast in a MATLAB host):
                 # host memory only -- no device allocation and no collective may precede xm_comm_init (xmodal.h "CALL
-                # ORDER") -- and a worker whose id generation failed tells the others instead of leaving them waiting
+                # ORDER").  The key's generation is taken BEFORE anything can fail (library load included), so that
+                # every worker uses the same key whatever happens to it, and a worker 0 that cannot produce the id
+                # says so under that key instead of leaving the others waiting for it.
                 ParameterServer._generation += 1
                 key = "xm_comm_id/%d" % ParameterServer._generation
                 store = self._store()
                 if self.rank == 0:
-                    rc = L.xm_comm_unique_id(buf)
+                    try:
+                        rc = _lib.load().xm_comm_unique_id(buf)
+                    except Exception:
+                        store.set(key, b"no")
+                        raise
                     store.set(key, b"ok" + bytes(buf) if rc == 0 else b"no")
                     _lib.check(rc)
+                if not self._wait_keys(store, [key]):
+                    raise RuntimeError("ParameterServer: no communicator id from worker 0 within %.0f s"
+                                       % self.store_timeout_s)
                 got = bytes(store.get(key))
                 if not got.startswith(b"ok"):
                     raise RuntimeError("ParameterServer: worker 0 could not create the communicator id")
                 raw = got[2:130]
+                L = _lib.load()
             else:
+                L = _lib.load()
+                _lib.check(L.xm_debug_comm_force_single(1))
                 _lib.check(L.xm_comm_unique_id(buf))
                 raw = bytes(buf)
             _lib.check(L.xm_comm_init(C.c_char_p(raw), self.rank, self.world))
@@ -94,9 +116,17 @@ class ParameterServer:
     def start_agreed(cls, backend="rccl-capi", force=False):
         """Start the `backend` ParameterServer on every worker, or -- if ANY worker failed to -- torch.distributed
         on all of them: the outcome is agreed through the process group's store (host side, nothing on the device),
-        so that no worker is left inside a collective the others never enter.  Returns the started instance."""
+        so that no worker is left inside a collective the others never enter.  Returns the started instance.
+
+        The agreement has its OWN round counter, advanced unconditionally before anything else: a worker that fails
+        early in start() (it cannot even load the library) still writes its outcome under the key the others read.
+        Two rounds: every worker posts its own outcome, then its VERDICT (all outcomes seen and good); the result is
+        the AND of the verdicts.  A key that does not arrive within store_timeout_s counts as a failure on the
+        worker that waited, and its verdict carries that to the others."""
         import sys
         import torch.distributed as dist
+        cls._agreement += 1
+        gen = cls._agreement
         ps = cls(backend)
         ps.force = force
         ok = 1
@@ -106,10 +136,11 @@ class ParameterServer:
             print("ParameterServer(%s) failed to start: %s" % (backend, e), file=sys.stderr, flush=True)
             ok = 0
         if backend != "torch" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            cls._generation += 1
             store, world, rank = cls._store(), dist.get_world_size(), dist.get_rank()
-            store.set("xm_ps_ok/%d/%d" % (cls._generation, rank), b"1" if ok else b"0")
-            ok = int(all(bytes(store.get("xm_ps_ok/%d/%d" % (cls._generation, r))) == b"1" for r in range(world)))
+            for phase in ("ok", "verdict"):
+                keys = ["xm_ps_%s/%d/%d" % (phase, gen, r) for r in range(world)]
+                store.set(keys[rank], b"1" if ok else b"0")
+                ok = int(cls._wait_keys(store, keys) and all(bytes(store.get(k)) == b"1" for k in keys))
         if not ok:
             try:
                 ps.stop()
@@ -135,7 +166,7 @@ class ParameterServer:
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         else:
             import torch.distributed as dist
-            self._handles.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+            self._handles.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def sync(self):
         if self.backend == "rccl-capi":
@@ -158,7 +189,19 @@ class ParameterServer:
             _lib.check(_lib.load().xm_comm_count(C.byref(n)))
             return int(n.value)
         import torch.distributed as dist
-        return dist.get_world_size() if dist.is_initialized() else 1
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def rccl_count(self):
+        """ranks of the RCCL communicator the exchange runs on, or None when it does not run over RCCL: the
+        library's own communicator (ncclCommCount), or torch's process group when that group's backend is nccl"""
+        if not self.active:
+            return None
+        if self.backend == "rccl-capi":
+            return self.comm_count()
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+            return dist.get_world_size(self.group)
+        return None
 
     def stop(self):
         if not self._started:
@@ -438,6 +481,7 @@ def process_epoch(net, imdb, getBatch, subset, opts, epoch, mode, parserv=None, 
     import time
     world = parserv.world if parserv is not None else 1
     rank = parserv.rank if parserv is not None else 0
+    net.workerRank = rank          # dagnn.DropOut folds it into its seed: every shard draws its own masks
     _reset_losses(net)
     subset = list(subset)
     t0 = time.perf_counter()
@@ -472,8 +516,11 @@ def save_checkpoint(net, path, info, epoch):
         off = p._flat_off
         vals[name] = net._flat.val[off:off + n].reshape(tuple(reversed(p.value.shape))).clone()
         moms[name] = net._flat.mom[off:off + n].reshape(tuple(reversed(p.value.shape))).clone()
+    # counter offsets of the dropout layers' Philox streams (training state: a resumed run must not repeat masks)
+    rng = {l.name: int(l.block._offset) for l in net.layers if hasattr(l.block, "_offset")}
     tmp = path + ".tmp"
-    torch.save({"format": "xmodal-params-v2", "params": vals, "momentum": moms, "info": info, "epoch": epoch}, tmp)
+    torch.save({"format": "xmodal-params-v2", "params": vals, "momentum": moms, "info": info, "epoch": epoch,
+                "rng": rng}, tmp)
     os.replace(tmp, path)
 
 
@@ -506,6 +553,9 @@ def load_checkpoint(net, path, strict=True):
         net._flat.val[off:off + n].copy_(src.reshape(-1))
         if mom is not None:
             net._flat.mom[off:off + n].copy_(mom.reshape(-1))
+    for l in net.layers:
+        if hasattr(l.block, "_offset") and l.name in (ck.get("rng") or {}):
+            l.block._offset = int(ck["rng"][l.name])
     net.paramGeneration = getattr(net, "paramGeneration", 0) + 1
     return ck
 

@@ -127,6 +127,18 @@ def tune_save(path=None):
     return int(tot.value), int(new.value)
 
 
+EXEC_SINGLE_STREAM = 1    # include/xmodal.h XM_EXEC_SINGLE_STREAM
+
+
+def set_exec_hint(flags):
+    """xm_set_exec_hint: tell the library HOW this host calls it (EXEC_SINGLE_STREAM: every operator call on one stream,
+    MatConvNet's own sequence) -- kernel choice is a function of (shape, table, this hint), never of the call history.
+    Returns the previous value."""
+    old = int(_L().xm_get_exec_hint())
+    _lib.check(_L().xm_set_exec_hint(int(flags)))
+    return old
+
+
 def out_size(n, pa, pb, f, d, s):
     return _L().xm_out_size(n, pa, pb, f, d, s)
 

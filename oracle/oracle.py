@@ -446,15 +446,52 @@ def physical_core_cpus():
     return sorted(first.values()) or sorted(allowed)
 
 
+def cpu_quota():
+    """CPU bandwidth limit of this process' cgroup in cores (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us),
+    or None when there is none.  A team of more threads than the quota pays for is throttled by the kernel for part
+    of every period -- pinned threads then stall in turn and a timed baseline swings by 2-3 x between boxes."""
+    def read(path):
+        try:
+            return open(path).read().split()
+        except OSError:
+            return None
+    v = read("/sys/fs/cgroup/cpu.max")
+    if v and len(v) == 2 and v[0] != "max":
+        try:
+            return float(v[0]) / float(v[1])
+        except ValueError:
+            return None
+    for d in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+        q, per = read(d + "/cpu.cfs_quota_us"), read(d + "/cpu.cfs_period_us")
+        if q and per:
+            try:
+                if float(q[0]) > 0:
+                    return float(q[0]) / float(per[0])
+            except ValueError:
+                pass
+    return None
+
+
+def baseline_cpus():
+    """the CPUs a timed baseline runs on: one per physical core of the affinity mask, no more of them than the
+    cgroup's CPU quota pays for (min(affinity, quota))"""
+    cpus = physical_core_cpus()
+    q = cpu_quota()
+    if q is not None:
+        cpus = cpus[:max(1, min(len(cpus), int(q)))]
+    return cpus
+
+
 def set_num_threads(n=None):
     lib().orc_set_num_threads(int(n or physical_cores()))
     return num_threads()
 
 
 def pin_threads():
-    """one OpenMP thread per physical core, each pinned to its core (timed baselines); returns (threads, restore):
-    call restore() afterwards -- the calling thread is team member 0 and was pinned as well."""
-    cpus = physical_core_cpus()
+    """one OpenMP thread per physical core (at most the cgroup's CPU quota of them), each pinned to its core (timed
+    baselines); returns (threads, restore): call restore() afterwards -- the calling thread is team member 0 and was
+    pinned as well."""
+    cpus = baseline_cpus()
     try:
         before = os.sched_getaffinity(0)
     except AttributeError:

@@ -41,6 +41,10 @@ def test_error_reporting_without_gpu():
     assert L.xm_comm_destroy() == 0
     assert L.xm_parserv_push(None, 4, None) == 1
     assert L.xm_out_size(512, 1, 1, 7, 1, 2) == 254
+    # execution hint: explicit, process-wide, unknown bits rejected
+    assert L.xm_get_exec_hint() == 0 and L.xm_set_exec_hint(1) == 0 and L.xm_get_exec_hint() == 1
+    assert L.xm_set_exec_hint(6) == 1 and b"unknown flag" in L.xm_last_error() and L.xm_get_exec_hint() == 1
+    assert L.xm_set_exec_hint(0) == 0
     # invalid arguments are rejected before any device work, with a MATLAB-style message
     rc = L.xm_nnconv_forward(None, 8, 8, 4, 2, None, 3, 3, 3, 5, None, None, 1, 1, 0, 0, 0, 0, 1, 1, None)
     assert rc == 1 and b"does not divide" in L.xm_last_error()

@@ -38,7 +38,8 @@ def test_launcher_world_must_match_the_flag():
 def test_gpus_flag_starts_the_ranks_itself(gpu):
     """`python bench.py --gpus 2` with no launcher: two ranks (XM_DEBUG_DIST=gloo0: both on the one GPU of the test
     box, exchange over gloo -- a functional run of the whole N > 1 path; the throughput means nothing) and ONE json line
-    that says so: n_gpus 2, rccl_ranks 2, dp2, global batch = 2 shards."""
+    that says so: n_gpus 2, world 2, dp2, global batch = 2 shards; rccl_ranks is null because no RCCL communicator
+    carried that exchange (it is reported from ncclCommCount only)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
                         "--no-cpu-baseline", "--no-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=_env(XM_DEBUG_DIST="gloo0"), timeout=900)
@@ -46,6 +47,7 @@ def test_gpus_flag_starts_the_ranks_itself(gpu):
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3
+    assert d["n_gpus"] == 2 and d["world"] == 2 and d["rccl_ranks"] is None and d["steps"] == 3
+    assert d["control_group"] == "gloo"
     assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
     assert d["value"] > 0 and d["scaling"] == "weak"

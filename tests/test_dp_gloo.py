@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from oracle import oracle as O
@@ -80,7 +81,7 @@ def test_shard_batch_is_interleaved():
     assert sorted(sum((train.shard_batch(range(10), r, 4) for r in range(4)), [])) == list(range(10))
 
 
-def _agree_worker(rank, world, port, out):
+def _agree_worker(rank, world, port, out, fail="init@1"):
     """ParameterServer.start_agreed over 2 gloo workers: the communicator's id travels through the store, and when ONE
     worker cannot start the library's communicator every worker ends up on torch.distributed (none is left waiting in a
     collective the others never enter)."""
@@ -118,6 +119,18 @@ def _agree_worker(rank, world, port, out):
             return b"simulated communicator failure"
     fake = FakeLib()
     _lib._lib = fake                               # what _lib.load() hands out from now on
+    real_load = _lib.load
+    if fail.startswith("load@"):
+        # the library cannot even be loaded on ONE worker: it fails before it has touched any store key
+        bad = int(fail[5:])
+
+        def load():
+            if rank == bad:
+                raise OSError("simulated: libxmodal_hip.so cannot be loaded")
+            return fake
+        _lib.load = load
+        fake.xm_comm_init = lambda raw, r, w: (ids.append(b"x"), 0)[1]
+    train.ParameterServer.store_timeout_s = 30.0   # a lost key fails the test instead of hanging it
     try:
         ps = train.ParameterServer.start_agreed("rccl-capi")
         backend = ps.backend
@@ -126,6 +139,7 @@ def _agree_worker(rank, world, port, out):
         ps.stop()
     finally:
         _lib._lib = L
+        _lib.load = real_load
     np.save(out + ".%d.npy" % rank, np.array([1.0 if backend == "torch" else 0.0, float(flat[0]), float(len(ids))]))
     dist.destroy_process_group()
     assert real_id is not None and real_init is not None
@@ -140,3 +154,19 @@ def test_start_agreed_falls_back_on_every_worker(tmp_path):
         assert backend_is_torch == 1.0, "worker %d stayed on the failed backend" % r
         assert summed == 3.0                      # 1 + 2 through the fallback's all-reduce
         assert inits == 1.0                       # every worker tried the library's communicator exactly once
+
+
+@pytest.mark.parametrize("bad", [0, 1])
+def test_start_agreed_when_one_worker_cannot_load_the_library(tmp_path, bad):
+    """round-4 advisor: a worker that fails BEFORE the id exchange (no library) must still meet the others in the
+    agreement round -- its own round counter -- and worker 0 must tell the others that no id is coming."""
+    import time
+    world, port = 2, _free_port()
+    out = str(tmp_path / "agree_load")
+    t0 = time.time()
+    mp.start_processes(_agree_worker, args=(world, port, out, "load@%d" % bad), nprocs=world, join=True,
+                       start_method="spawn")
+    assert time.time() - t0 < 25.0, "a worker sat in a store timeout"
+    for r in range(world):
+        backend_is_torch, summed, inits = np.load(out + ".%d.npy" % r)
+        assert backend_is_torch == 1.0 and summed == 3.0

@@ -104,6 +104,27 @@ def test_student_step_with_dropout(gpu):
     net.eval(inputs)
     Vt = oracle_net.forward(net, {"data": data, "logitTarget": lgo, "maxLabel": lab}, P0, mode="test")
     close(vl.to_numpy(net.vars["prediction"].value), Vt["prediction"], 1e-4, "test-mode prediction")
+    # round-4 advisor: the counter offsets are training state (a resumed run continues the mask sequence instead of
+    # repeating it), and a data-parallel worker folds its rank into the seed (no two shards share masks)
+    import os
+    import tempfile
+    from mcncrossmodalemotions_amd import train
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "net-epoch-1.pt")
+        train.save_checkpoint(net, path, {}, 1)
+        offs = {l.name: l.block._offset for l in drops}
+        assert all(v == 2 * ((first[k].size + 3) // 4) for k, v in offs.items()), offs
+        net2 = zoo.emoVoxZoo(numSeconds=1, width_mult=0.125, seed=5, dropout=0.5)
+        net2.pack_params()
+        train.load_checkpoint(net2, path)
+        assert {l.name: l.block._offset for l in net2.layers if isinstance(l.block, dagnn.DropOut)} == offs
+    net.mode = "normal"
+    net.workerRank = 1
+    net.eval(inputs, ["objective", 1])
+    for l in drops:
+        m = vl.to_numpy(l.block.mask)
+        assert not np.array_equal(m, O.dropout_mask(m.shape, 0.5, l.block.seed, offs[l.name])), l.name
+        assert np.array_equal(m, O.dropout_mask(m.shape, 0.5, (l.block.seed + 0x9E3779B1) & 0x7FFFFFFF, offs[l.name]))
 
 
 def test_pool6_buckets_on_device(gpu):
