@@ -1957,7 +1957,11 @@ static int launch_stem_wgrad(const float *x, const float *dzdy, float *dfo, cons
 // The choice depends on the shape, the tuning table and that explicit hint -- never on what the process called before.
 static bool wgrad_patch_ok(const Geo &g, const float *x, const float *dzdy, hipStream_t st) {
   if (!path_on(kPathWgradPatch) || g_force_cfg >= 0 || g_force_splits > 0) return false;
-  if (g_force_wgrad_patch < 0 && !(g_exec_hint & XM_EXEC_SINGLE_STREAM)) return false;
+  // a candidate for hosts that declared one stream, and -- whatever the host does -- for launches of at least
+  // XM_WGRAD_PATCH_MIN_STAGES output columns (default 4096: the batch-256 layers, which fill the chip for ~2 ms by
+  // themselves; like the eight-wave rule "from 1024 tiles" a function of the shape only)
+  static const long long min_stages = env_int("XM_WGRAD_PATCH_MIN_STAGES", 4096);
+  if (g_force_wgrad_patch < 0 && !(g_exec_hint & XM_EXEC_SINGLE_STREAM) && (long long)g.N * g.W < min_stages) return false;
   if (g.G != 1 || g.FH != 3 || g.FW != 3 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1) return false;
   if (g.pt != 1 || g.pb != 1 || g.pl != 1 || g.pr != 1) return false;
   if (g.H != 30 || g.Ho != g.H || g.Wo != g.W) return false;          // instantiated row counts (HH)
@@ -1991,6 +1995,56 @@ static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, con
   {
     ProfScope ps(9 * 100, 2.0 * g.Kg * (double)g.Ho * g.Wo * g.N * g.R, st, (double)a.xBytes + (double)a.dyBytes + 4.0 * slab);
     hipLaunchKernelGGL(conv_wgrad_patch_kernel<30>, dim3(tiles, splits), dim3(256), 0, st, a);
+  }
+  XM_LAUNCH_CHECK();
+  if (splits > 1) {
+    launch_reduce_splits(part, dfo, slab, splits, slab, st);
+    XM_LAUNCH_CHECK();
+  }
+  return XM_OK;
+}
+
+// ---- filter derivative of 5 x 5 / stride 2 layers from an input patch (conv_wgrad_patch_s2_kernel, round 5) ------------------
+// The student's conv2 (44 % of its arithmetic).  Unlike the 3 x 3 patch kernel above this one is a candidate for every caller
+// (measured once per shape against the best generic configuration): 53 KB of LDS per block, three blocks per CU.
+static int g_force_wgrad_patch_s2 = -1; // test hook (xm_debug_force_wgrad_patch_s2)
+static bool wgrad_patch_s2_ok(const Geo &g, const float *x, const float *dzdy) {
+  if (!path_on(kPathWgradPatchS2) || g_force_cfg >= 0 || g_force_splits > 0) return false;
+  if (g.G != 1 || g.FH != 5 || g.FW != 5 || g.sy != 2 || g.sx != 2 || g.dy != 1 || g.dx != 1) return false;
+  if (g.pt < 1 || g.pt > 2 || g.pl < 0 || g.pl > 4) return false;
+  if ((g.H & 1) || (g.Ho & 1)) return false;                            // 8-byte loads of row pairs
+  if ((((uintptr_t)x | (uintptr_t)dzdy) & 7) != 0) return false;
+  return (long long)g.N * g.Wo * ((g.Ho + 31) / 32) >= 64;              // enough stages to split
+}
+static int launch_wgrad_patch_s2(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int max_splits,
+                                 hipStream_t st) {
+  WgradPatchS2Args a{};
+  a.dY = dzdy;
+  a.X = x;
+  a.xBytes = (unsigned)((size_t)g.H * g.W * g.C * g.N * 4);
+  a.dyBytes = (unsigned)((size_t)g.Ho * g.Wo * g.K * g.N * 4);
+  a.M = g.Kg;
+  a.R = g.R;
+  a.ldo = g.R;
+  a.C = g.C;
+  a.H = g.H, a.W = g.W, a.Ho = g.Ho, a.Wo = g.Wo, a.K = g.K;
+  a.pt = g.pt, a.pl = g.pl;
+  a.nSeg = (g.Ho + 31) / 32;
+  a.nStages = g.N * g.Wo * a.nSeg;
+  a.nbm = (g.Kg + 127) / 128;
+  a.nbn = (g.R + 127) / 128;
+  const int tiles = a.nbm * a.nbn;
+  static const int slots = std::max(64, (int)env_int("XM_WGRAD_PATCH_SLOTS", 768));   // one round of 3 blocks per CU
+  int splits = std::max(1, std::min(std::min(a.nStages / 8, slots / std::max(1, tiles)), max_splits));
+  a.stagesPerSplit = (a.nStages + splits - 1) / splits;
+  splits = (a.nStages + a.stagesPerSplit - 1) / a.stagesPerSplit;
+  a.splits = splits;
+  const size_t slab = (size_t)g.Kg * g.R;
+  a.splitStride = slab;
+  a.out = splits > 1 ? part : dfo;
+  {
+    ProfScope ps(10 * 100, 2.0 * g.Kg * (double)g.Ho * g.Wo * g.N * g.R, st, (double)a.xBytes + (double)a.dyBytes + 4.0 * slab);
+    hipLaunchKernelGGL((conv_wgrad_patch_s2_kernel<5, 2>), dim3(tiles * splits), dim3(256), 0, st, a);
   }
   XM_LAUNCH_CHECK();
   if (splits > 1) {
@@ -2047,6 +2101,13 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
     const int pick = g_force_wgrad_patch >= 0 ? g_force_wgrad_patch : tune_challengers(pkey, st, run3, 2, pok, 0.01f);
     return run3(pick);
   }
+  if (wgrad_patch_s2_ok(g, x, dzdy)) {
+    auto run4 = [&](int h) { return h ? launch_wgrad_patch_s2(x, dzdy, dfo, g, part, max_splits, st) : run(ci); };
+    bool pok[2] = {true, true};
+    TuneKey pkey{10, g.Kg, NP, g.R, g.G, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+    const int pick = g_force_wgrad_patch_s2 >= 0 ? g_force_wgrad_patch_s2 : tune_challengers(pkey, st, run4, 2, pok, 0.01f);
+    return run4(pick);
+  }
   return run(ci);
 }
 
@@ -2075,6 +2136,11 @@ int xm_set_exec_hint(unsigned flags) {
 }
 unsigned xm_get_exec_hint(void) { return g_exec_hint; }
 
+int xm_debug_force_wgrad_patch_s2(int on) {
+  int old = g_force_wgrad_patch_s2;
+  g_force_wgrad_patch_s2 = on < 0 ? -1 : (on ? 1 : 0);
+  return old;
+}
 int xm_debug_force_wgrad_patch(int on) {
   int old = g_force_wgrad_patch;
   g_force_wgrad_patch = on < 0 ? -1 : (on ? 1 : 0);
@@ -2216,6 +2282,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   }
   if (kind == 9) {
     snprintf(buf, len, "conv_wgrad_patch_kernel<30>");
+    return XM_OK;
+  }
+  if (kind == 10) {
+    snprintf(buf, len, "conv_wgrad_patch_s2_kernel<5, 2>");
     return XM_OK;
   }
   if (kind == 5 || kind == 6) {

@@ -2473,4 +2473,227 @@ conv_wgrad_patch_kernel(const WgradPatchArgs a) {
   }
 }
 
+// ---- filter derivative of a 5 x 5 / stride 2 layer from an input PATCH (round 5: the student's conv2) ----------------------
+// The same idea as conv_wgrad_patch_kernel for the layer that carries 44 % of the student's arithmetic: conv_wgrad_kernel
+// gathers its im2col operand tap by tap -- every input element of a 5 x 5 / stride 2 layer is fetched 25 / 4 times (dword
+// loads with padding test + address arithmetic, parked one by one; PMC: 4.2 x the algorithmic bytes).  Here a stage is a
+// SEGMENT of 32 output rows of one output column of one sample (k = the 32 reduction indices of the stage):
+//   * the dY tile [128 filters][32 pixels]: 8-byte loads of contiguous rows, LDS image [k/4][row][k%4]; output rows that do
+//     not exist are loaded as zeros; a segment of exactly 30 rows (the second half of the student's 62-row columns) runs 15
+//     reduction steps with conv_wgrad_patch_kernel's tail pairing, so that layer has no padded reduction step at all;
+//   * the input patch under the segment: FW input columns x 68 rows (2 * 32 + FH - 1 = 67, from an even row) of the <= 7
+//     channels the block's 128 (tap, channel) columns touch, each element loaded ONCE (8-byte loads; rows / columns outside
+//     the image are out-of-range loads = zeros) into [channel][column][row]; tap (u, v) of pixel k sits at lane base + 2 k:
+//     ds_read_b32 with immediate offsets, no masks, no VALU in the loop.  Pitches: column 70 = 6 (mod 64), channel 350 = 30
+//     (mod 64): bank = u + 6 v + 30 c grows with the column index and 32 consecutive (u, v, c) columns span < 64 of it, so an
+//     MFMA tile's B read touches 32 different LDS banks (even pitches: the 8-byte stores of the staging path stay aligned).
+// 64 MFMAs per wave and stage behind ONE barrier, double-buffered LDS (2 x 26.7 KB: three blocks per CU), prefetch distance 2,
+// split over the stage range; partials combined by reduce_splits_kernel in a fixed order.  Blocks that work on the same stage
+// range (the tiles of one split: they share the dY tile / the patch) are placed on ONE XCD, so each L2 fetches a stage once.
+struct WgradPatchS2Args {
+  const float *dY, *X;
+  float *out;                       // [splits][M][ldo]
+  unsigned xBytes, dyBytes;
+  int M, R, ldo, C;                 // filters, FH * FW * C columns, row pitch of out, input channels
+  int H, W, Ho, Wo, K;              // input rows / columns, output rows / columns, filters of the whole tensor
+  int pt, pl;                       // top (1 or 2) / left padding
+  int nSeg;                         // 32-row segments per output column
+  int nStages, stagesPerSplit;      // stages = N * Wo * nSeg
+  int nbm, nbn, splits;
+  size_t splitStride;
+};
+
+template <int FHW, int S>
+__global__ void __launch_bounds__(256, 3)
+conv_wgrad_patch_s2_kernel(const WgradPatchS2Args a) {
+  static_assert(FHW == 5 && S == 2, "pitches / channel count are laid out for 5 x 5 taps, stride 2");
+  constexpr int BM = 128, BN = 128, HH = 32, G = HH / 4;                      // pixels per stage, float4 groups
+  constexpr int PLA = BM * 4 + 16;                                             // plane pitch of the dY image (floats)
+  constexpr int PR = (S * (HH - 1) + FHW + 2) / 2;                             // row pairs of the patch (34: rows -2 ... 65; pt >= 1)
+  constexpr int CS = 70, PC = FHW * CS, NCHN = (BN + FHW * FHW - 2) / (FHW * FHW) + 1, PGUARD = 4;
+  static_assert(CS >= 2 * PR && CS % 2 == 0 && CS % 64 == FHW + 1 && PC % 64 == 30 && NCHN == 7, "patch pitches");
+  constexpr int SA = G * PLA, SP = PGUARD + NCHN * PC + 2, STG = SA + SP;     // floats per stage buffer
+  static_assert(STG % 4 == 0, "16-byte aligned stage buffers");
+  constexpr int HP = HH / 2;                                                   // pixel pairs per dY row segment
+  constexpr int NLA = BM * HP / 256, NLB = (NCHN * FHW * PR + 255) / 256;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float smem[2 * STG];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave & 1, wn = wave >> 1;
+  // block -> (tile, split): groups of 8 splits, one per XCD (hardware places block b on XCD b % 8)
+  const int ntile = a.nbm * a.nbn;
+  int tile, split;
+  {
+    const int L = blockIdx.x, grp = L / (8 * ntile), rem = L - grp * 8 * ntile;
+    const int nsp = min(8, a.splits - grp * 8);
+    split = grp * 8 + rem % nsp;
+    tile = rem / nsp;
+  }
+  const int bm = tile % a.nbm, bn = tile / a.nbm;
+  const int s0 = split * a.stagesPerSplit, s1 = min(a.nStages, s0 + a.stagesPerSplit);
+  const int ci0 = (bn * BN) / (FHW * FHW);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
+
+  for (int i = t; i < 2 * STG / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging maps (fixed for the whole kernel)
+  unsigned voA[NLA], voB[NLB];
+  int ldB[NLB], colB[NLB], rowB[NLB];
+  const int prA = 2 * (t % HP);                                                // first pixel of this thread's dY pairs
+  const int ldA0 = ((t % HP) >> 1) * PLA + (t / HP) * 4 + 2 * (t & 1);         // + 16 rows per j
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int row = t / HP + (256 / HP) * j;
+    const int gm = min(bm * BM + row, a.M - 1);
+    voA[j] = (unsigned)((gm * a.Wo * a.Ho + prA) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int idx = t + 256 * j;
+    const int ch = idx / (FHW * PR), rem = idx - ch * (FHW * PR), col = rem / PR, pr = rem - col * PR;
+    const bool ok = idx < NCHN * FHW * PR && ci0 + ch < a.C;
+    voB[j] = (unsigned)((((ci0 + ch) * a.W + col - a.pl) * a.H + 2 * pr - 2) * 4);   // + the stage's column / row below
+    colB[j] = ok ? col - a.pl : -(1 << 20);
+    rowB[j] = 2 * pr - 2;
+    ldB[j] = idx < NCHN * FHW * PR ? SA + PGUARD + ch * PC + col * CS + 2 * pr : STG - 2;
+  }
+  // fragment addresses
+  const float *sAr = smem + half * PLA + (wm * 64 + l31) * 4;
+  int bB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = min(bn * BN + (wn * 2 + j) * 32 + l31, a.R - 1);
+    const int ci = r / (FHW * FHW), tap = r - ci * (FHW * FHW), v = tap / FHW, u = tap - v * FHW;
+    bB[j] = SA + PGUARD + (ci - ci0) * PC + v * CS + u + (2 - a.pt) + S * 4 * half;   // k = 8 c + e (+ 4 for lanes 32-63)
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x2 ra[NLA], rb[NLB];
+  int ln, lc, lh, ch = 0;          // load side: sample / column / segment of the next stage to request; compute side: segment
+#define XM_WS_LOAD()   /* the stage (ln, lc, lh), then on to the next segment / column / sample */              \
+  {                                                                                                 \
+    const int n_ = ln, c_ = lc, h_ = lh;                                                            \
+    if (++lh == a.nSeg) { lh = 0; if (++lc == a.Wo) lc = 0, ++ln; }                                 \
+    const unsigned sA_ = (unsigned)((((n_ * a.K) * a.Wo + c_) * a.Ho + HH * h_) * 4);               \
+    const unsigned sB_ = (unsigned)((((n_ * a.C) * a.W + S * c_) * a.H + S * HH * h_) * 4);         \
+    const bool okA_ = HH * h_ + prA < a.Ho;                                                         \
+    _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                 \
+      ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dyrsrc, (int)(okA_ ? voA[j] : 0xFFFFFFFFu), (int)sA_, 0)); \
+    _Pragma("unroll") for (int j = 0; j < NLB; ++j) {                                               \
+      const bool ok_ = (unsigned)(S * c_ + colB[j]) < (unsigned)a.W && (unsigned)(S * HH * h_ + rowB[j]) < (unsigned)a.H; \
+      rb[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)(ok_ ? voB[j] + sB_ : 0xFFFFFFFFu), 0, 0)); \
+    }                                                                                               \
+  }
+#define XM_WS_STORE(BUF)                                                                            \
+  _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                   \
+    *reinterpret_cast<f32x2 *>(smem + (BUF) * STG + ldA0 + (256 / HP) * 4 * j) = ra[j];             \
+  _Pragma("unroll") for (int j = 0; j < NLB; ++j)                                                   \
+    *reinterpret_cast<f32x2 *>(smem + (BUF) * STG + ldB[j]) = rb[j];
+
+  __syncthreads();   // the zero fill
+  if (s0 < s1) {
+    lh = ch = s0 % a.nSeg;
+    lc = (s0 / a.nSeg) % a.Wo;
+    ln = s0 / (a.nSeg * a.Wo);
+    XM_WS_LOAD()
+    XM_WS_STORE(0)
+    __syncthreads();
+    if (s0 + 1 < s1) XM_WS_LOAD()
+    int cur = 0;
+    for (int s = s0; s < s1; ++s) {
+      // registers hold stage s + 1 (requested a whole stage ago): park it in the buffer the previous barrier freed, request
+      // stage s + 2, multiply stage s
+      if (s + 1 < s1) {
+        XM_WS_STORE(cur ^ 1)
+      }
+      if (s + 2 < s1) XM_WS_LOAD()
+      const float *A = sAr + cur * STG;
+      const float *P = smem + cur * STG;
+      // a segment of 30 rows (the second half of a 62-row column) multiplies 15 reduction steps instead of 16: its last
+      // chunk pairs (24, 28), (25, 29), (26, 27) -- lanes 32-63 take the dY value of k = 27 from the chunk's first group
+      const bool tail30 = a.Ho - HH * ch == HH - 2;
+      if (++ch == a.nSeg) ch = 0;
+#define XM_WS_FULL(c)                                                                               \
+  {                                                                                                 \
+    f32x4 af[2];                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4 *>(A + 2 * (c) * PLA + i * 128); \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+      float bf[2];                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j] = P[bB[j] + S * (8 * (c) + e)];           \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);    \
+    }                                                                                               \
+  }
+      XM_WS_FULL(0)
+      XM_WS_FULL(1)
+      XM_WS_FULL(2)
+      {
+        // last chunk: steps (24, 28), (25, 29) are common; the third is (26, 30) or -- tail -- (26, 27): only the ADDRESSES of
+        // the operands of lanes 32-63 differ (one select per stage); the fourth step (27, 31) exists in a full segment only
+        constexpr int c = 3;
+        const int adjB = tail30 ? S * 3 * half : 0, adjA = tail30 ? half * (PLA - 1) : 0;
+        f32x4 af[2];
+        float a2[2], b2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[i] = *reinterpret_cast<const f32x4 *>(A + 2 * c * PLA + i * 128);
+          a2[i] = (A + 2 * c * PLA + i * 128 + 2)[-adjA];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b2[j] = (P + bB[j] + S * (8 * c + 2))[-adjB];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = P[bB[j] + S * (8 * c + e)];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], b2[j], acc[i][j], 0, 0, 0);
+        if (!tail30) {
+          float bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = P[bB[j] + S * (8 * c + 3)];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][3], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+#undef XM_WS_FULL
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef XM_WS_LOAD
+#undef XM_WS_STORE
+  float *out = a.out + (size_t)split * a.splitStride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = bn * BN + (wn * 2 + j) * 32 + l31;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int m = bm * BM + (wm * 2 + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        if (m < a.M) out[(size_t)m * a.ldo + r] = acc[i][j][rr];
+      }
+  }
+}
+
 }  // namespace xm

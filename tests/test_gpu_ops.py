@@ -157,6 +157,51 @@ def test_conv_wgrad_patch_kernel(gpu, case):
         L.xm_debug_force_wgrad_patch(old)
 
 
+WGRAD_PATCH_S2_CASES = [  # H, W, C, N, K, pad (t b l r)
+    (126, 25, 7, 3, 70, (1, 1, 1, 1)),      # the student's conv2 rows (62 output rows: segments of 32 + 30), ragged channels / filters
+    (30, 21, 20, 8, 130, (1, 1, 1, 1)),     # 14 output rows: one segment, most of it zero padding of the reduction
+    (126, 17, 96, 4, 256, (1, 1, 1, 1)),    # conv2's channels and filters: 19 column tiles, 2 filter tiles, channel groups of 7
+    (64, 12, 5, 13, 33, (1, 2, 0, 1)),      # no left padding, other bottom / right padding
+    (68, 11, 3, 8, 8, (2, 1, 3, 0)),        # two rows / three columns of padding in front
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PATCH_S2_CASES)
+def test_conv_wgrad_patch_s2_kernel(gpu, case):
+    """Filter derivative of 5 x 5 / stride 2 layers (the student's conv2) through conv_wgrad_patch_s2_kernel -- a stage is a
+    32-row segment of one output column, the input patch under it is staged once in LDS and the 25 taps read from it --
+    against the oracle, next to the generic kernel on the same operands; the profiler hooks prove which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, K, pad = case
+    rng = np.random.default_rng(H * 7 + W * 3 + C + N + K)
+    x, f, b = rnd(rng, H, W, C, N), rnd(rng, 5, 5, C, K), rnd(rng, K)
+    y = O.vl_nnconv(x, f, b, stride=2, pad=pad)
+    dzdy = rnd(rng, *y.shape)
+    dzdy[rng.random(dzdy.shape) < 0.3] = 0                     # a ReLU mask's zeros
+    _, df_ref, db_ref = O.vl_nnconv(x, f, b, dzdy, stride=2, pad=pad, acc64=True)
+    xd, fd, bd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1)), vl.from_numpy(dzdy)
+    old = L.xm_debug_force_wgrad_patch_s2(1)
+    try:
+        (_, df, db), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, dd, stride=2, pad=pad, no_der_data=True))
+        assert "conv_wgrad_patch_s2_kernel<5, 2>" in names, names
+        close(vl.to_numpy(df), df_ref, what="patch wgrad (5 x 5 / 2)")
+        close(vl.to_numpy(db).ravel(), db_ref.ravel(), what="dzdb next to it")
+        L.xm_debug_force_wgrad_patch_s2(0)
+        (_, df0, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, dd, stride=2, pad=pad, no_der_data=True))
+        assert not any("patch" in n for n in names), names
+        close(vl.to_numpy(df0), df_ref, what="generic wgrad")
+        # other geometries never take it: odd row count, stride 1
+        L.xm_debug_force_wgrad_patch_s2(1)
+        x2 = vl.from_numpy(rnd(rng, H + 1, W, C, N))
+        y2 = vl.vl_nnconv(x2, fd, bd, stride=2, pad=pad)
+        _, names = _kernels_run(L, lambda: vl.vl_nnconv(x2, fd, bd, vl.from_numpy(rnd(rng, *y2.shape)), stride=2, pad=pad,
+                                                        no_der_data=True))
+        assert not any("patch" in n for n in names), names
+    finally:
+        L.xm_debug_force_wgrad_patch_s2(old)
+
+
 # (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
 STEM_CASES = [(512, 60, 2, 96, (1, 1, 1, 1)), (131, 45, 3, 96, (1, 1, 1, 1)), (64, 33, 2, 64, (3, 3, 3, 3)),
               (40, 41, 2, 33, (0, 0, 0, 0)), (29, 23, 1, 7, (2, 1, 0, 3)), (300, 18, 1, 96, (1, 0, 1, 0))]
