@@ -211,7 +211,8 @@ def main():
     # HOW this host calls the library, stated once and before the first operator call (include/xmodal.h): the kernel a
     # shape gets depends on (shape, table, this hint) only -- the roofline leg below runs on one stream but keeps the
     # hint of the timed region, so both run the same kernels
-    exec_hint = int(args.exec_hint) if args.exec_hint != "auto" else (1 if args.serial else 0)
+    one_stream = args.serial or (not args.wgrad_stream and (args.workload in ("student", "joint") or not args.overlap_teacher))
+    exec_hint = int(args.exec_hint) if args.exec_hint != "auto" else (1 if one_stream else 0)
     vl.set_exec_hint(vl.EXEC_SINGLE_STREAM if exec_hint else 0)
 
     def ctl_max(x, dtype):

@@ -18,6 +18,11 @@ python bench.py --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-
 python bench.py --serial --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
 python bench.py --teacher senet50 --per-gpu-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
 python bench.py --frames 13 --teacher senet50 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null
+# the reference's real default shape: numSeconds = 4 -> 512 x 400 spectrograms (run_distillation.m:74), batch 64 and the 32-pair shard
+python bench.py --workload student --width 400 $A > /dev/null
+python bench.py --workload student --width 400 --serial $A > /dev/null
+python bench.py --width 400 $A > /dev/null
+python bench.py --teacher senet50 --width 400 $A > /dev/null
 python - <<PY
 import numpy as np, torch
 from mcncrossmodalemotions_amd import vl, zoo, external
