@@ -11,11 +11,14 @@
  *                  eight-wave configuration is a candidate for launches of at least this many 128 x 128 tiles, default 1024),
  *                  XM_WGRAD_PATCH_SLOTS (conv_wgrad_patch_kernel's grid: blocks per round, default 768; WHETHER that kernel
  *                  is a candidate is the host's xm_set_exec_hint(XM_EXEC_SINGLE_STREAM), not an environment setting)
+ *                  XM_WGRAD_PATCH_MIN_STAGES (conv_wgrad_patch_kernel without the one-stream hint: launches of at least this
+ *                  many output columns, default 4096), XM_DGRAD_S2_MIN_BLOCKS (conv_dgrad_s2_kernel: launches of at least this
+ *                  many blocks, default 6 x 768)
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
  *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
- *                  XM_NO_W8, XM_NO_WGRAD_PATCH, XM_NO_WGRAD_PATCH_S2.
+ *                  XM_NO_W8, XM_NO_WGRAD_PATCH, XM_NO_WGRAD_PATCH_S2, XM_NO_DGRAD_S2.
  *                  Each chooses between two complete, parity-tested implementations of the same operator (the operator tests
  *                  force both arms through the xm_debug_force_* hooks; tests/test_gpu_path_switches.py runs whole passes
  *                  with every selector set, in fresh processes, against the default; profiles/ holds the A/B lines);
@@ -47,6 +50,8 @@ int xm_debug_force_conv_stem(int on);
 int xm_debug_force_wgrad_patch(int on);
 /* the same for the patch kernel of 5 x 5 / stride 2 layers (conv_wgrad_patch_s2_kernel: the student's conv2) */
 int xm_debug_force_wgrad_patch_s2(int on);
+/* 0: never conv_dgrad_s2_kernel (dgrad of 5 x 5 / stride 2 layers); 1 / -1: wherever it can run (default) */
+int xm_debug_force_dgrad_s2(int on);
 /* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
 int xm_debug_force_conv_splits(int splits);
 /* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,

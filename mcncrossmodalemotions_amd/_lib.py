@@ -117,6 +117,7 @@ _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           "xm_debug_force_conv_stem": [_i],
           "xm_debug_force_wgrad_patch": [_i],
           "xm_debug_force_wgrad_patch_s2": [_i],
+          "xm_debug_force_dgrad_s2": [_i],
           "xm_prof_enable": [_i],
           "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_longlong)],

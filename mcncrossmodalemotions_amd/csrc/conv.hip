@@ -1461,12 +1461,72 @@ static PrepKey prep_key(const float *f, const Geo &g, bool fold) {
 // accum != NULL: dX = dgrad + accum (the derivative another branch of a fork already produced), added in
 // the GEMM epilogue instead of by a separate pass
 // prepare_only: run just the filter transpositions into the persistent cache (xm_nnconv_prepare_backward)
+// ---- dgrad of 5 x 5 / stride 2 layers with both row parities per wave (conv_dgrad_s2_kernel, round 5) ---------------------
+static int g_force_dgrad_s2 = -1;   // test hook (xm_debug_force_dgrad_s2): 0 = never, 1 / -1 = wherever it can run
+static bool dgrad_s2_ok(const Geo &g, const float *dzdy, const float *dxo, const float *accum) {
+  if (!path_on(kPathDgradS2) || g_force_dgrad_s2 == 0 || g_force_cfg >= 0 || g_force_splits > 0 || accum) return false;
+  if (g.G != 1 || g.FH != 5 || g.FW != 5 || g.sy != 2 || g.sx != 2 || g.dy != 1 || g.dx != 1) return false;
+  if (g.pt != 1 || g.pl < 0 || g.pl > 4 || (g.H & 1) || (g.Ho & 1) || (g.K & 7)) return false;
+  if ((((uintptr_t)dzdy | (uintptr_t)dxo) & 7) != 0) return false;
+  if ((size_t)g.Ho * g.Wo * g.K * g.N * 4 >= (1ull << 32)) return false;
+  if (g_force_dgrad_s2 == 1) return true;
+  // Its blocks are large (two output columns x 64 row pairs x all filters: ~0.4 ms of a CU slot) and there are 37 of them per
+  // 126 x 73 sample, so small batches pay the partly filled last round -- 32 spectrograms: 1.54 rounds of 768 slots cost 2
+  // (90 against 95 TFLOP/s for the merged launch), 64: 3.08 rounds cost 4 and the 40 KB blocks are poor neighbours of the
+  // filter derivative on the side stream (student step - 4 %); 256: 12.3 rounds, 124 against 115 TFLOP/s and - 0.5 ms per
+  // step.  A function of the shape only: launches of at least XM_DGRAD_S2_MIN_BLOCKS blocks (default 6 rounds of the chip).
+  static const long long min_blocks = env_int("XM_DGRAD_S2_MIN_BLOCKS", 6 * 768);
+  const long long per_sample = (long long)((g.W + 3) / 4 + (g.W + 2) / 4) * (((g.H + 1) / 2 + 63) / 64) * ((g.C + kDgS2Rows - 1) / kDgS2Rows);
+  return per_sample * g.N >= min_blocks;
+}
+static int launch_dgrad_s2(const float *dzdy, const float *f, float *dxo, const Geo &g, hipStream_t st) {
+  DgradS2Args a{};
+  a.dY = dzdy;
+  a.dX = dxo;
+  a.dyBytes = (unsigned)((size_t)g.Ho * g.Wo * g.K * g.N * 4);
+  a.C = g.C, a.K = g.K, a.H = g.H, a.W = g.W, a.Ho = g.Ho, a.Wo = g.Wo;
+  a.pl = g.pl;
+  a.nbm = (g.C + kDgS2Rows - 1) / kDgS2Rows;
+  a.nkg = g.K / 8;
+  a.nmt = ((g.H + 1) / 2 + 63) / 64;
+  int blocks = 0;
+  for (int px = 0; px < 2; ++px) {
+    a.xfirst[px] = ((px - g.pl) % 2 + 2) % 2;               // columns x with (x + pl) % 2 == px
+    const int ncols = a.xfirst[px] < g.W ? (g.W - a.xfirst[px] + 1) / 2 : 0;
+    a.ncg[px] = (ncols + 1) / 2;
+    a.nv[px] = px == 0 ? 3 : 2;                              // v = px, px + 2, (px + 4)
+    blocks += a.ncg[px] * a.nmt * a.nbm;
+  }
+  const size_t fdFloats = (size_t)a.nbm * 2 * 3 * a.nkg * kDgS2Tile;
+  WsCarver ws;
+  int rc = ws.init(WsCarver::need(fdFloats, 4), st);
+  if (rc) return rc;
+  float *Fd = ws.take<float>(fdFloats);
+  a.Fd = Fd;
+  hipLaunchKernelGGL(prep_dgrad_s2_kernel, dim3((unsigned)std::min<size_t>((fdFloats + 255) / 256, 2048)), dim3(256), 0, st, f,
+                     Fd, g.C, g.K, a.nbm, a.nkg, g.pl);
+  XM_LAUNCH_CHECK();
+  {
+    ProfScope ps(11 * 100, 2.0 * g.K * (double)g.Ho * g.Wo * g.N * g.R, st,
+                 (double)a.dyBytes + 4.0 * g.K * g.R + 4.0 * g.C * (double)g.H * g.W * g.N);
+    hipLaunchKernelGGL(conv_dgrad_s2_kernel<1>, dim3((unsigned)(blocks * g.N)), dim3(256), 0, st, a);
+  }
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &g, hipStream_t st,
                       const float *accum = nullptr, bool prepare_only = false) {
   struct Cls {
     int a, b, u0, ustep, nU, v0, vstep, nV, Rc, Rp, i0, hi0, PI, j0, wi0, PJ;
     size_t aoff;
   };
+  if (dgrad_s2_ok(g, dzdy, dxo, accum)) {
+    // the student's conv2: both row parities per wave, whole-line stores (conv_dgrad_s2_kernel); its filter operand is laid
+    // out by a 3 MB pass inside the call, so there is nothing to prepare ahead
+    if (prepare_only) return XM_OK;
+    return launch_dgrad_s2(dzdy, f, dxo, g, st);
+  }
   // H-collapsing convolution (FC layer sliding along W only, e.g. the student's fc6: 9x1 filter on a
   // 9 x Wi map): every input row hi is touched by exactly one filter row u = hi, so folding u into
   // the GEMM rows (M = FH*FC) avoids multiplying FH-1 masked-out taps per pixel.
@@ -2136,6 +2196,11 @@ int xm_set_exec_hint(unsigned flags) {
 }
 unsigned xm_get_exec_hint(void) { return g_exec_hint; }
 
+int xm_debug_force_dgrad_s2(int on) {
+  int old = g_force_dgrad_s2;
+  g_force_dgrad_s2 = on < 0 ? -1 : (on ? 1 : 0);
+  return old;
+}
 int xm_debug_force_wgrad_patch_s2(int on) {
   int old = g_force_wgrad_patch_s2;
   g_force_wgrad_patch_s2 = on < 0 ? -1 : (on ? 1 : 0);
@@ -2286,6 +2351,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   }
   if (kind == 10) {
     snprintf(buf, len, "conv_wgrad_patch_s2_kernel<5, 2>");
+    return XM_OK;
+  }
+  if (kind == 11) {
+    snprintf(buf, len, "conv_dgrad_s2_kernel<1>");
     return XM_OK;
   }
   if (kind == 5 || kind == 6) {

@@ -2696,4 +2696,198 @@ conv_wgrad_patch_s2_kernel(const WgradPatchS2Args a) {
   }
 }
 
+// ---- dgrad of a 5 x 5 / stride 2 layer (round 5: the student's conv2, 9 % of the default step) ------------------------------
+// dX(c, y, x) = sum_k sum_{u = (y + pt) mod 2, v = (x + pl) mod 2 (step 2)} dY(k, (y + pt - u) / 2, (x + pl - v) / 2) F(u, v, c, k).
+// conv_gemm_multi_kernel runs the four stride-parity classes as four masked implicit GEMMs (gathers tap by tap) and each class
+// writes every other element of every other column: dword stores at an 8-byte stride, half-written cache lines (PMC: 2.1 x
+// the algorithmic bytes written).  Here a wave owns ONE output column x and 32 consecutive row PAIRS (y = 2 m, 2 m + 1):
+//   * both row parities in one wave (two pixel tiles x three 32-channel row tiles = 96 accumulator registers): filter rows
+//     u = 1, 3 feed the even rows, u = 0, 2, 4 the odd ones -- every wave multiplies 5 filter rows per stage, so the waves
+//     of a block stay in step -- and the epilogue stores (y = 2 m, 2 m + 1) of a channel as ONE 8-byte store: 32 lanes x
+//     8 bytes = 256 contiguous bytes per instruction and channel, every line written once and whole;
+//   * a stage = 8 filters (k) x one filter column v: the filter operand is a 15 KB tile that the preparation kernel has laid
+//     out in LDS order [k-group][channel row][4] (a linear copy: 16-byte loads, no arithmetic), the dY patch of the block --
+//     2 dY columns x 68 rows x 8 filters, every element loaded ONCE -- goes through registers into [k][column][row]; tap u
+//     of pixel m reads patch[m + (1 + pt - u) / 2]: ds_read_b32 with immediate offsets, no masks, no VALU;
+//   * 60 MFMAs per wave and stage behind one barrier, double-buffered LDS (2 x 20 KB, three blocks per CU), prefetch
+//     distance 2 as in conv_wgrad_patch_s2_kernel.  Block = 2 columns of one column-parity class x 64 row pairs x 96 channels.
+struct DgradS2Args {
+  const float *dY, *Fd;             // Fd: [bm][class][v slot (3)][K / 8][10 planes][96 rows + 1][4]  (prep_dgrad_s2_kernel): the LDS image
+  float *dX;
+  unsigned dyBytes;
+  int C, K, H, W, Ho, Wo;
+  int pl;                           // left padding (the top padding is the template parameter)
+  int nbm, nkg, nmt;                // channel blocks of 96, K / 8, blocks of 64 row pairs
+  int ncg[2], xfirst[2], nv[2];     // per column-parity class: column pairs, first column, filter columns (3 / 2)
+};
+
+constexpr int kDgS2Rows = 96, kDgS2Planes = 10, kDgS2PLA = kDgS2Rows * 4 + 4;   // plane pitch: one float4 of padding (the two
+constexpr int kDgS2Tile = kDgS2Planes * kDgS2PLA;                               // half-waves read neighbouring planes)
+
+// Fd from the filter bank F (FH x FW x C x K, u fastest): plane p = 2 u + (kk >> 2) of stage (class, v slot, k-group)
+__global__ void __launch_bounds__(256)
+prep_dgrad_s2_kernel(const float *__restrict__ F, float *__restrict__ Fd, int C, int K, int nbm, int nkg, int pl) {
+  const size_t total = (size_t)nbm * 2 * 3 * nkg * kDgS2Tile;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i & 3);
+    size_t r = i >> 2;
+    const int row = (int)(r % (kDgS2Rows + 1));     // row 96 = the padding quad of a plane
+    r /= kDgS2Rows + 1;
+    const int p = (int)(r % kDgS2Planes);
+    r /= kDgS2Planes;
+    const int kg = (int)(r % nkg);
+    r /= nkg;
+    const int vs = (int)(r % 3);
+    r /= 3;
+    const int cls = (int)(r & 1), bm = (int)(r >> 1);
+    const int u = p >> 1, k = 8 * kg + 4 * (p & 1) + q, v = cls + 2 * vs, c = bm * kDgS2Rows + row;
+    Fd[i] = (row < kDgS2Rows && c < C && v < 5 && k < K) ? F[u + 5 * (v + 5 * (c + (size_t)C * k))] : 0.f;
+  }
+}
+
+template <int PT>
+__global__ void __launch_bounds__(256, 3)
+conv_dgrad_s2_kernel(const DgradS2Args a) {
+  static_assert(PT == 1, "row offsets of the five filter rows are written out for a top padding of 1");
+  constexpr int PLA = kDgS2PLA;                           // plane pitch of the filter image (floats)
+  constexpr int SA = kDgS2Tile;                           // 3880: the stage's filter tile is copied as it lies in memory
+  constexpr int PR = 34, PCOL = 72, PK = 2 * PCOL;        // patch: 34 row pairs (rows m0 - 2 ... m0 + 65) per column, 2 columns per k
+  constexpr int SP = 8 * PK, STG = SA + SP + 4;           // (+ 4 spare floats: staging threads without work)
+  static_assert(STG % 4 == 0, "16-byte aligned stage buffers");
+  constexpr int NLA = (kDgS2Tile / 4 + 255) / 256, NLB = (8 * 2 * PR + 255) / 256;   // 4, 3
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float smem[2 * STG];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  const int wc = wave & 1, wh = wave >> 1;
+  // block -> (sample, channel block, row-pair block, class, column pair); the class with three filter columns first
+  int b = blockIdx.x;
+  const int percls0 = a.ncg[0] * a.nmt * a.nbm, percls1 = a.ncg[1] * a.nmt * a.nbm;
+  const int n = b / (percls0 + percls1);
+  b -= n * (percls0 + percls1);
+  const int first = a.nv[0] >= a.nv[1] ? 0 : 1;
+  int cls = first;
+  if (b >= (first == 0 ? percls0 : percls1)) {
+    b -= first == 0 ? percls0 : percls1;
+    cls = first ^ 1;
+  }
+  const int cg = b % a.ncg[cls];
+  b /= a.ncg[cls];
+  const int mt = b % a.nmt, bm = b / a.nmt;
+  const int m0 = 64 * mt;
+  const int xa = a.xfirst[cls] + 4 * cg;                  // the block's columns: xa, xa + 2
+  const int nv = a.nv[cls];
+  const int nst = nv * a.nkg;
+  const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dY, 0, a.dyBytes, 0x00020000);
+
+  for (int i = t; i < 2 * STG / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging maps ----
+  const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(a.Fd + ((size_t)(bm * 2 + cls) * 3) * a.nkg * kDgS2Tile) + t;
+  const int ldA3 = t + 768 < kDgS2Tile / 4 ? 4 * (t + 768) : STG - 4;   // the fourth quad of the threads that have one
+  unsigned voB[NLB];
+  int ldB[NLB], colB[NLB];
+  bool rowOk[NLB];
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int idx = t + 256 * j;
+    const int kk = idx / (2 * PR), rem = idx - kk * (2 * PR), col = rem / PR, pr = rem - col * PR;
+    const bool ok = idx < 8 * 2 * PR;
+    const int row = m0 - 2 + 2 * pr;
+    rowOk[j] = ok && (unsigned)row < (unsigned)a.Ho;
+    colB[j] = col;
+    voB[j] = (unsigned)((((n * a.K + kk) * a.Wo + col) * a.Ho + row) * 4);   // + 8 kg filters and the stage's dY column below
+    ldB[j] = ok ? SA + kk * PK + col * PCOL + 2 * pr : STG - 4;
+  }
+  // ---- fragment addresses ----
+  const float *sAr = smem + half * PLA + l31 * 4;
+  const float *sBr = smem + SA + 4 * half * PK + wc * PCOL + 32 * wh + l31 + 2;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][e][r] = 0.f;
+
+  f32x4 ra[NLA];
+  f32x2 rb[NLB];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int lv = 0, lkg = 0;             // the next stage to request: filter column slot, k-group
+#define XM_DG_LOAD()                                                                                 \
+  {                                                                                                  \
+    const int v_ = cls + 2 * lv, kg_ = lkg;                                                          \
+    const f32x4 *fs_ = fsrc + (size_t)(lv * a.nkg + kg_) * (kDgS2Tile / 4);                         \
+    if (++lkg == a.nkg) lkg = 0, ++lv;                                                               \
+    const int ja_ = (xa + a.pl - v_) >> 1;               /* dY column of the block's first column (xa + pl - v is even) */ \
+    const unsigned sB_ = (unsigned)(((8 * kg_) * a.Wo + ja_) * a.Ho * 4);                             \
+    _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                  \
+      if (j < NLA - 1 || t + 256 * j < kDgS2Tile / 4) ra[j] = fs_[256 * j];                           \
+    _Pragma("unroll") for (int j = 0; j < NLB; ++j) {                                                \
+      const bool ok_ = rowOk[j] && (unsigned)(ja_ + colB[j]) < (unsigned)a.Wo;                       \
+      rb[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(dyrsrc, (int)(ok_ ? voB[j] + sB_ : 0xFFFFFFFFu), 0, 0)); \
+    }                                                                                                \
+  }
+#define XM_DG_STORE(BUF)                                                                             \
+  _Pragma("unroll") for (int j = 0; j < NLA; ++j)                                                    \
+    *reinterpret_cast<f32x4 *>(smem + (BUF) * STG + (j < NLA - 1 ? 4 * (t + 256 * j) : ldA3)) = ra[j]; \
+  _Pragma("unroll") for (int j = 0; j < NLB; ++j)                                                    \
+    *reinterpret_cast<f32x2 *>(smem + (BUF) * STG + ldB[j]) = rb[j];
+  // filter row U -> (row parity E = (U + PT) & 1, dY row offset (E + PT - U) / 2): u = 0: (1, +1), 1: (0, 0), 2: (1, 0), 3: (0, -1), 4: (1, -1)
+#define XM_DG_TAP(U, E, DI)                                                                          \
+  {                                                                                                  \
+    f32x4 af[3];                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const f32x4 *>(A + 2 * (U) * PLA + i * 128); \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+      const float bf = B[e * PK + (DI)];                                                             \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                  \
+        acc[i][E] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf, acc[i][E], 0, 0, 0);          \
+    }                                                                                                \
+  }
+
+  __syncthreads();   // the zero fill
+  if (nst > 0) {
+    XM_DG_LOAD()
+    XM_DG_STORE(0)
+    __syncthreads();
+    if (1 < nst) XM_DG_LOAD()
+    int cur = 0;
+    for (int s = 0; s < nst; ++s) {
+      if (s + 1 < nst) {
+        XM_DG_STORE(cur ^ 1)
+      }
+      if (s + 2 < nst) XM_DG_LOAD()
+      const float *A = sAr + cur * STG;
+      const float *B = sBr + cur * STG;
+      XM_DG_TAP(1, 0, 0)
+      XM_DG_TAP(0, 1, 1)
+      XM_DG_TAP(3, 0, -1)
+      XM_DG_TAP(2, 1, 0)
+      XM_DG_TAP(4, 1, -1)
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef XM_DG_LOAD
+#undef XM_DG_STORE
+#undef XM_DG_TAP
+  // ---- epilogue: (y = 2 m, 2 m + 1) of one channel = one 8-byte store; 32 lanes = 256 contiguous bytes ----
+  const int x = xa + 2 * wc, m = m0 + 32 * wh + l31;
+  if (x < a.W && 2 * m < a.H) {
+    const bool pair = 2 * m + 1 < a.H;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = bm * kDgS2Rows + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < a.C) {
+          float *dst = a.dX + ((size_t)(n * a.C + c) * a.W + x) * a.H + 2 * m;
+          if (pair) *reinterpret_cast<f32x2 *>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
+          else *dst = acc[i][0][r];
+        }
+      }
+  }
+}
+
 }  // namespace xm

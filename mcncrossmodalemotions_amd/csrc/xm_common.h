@@ -80,6 +80,7 @@ enum Path {
   kPathW8,              // XM_NO_W8              128 x 128 tiles by eight waves of 128 VGPRs (conv.hip kCfgs[7]); off = four waves of 222
   kPathWgradPatch,      // XM_NO_WGRAD_PATCH     filter derivative of 3 x 3 / stride 1 layers from an input patch (conv_wgrad_patch_kernel)
   kPathWgradPatchS2,    // XM_NO_WGRAD_PATCH_S2  filter derivative of 5 x 5 / stride 2 layers from an input patch (conv_wgrad_patch_s2_kernel)
+  kPathDgradS2,         // XM_NO_DGRAD_S2        dgrad of 5 x 5 / stride 2 layers with both row parities per wave (conv_dgrad_s2_kernel)
   kPathCount
 };
 bool path_on(Path p);

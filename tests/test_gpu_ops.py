@@ -202,6 +202,49 @@ def test_conv_wgrad_patch_s2_kernel(gpu, case):
         L.xm_debug_force_wgrad_patch_s2(old)
 
 
+DGRAD_S2_CASES = [  # H, W, C, N, K, pad (t b l r)
+    (126, 13, 96, 2, 16, (1, 1, 1, 1)),     # the student's conv2 rows and channels; columns of both parities, a lone last column
+    (30, 21, 20, 3, 24, (1, 1, 1, 1)),      # 15 row pairs of 64, 20 of 96 channel rows
+    (126, 9, 7, 2, 8, (1, 1, 0, 1)),        # no left padding: the column classes swap
+    (62, 12, 100, 2, 16, (1, 1, 2, 1)),     # 100 channels: two channel blocks; two columns of padding in front
+    (134, 10, 5, 1, 8, (1, 1, 1, 1)),       # 67 row pairs: two row blocks
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_S2_CASES)
+def test_conv_dgrad_s2_kernel(gpu, case):
+    """dgrad of 5 x 5 / stride 2 layers (the student's conv2) through conv_dgrad_s2_kernel -- a wave owns one output column and
+    32 row PAIRS, both row parities accumulate in it and leave as 8-byte stores -- against the oracle, next to the merged
+    stride-parity launch on the same operands; the profiler hooks prove which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, C, N, K, pad = case
+    rng = np.random.default_rng(H * 7 + W * 3 + C + N + K)
+    x, f = rnd(rng, H, W, C, N), rnd(rng, 5, 5, C, K)
+    y = O.vl_nnconv(x, f, None, stride=2, pad=pad)
+    dzdy = rnd(rng, *y.shape)
+    dx_ref, _, _ = O.vl_nnconv(x, f, None, dzdy, stride=2, pad=pad, acc64=True)
+    xd, fd, dd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(dzdy)
+    old = L.xm_debug_force_dgrad_s2(1)
+    try:
+        (dx, _, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, None, dd, stride=2, pad=pad, no_der_filters=True))
+        assert "conv_dgrad_s2_kernel<1>" in names, names
+        close(vl.to_numpy(dx), dx_ref, what="dgrad (5 x 5 / 2), both row parities per wave")
+        L.xm_debug_force_dgrad_s2(0)
+        (dx0, _, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, None, dd, stride=2, pad=pad, no_der_filters=True))
+        assert not any("dgrad_s2" in n for n in names), names
+        close(vl.to_numpy(dx0), dx_ref, what="merged stride-parity dgrad")
+        # the accumulating epilogue (derivative sums at forks) keeps the implicit-GEMM path
+        L.xm_debug_force_dgrad_s2(1)
+        acc = rnd(rng, H, W, C, N)
+        (dx2, _, _), names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, None, dd, stride=2, pad=pad, no_der_filters=True,
+                                                                  dx_accum=vl.from_numpy(acc)))
+        assert not any("dgrad_s2" in n for n in names), names
+        close(vl.to_numpy(dx2), dx_ref + acc, what="dgrad + accum")
+    finally:
+        L.xm_debug_force_dgrad_s2(old)
+
+
 # (H, W, N, K, pad): 7x7 / stride 2 on one channel (the student's first layer)
 STEM_CASES = [(512, 60, 2, 96, (1, 1, 1, 1)), (131, 45, 3, 96, (1, 1, 1, 1)), (64, 33, 2, 64, (3, 3, 3, 3)),
               (40, 41, 2, 33, (0, 0, 0, 0)), (29, 23, 1, 7, (2, 1, 0, 3)), (300, 18, 1, 96, (1, 0, 1, 0))]
