@@ -33,6 +33,18 @@ inline void xm_check(int rc) {
   if (rc != XM_OK) mexErrMsgIdAndTxt("XM:error", "%s", xm_last_error());
 }
 
+/* Once per gateway (the state lives in libxmodal_hip.so, shared by all of them): every gateway issues its operator on
+ * the null stream, one call after the other -- MatConvNet's own sequence (cnn_train_dag -> net.eval -> vl_nn*,
+ * run_distillation.m:170-182) -- so the host declares XM_EXEC_SINGLE_STREAM (include/xmodal.h: kernels that are faster
+ * alone but poor neighbours become candidates; an explicit statement, the library infers nothing from the call history). */
+inline void xm_mex_startup() {
+  static bool done = false;
+  if (done) return;
+  if (xm_version() < 105) mexErrMsgIdAndTxt("XM:version", "libxmodal_hip.so is older than ABI revision 105.");
+  xm_check(xm_set_exec_hint(XM_EXEC_SINGLE_STREAM));
+  done = true;
+}
+
 struct XmTensor {
   const float *ptr = nullptr;  // device address
   int d[4] = {1, 1, 1, 1};
@@ -48,6 +60,7 @@ struct XmCall {
   std::vector<void *> temps;
   bool any_handle = false;
 
+  XmCall() { xm_mex_startup(); }
   ~XmCall() { release(); }
   void release() {
     for (void *p : temps) xm_device_free(p);

@@ -28,6 +28,6 @@ def test_mex_gateways_call_only_exported_symbols():
     for s in glob.glob(os.path.join(ROOT, "mex", "*")):
         if os.path.isfile(s):
             used |= set(re.findall(r"\b(xm_[a-z0-9_]+)\s*\(", open(s).read()))
-    used -= {"xm_check", "xm_intvec", "xm_streq", "xm_ignored_option", "xm_device", "xm_mex"}
+    used -= {"xm_check", "xm_intvec", "xm_streq", "xm_ignored_option", "xm_device", "xm_mex", "xm_mex_startup"}
     missing = sorted(u for u in used if u not in _lib.SIGNATURES)
     assert not missing, missing
