@@ -617,14 +617,16 @@ def main():
     if rank == 0 and world == 1 and want_ns:
         north = north_star_pass()
 
+    # student FLOPs scale with the spectrogram width (16.633 GFLOP at W = 300, 22.33 at the reference's default W = 400)
+    student_gflop = 22.33 if W == 400 else GFLOP["student_fwd_bwd_300"] * (W / 300.0)
     if wl == "distill":
-        gflop_unit = F * GFLOP["%s_fwd" % args.teacher] + GFLOP["student_fwd_bwd_300"] * (W / 300.0 if W != 300 else 1.0)
+        gflop_unit = F * GFLOP["%s_fwd" % args.teacher] + student_gflop
     elif wl == "student":
-        gflop_unit = GFLOP["student_fwd_bwd_300"]
+        gflop_unit = student_gflop
     elif wl == "teacher":
         gflop_unit = GFLOP["senet50_fwd"]
     else:
-        gflop_unit = GFLOP["senet50_fwd_bwd"] + GFLOP["student_fwd_bwd_300"]
+        gflop_unit = GFLOP["senet50_fwd_bwd"] + student_gflop
 
     # proof of N RCCL ranks: ncclCommCount of the communicator the exchange runs on (the library's through
     # xm_comm_count, or torch's nccl group); null when the exchange does not run over RCCL (gloo debug runs, N = 1
