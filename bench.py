@@ -504,7 +504,7 @@ def main():
     # the timed region: exactly K steps between barrier + synchronize on both sides.  Window marks are HIP events
     # recorded on the main stream every K/8 steps (no host synchronisation): min / median / max window rate show
     # the spread inside the region.
-    nwin = 8 if K >= 40 else 1
+    nwin = 8 if K >= 40 else (4 if K >= 16 else 1)   # the driver's --steps 20: four windows of five steps
     marks = []
     barrier()
     t0 = time.perf_counter()
