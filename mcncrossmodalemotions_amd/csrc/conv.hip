@@ -1468,7 +1468,7 @@ static bool dgrad_s2_ok(const Geo &g, const float *dzdy, const float *dxo, const
   if (g.G != 1 || g.FH != 5 || g.FW != 5 || g.sy != 2 || g.sx != 2 || g.dy != 1 || g.dx != 1) return false;
   if (g.pt != 1 || g.pl < 0 || g.pl > 4 || (g.H & 1) || (g.Ho & 1) || (g.K & 7)) return false;
   if ((((uintptr_t)dzdy | (uintptr_t)dxo) & 7) != 0) return false;
-  if ((size_t)g.Ho * g.Wo * g.K * g.N * 4 >= (1ull << 32)) return false;
+  if ((size_t)g.Ho * g.Wo * g.K * g.N * 4 >= (1ull << 31)) return false;   // dY byte offsets are formed in 32-bit arithmetic
   if (g_force_dgrad_s2 == 1) return true;
   // Its blocks are large (two output columns x 64 row pairs x all filters: ~0.4 ms of a CU slot) and there are 37 of them per
   // 126 x 73 sample, so small batches pay the partly filled last round -- 32 spectrograms: 1.54 rounds of 768 slots cost 2
@@ -2026,6 +2026,7 @@ static bool wgrad_patch_ok(const Geo &g, const float *x, const float *dzdy, hipS
   if (g.pt != 1 || g.pb != 1 || g.pl != 1 || g.pr != 1) return false;
   if (g.H != 30 || g.Ho != g.H || g.Wo != g.W) return false;          // instantiated row counts (HH)
   if ((((uintptr_t)x | (uintptr_t)dzdy) & 7) != 0) return false;
+  if ((size_t)g.H * g.W * g.C * g.N * 4 >= (1ull << 31) || (size_t)g.Ho * g.Wo * g.K * g.N * 4 >= (1ull << 31)) return false;
   return (long long)g.N * g.W >= 64;                                    // enough stages to split
 }
 static int launch_wgrad_patch(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int max_splits,
@@ -2074,6 +2075,8 @@ static bool wgrad_patch_s2_ok(const Geo &g, const float *x, const float *dzdy) {
   if (g.pt < 1 || g.pt > 2 || g.pl < 0 || g.pl > 4) return false;
   if ((g.H & 1) || (g.Ho & 1)) return false;                            // 8-byte loads of row pairs
   if ((((uintptr_t)x | (uintptr_t)dzdy) & 7) != 0) return false;
+  // byte offsets are formed in 32-bit arithmetic: both tensors below 2 GiB (904 MB / 585 MB at 256 spectrograms)
+  if ((size_t)g.H * g.W * g.C * g.N * 4 >= (1ull << 31) || (size_t)g.Ho * g.Wo * g.K * g.N * 4 >= (1ull << 31)) return false;
   return (long long)g.N * g.Wo * ((g.Ho + 31) / 32) >= 64;              // enough stages to split
 }
 static int launch_wgrad_patch_s2(const float *x, const float *dzdy, float *dfo, const Geo &g, float *part, int max_splits,
