@@ -18,7 +18,7 @@
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
  *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
- *                  XM_NO_W8, XM_NO_WGRAD_PATCH, XM_NO_WGRAD_PATCH_S2, XM_NO_DGRAD_S2.
+ *                  XM_NO_W8, XM_NO_WGRAD_PATCH, XM_NO_WGRAD_PATCH_S2, XM_NO_DGRAD_S2, XM_NO_STEM3.
  *                  Each chooses between two complete, parity-tested implementations of the same operator (the operator tests
  *                  force both arms through the xm_debug_force_* hooks; tests/test_gpu_path_switches.py runs whole passes
  *                  with every selector set, in fresh processes, against the default; profiles/ holds the A/B lines);
@@ -45,6 +45,8 @@ int xm_debug_num_conv_cfgs(void);
 int xm_debug_force_conv_halo(int on);
 /* 1: the single-channel stem kernel (conv_stem_kernel) wherever it can run; 0: never; -1: measured choice (default) */
 int xm_debug_force_conv_stem(int on);
+/* the same for the three-channel 7 x 7 / stride 2 stem kernel (conv_stem3_kernel: the teachers' first layer) */
+int xm_debug_force_conv_stem3(int on);
 /* 1: the patch kernel for the filter derivative of 3 x 3 / stride 1 / pad 1 layers (conv_wgrad_patch_kernel) wherever it
  * can run; 0: never; -1: measured choice (default) */
 int xm_debug_force_wgrad_patch(int on);

@@ -115,6 +115,7 @@ _DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
           # include/xmodal_prof.h
           "xm_debug_force_conv_halo": [_i],
           "xm_debug_force_conv_stem": [_i],
+          "xm_debug_force_conv_stem3": [_i],
           "xm_debug_force_wgrad_patch": [_i],
           "xm_debug_force_wgrad_patch_s2": [_i],
           "xm_debug_force_dgrad_s2": [_i],

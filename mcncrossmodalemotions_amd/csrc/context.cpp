@@ -13,7 +13,7 @@ bool path_on(Path p) {
   static const char *const kEnv[kPathCount] = {"XM_NO_HYBRID",      "XM_NO_HALO",        "XM_NO_SKINNY",     "XM_NO_SKINNY4",
                                                "XM_NO_STEM",        "XM_NO_STEM_WGRAD",  "XM_NO_DMA",        "XM_NO_FUSED_STATS",
                                                "XM_DGRAD_MERGE",    "XM_NO_FAST_TRANSPOSE", "XM_NO_POOL_LDS", "XM_NO_POOL_PATCH",
-                                               "XM_NO_POOL_POOLED", "XM_NO_W8", "XM_NO_WGRAD_PATCH", "XM_NO_WGRAD_PATCH_S2", "XM_NO_DGRAD_S2"};
+                                               "XM_NO_POOL_POOLED", "XM_NO_W8", "XM_NO_WGRAD_PATCH", "XM_NO_WGRAD_PATCH_S2", "XM_NO_DGRAD_S2", "XM_NO_STEM3"};
   static bool on[kPathCount];
   static bool read = false;
   if (!read) {

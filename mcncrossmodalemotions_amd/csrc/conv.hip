@@ -1225,6 +1225,31 @@ static int launch_stem(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
   return XM_OK;
 }
 
+// ---- three-channel stem (conv_stem3_kernel): 7 x 7 / stride 2 over RGB images, 64 filters -- the teachers' conv1 --------------
+static int g_force_stem3 = -1;   // test hook (xm_debug_force_conv_stem3)
+static bool stem3_ok(const ConvGemmArgs &a, const Geo &g, const float *x, bool stats) {
+  if (!path_on(kPathStem3) || g_force_cfg >= 0 || g_force_splits > 0 || stats) return false;
+  if (g.C != 3 || g.G != 1 || g.FC != 3 || g.FH != 7 || g.FW != 7 || g.sy != 2 || g.sx != 2 || g.dy != 1 || g.dx != 1) return false;
+  if (g.Kg != 64 || !a.vecStore || a.resid || a.gate) return false;
+  if ((g.Ho * g.Wo) % 128 != 0 || g.Ho < 64 || (g.H & 1) || g.pt > 4 || g.pl > 6) return false;
+  if (2 * (g.Ho - 1) + 8 + (4 - g.pt) + 1 > kStem3CS) return false;                 // patch rows of a column
+  if (((uintptr_t)x & 7) != 0 || (size_t)g.H * g.W * g.C * g.N * 4 >= (1ull << 31)) return false;
+  return g_force_stem3 == 1 || (long long)g.Ho * g.Wo * g.N >= 128 * 512;           // >= one round of the chip
+}
+static int launch_stem3(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
+  a.A = f;
+  a.lda = R;
+  a.nbm = 1;
+  a.nbn = a.NP / 128;
+  a.slab = nullptr;
+  const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP;
+  ProfScope ps(12 * 100, 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
+  const int grid = std::min(512, (a.nbn + 7) / 8 * 8);
+  hipLaunchKernelGGL(conv_stem3_kernel, dim3(grid), dim3(256), 0, st, a, a.nbn);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 static int conv_forward(const float *x, const float *f, const float *b, float *y, const Geo &g,
                         const float *scale, const float *shift, const float *resid, int relu,
                         hipStream_t st, float *moments_out = nullptr, float eps = 0.f, const float *gate = nullptr) {
@@ -1381,6 +1406,14 @@ static int conv_forward(const float *x, const float *f, const float *b, float *y
       TuneKey skey{7, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
       const int pick = g_force_stem >= 0 ? g_force_stem : tune_challengers(skey, st, run3, 2, sok, kHaloMargin);
       rc = run3(pick);
+      if (rc) return rc;
+    } else if (stem3_ok(a, g, x, stats_ok)) {
+      // the three-channel stem kernel against the best implicit-GEMM configuration (measured once per shape)
+      auto run5 = [&](int h) { return h ? launch_stem3(a, f, g.R, st) : run(ci); };
+      bool sok[2] = {true, true};
+      TuneKey skey{12, a.M, a.NP, Rp, tmode, g.sy * 16 + g.sx, g.FH * 64 + g.FW, g.H, g.W};
+      const int pick = g_force_stem3 >= 0 ? g_force_stem3 : tune_challengers(skey, st, run5, 2, sok, kHaloMargin);
+      rc = run5(pick);
       if (rc) return rc;
     } else {
     // <= 3 x 3 taps / unit stride: the halo-patch kernel variants against the best implicit-GEMM configuration
@@ -2199,6 +2232,11 @@ int xm_set_exec_hint(unsigned flags) {
 }
 unsigned xm_get_exec_hint(void) { return g_exec_hint; }
 
+int xm_debug_force_conv_stem3(int on) {
+  int old = g_force_stem3;
+  g_force_stem3 = on < 0 ? -1 : (on ? 1 : 0);
+  return old;
+}
 int xm_debug_force_dgrad_s2(int on) {
   int old = g_force_dgrad_s2;
   g_force_dgrad_s2 = on < 0 ? -1 : (on ? 1 : 0);
@@ -2354,6 +2392,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
   }
   if (kind == 10) {
     snprintf(buf, len, "conv_wgrad_patch_s2_kernel<5, 2>");
+    return XM_OK;
+  }
+  if (kind == 12) {
+    snprintf(buf, len, "conv_stem3_kernel");
     return XM_OK;
   }
   if (kind == 11) {

@@ -1172,6 +1172,166 @@ conv_halo_multi_kernel(const ConvGemmMulti m) {
   else conv_halo_body<4, TM, TN, WGM, WGN, PS>(a, smem);
 }
 
+// ---- three-channel stem (round 5): 7 x 7 / stride 2 over 224 x 224 x 3 faces, the teachers' conv1 ---------------------------
+// K = 147: the implicit-GEMM kernel pads it to 160, gathers 147 taps per pixel (dword loads with padding masks) and runs at
+// 72 TFLOP/s (0.84 ms at 256 faces).  Same idea as the stride-2 patch kernels above, for the forward direction: a tile = 128
+// consecutive output pixels of one sample (1 - 3 output columns); the input patch under it -- 3 channels x 11 source columns x
+// 232 rows (source rows -4 ... 227), every element loaded ONCE with 8-byte loads, padding as out-of-range loads -- sits in LDS
+// as [channel][column][row]; tap (u, v, c) of pixel (i, j) is at lane base + (c * 11 + v) * 232 + u with lane base =
+// 2 (j - j0) * 232 + 2 i + 1: ds_read_b32 with immediate offsets, no masks, no VALU.  The filter bank lives in LDS for the whole
+// (persistent) kernel with the filter rows padded to 8 (k' = u + 8 (v + 7 c), u = 7: zero weights -- 168 reduction steps for 147
+// taps): an MFMA step multiplies k' = 2 t (lanes 0-31) and 2 t + 1 (lanes 32-63), i.e. rows u and u + 1 of one filter column,
+// so the two half-waves' patch offsets differ by exactly 1 and everything stays an immediate.  Image [k' / 4][row][4] stored as
+// {4g, 4g + 2, 4g + 1, 4g + 3}: each half-wave reads ITS two weights of a group with one ds_read_b64.
+// One patch buffer (30.6 KB) + the filter image (43 KB): two blocks per CU; the next tile's patch waits in registers (15 8-byte
+// asm loads, issued before the MFMAs) and is parked between two barriers; the epilogue (bias / folded bnorm / relu; row
+// constants loaded once, they are the same for every tile) leaves through asm stores the waits do not count:
+// `s_waitcnt vmcnt(8)` in front of the patch store = the loads are in, this tile's 8 stores may still be in flight.
+constexpr int kStem3NSC = 11, kStem3CS = 232, kStem3G = 42;
+
+__global__ void __launch_bounds__(256, 2)
+conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
+  constexpr int NC = 3, FW = 7, S = 2, NSC = kStem3NSC, CS = kStem3CS, G = kStem3G, PR = CS / 2;
+  constexpr int PATCH = NC * NSC * CS;                     // 7656 floats
+  constexpr int NLD = (NC * NSC * PR + 255) / 256;         // 15 row-pair loads per thread and tile
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float sA[G * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float sP[PATCH + 8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  // the filter bank in MFMA operand order (zero rows / taps where the layer has none)
+  for (int idx = t; idx < G * 64 * 4; idx += 256) {
+    const int q = idx & 3, row = (idx >> 2) & 63, g = idx >> 8;
+    const int kp = 4 * g + ((q & 1) << 1) + (q >> 1), u = kp & 7, vc = kp >> 3, v = vc % FW, c = vc / FW;
+    sA[idx] = (row < a.M && u < a.nU && v < a.nV && c < NC) ? a.A[(size_t)row * a.lda + u + a.nU * (v + a.nV * c)] : 0.f;
+  }
+  for (int i = t; i < (PATCH + 8) / 4; i += 256) reinterpret_cast<f32x4 *>(sP)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int PI = (int)a.divPI.d, PIJ = (int)a.divPIJ.d;   // output rows per column, output pixels per sample
+  const int tps = PIJ / 128;                               // tiles per sample (host: PIJ % 128 == 0)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
+  // XCD-contiguous tile ranges (as conv_stem_kernel): XCD x walks tiles [x * per, (x + 1) * per)
+  const int per = (ntiles + 7) >> 3, tbase = (blockIdx.x & 7) * per, tstep = gridDim.x >> 3;
+  const int tend = min(per, ntiles - tbase);
+
+  // ---- patch staging map (fixed for the whole kernel): thread -> (channel, patch column, row pair) ----
+  unsigned voP[NLD];
+  int ldP[NLD], scP[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int idx = t + 256 * j;
+    const int c = idx / (NSC * PR), rem = idx - c * (NSC * PR), sc = rem / PR, pr = rem - sc * PR;
+    const int row = 2 * pr - 4;                            // source row of the pair's first element
+    const bool ok = idx < NC * NSC * PR && (unsigned)row < (unsigned)a.LimH;   // (LimH even: a pair is in or out as a whole)
+    voP[j] = ok ? (unsigned)(((c * a.LimW + sc) * a.LimH + row) * 4) : 0xFFFFFFFFu;   // + sample and first source column below
+    scP[j] = ok ? sc : -(1 << 20);
+    ldP[j] = idx < NC * NSC * PR ? (c * NSC + sc) * CS + 2 * pr : PATCH;
+  }
+  // ---- epilogue constants of the rows this lane stores after the in-quad transpose (the same for every tile) ----
+  const int iq = l31 & 3;
+  float rmul[2][4], radd[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int rowc = min(32 * i + 8 * g4 + 4 * half + iq, a.M - 1);
+      const float m_ = a.scale ? a.scale[rowc] : 1.f;
+      float t_ = a.scale ? a.shift[rowc] : 0.f;
+      if (a.bias) t_ += a.bias[rowc] * m_;
+      rmul[i][g4] = m_;
+      radd[i][g4] = t_;
+    }
+
+  f32x2 ld[NLD];
+  auto issue_loads = [&](int tile) {
+    const int n = tile / tps, q0 = (tile - n * tps) * 128, j0 = q0 / PI;
+    const int c0 = S * j0 + a.gw0;                         // source column of patch column 0 (gw0 = - left padding)
+    const unsigned base = (unsigned)((n * a.xSampleStride + c0 * a.LimH) * 4);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const unsigned off = (unsigned)(c0 + scP[j]) < (unsigned)a.LimW ? voP[j] + base : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(ld[j]) : "v"(off), "s"(xrsrc) : "memory");
+    }
+  };
+  auto park_patch = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) *reinterpret_cast<f32x2 *>(sP + ldP[j]) = ld[j];
+  };
+#define XM_S3_WAIT(N)                                                                                         \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                      \
+               : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[5]), "+v"(ld[6]), "+v"(ld[7]), \
+                 "+v"(ld[8]), "+v"(ld[9]), "+v"(ld[10]), "+v"(ld[11]), "+v"(ld[12]), "+v"(ld[13]), "+v"(ld[14])  \
+               :                                                                                              \
+               : "memory")
+  static_assert(NLD == 15, "XM_S3_WAIT lists the load registers");
+
+  int q = blockIdx.x >> 3;
+  __syncthreads();                                         // filter image and zero fill
+  if (q < tend) {
+    issue_loads(tbase + q);
+    XM_S3_WAIT(0);
+    park_patch();
+  }
+  __syncthreads();
+  const float *pA = sA + (l31 * 4 + 2 * half);             // + 32 rows per row tile, + 256 floats per group
+  for (; q < tend; q += tstep) {
+    const int tile = tbase + q;
+    const bool more = q + tstep < tend;
+    if (more) issue_loads(tile + tstep);
+    // this lane's pixel
+    const int n = tile / tps, q0 = (tile - n * tps) * 128, j0 = q0 / PI;
+    const int qq = q0 + 32 * wave + l31, jj = qq / PI, ii = qq - jj * PI;
+    const float *pB = sP + (S * (jj - j0)) * CS + S * ii + (4 + a.gh0) + half;   // gh0 = - top padding; patch row 0 = source row -4
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      // group g: k' = 4 g ... 4 g + 3 = filter rows u0 ... u0 + 3 of filter column vc = g / 2, u0 = 4 (g & 1)
+      const int vc = g >> 1, u0 = 4 * (g & 1), v = vc % FW, c = vc / FW;
+      f32x2 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x2 *>(pA + g * 256 + i * 128);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float bf = pB[(c * NSC + v) * CS + u0 + 2 * e];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf, acc[i], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: y = act(acc * scale + (bias * scale + shift)), 16-byte stores through the in-quad transpose ----
+    float *yb = a.Y + (size_t)n * a.oSampleStride + (qq - iq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int row = 32 * i + 8 * g4 + 4 * half + iq;
+        float v4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v4[k] = acc[i][4 * g4 + k];
+        quad_transpose4(v4, iq);
+        f32x4 o = {v4[0] * rmul[i][g4] + radd[i][g4], v4[1] * rmul[i][g4] + radd[i][g4],
+                   v4[2] * rmul[i][g4] + radd[i][g4], v4[3] * rmul[i][g4] + radd[i][g4]};
+        if (a.relu) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        xm_st16<true>(yb + (size_t)row * a.oChanStride, o);   // (host: exactly 64 filters, so every lane issues its 8 stores)
+      }
+    __syncthreads();                                       // every wave has read its taps: the patch may be replaced
+    if (more) {
+      XM_S3_WAIT(8);                                       // the next patch is in; this tile's 8 stores may still be in flight
+      park_patch();
+    }
+    __syncthreads();
+  }
+#undef XM_S3_WAIT
+}
+
+
 // ---- single-channel stem (the student's conv1: 7 x 7 taps, stride 2, 1 -> 96 channels over 512 x W spectrograms) ----
 // K = 49 and a 462 MB output at 32 spectrograms: the layer is bounded by its stores (0.09 ms at the write rate this
 // store pattern reaches; tools/store_mfma_probe.hip: 0.107 ms with the MFMAs next to them), the generic kernel needs

@@ -81,6 +81,7 @@ enum Path {
   kPathWgradPatch,      // XM_NO_WGRAD_PATCH     filter derivative of 3 x 3 / stride 1 layers from an input patch (conv_wgrad_patch_kernel)
   kPathWgradPatchS2,    // XM_NO_WGRAD_PATCH_S2  filter derivative of 5 x 5 / stride 2 layers from an input patch (conv_wgrad_patch_s2_kernel)
   kPathDgradS2,         // XM_NO_DGRAD_S2        dgrad of 5 x 5 / stride 2 layers with both row parities per wave (conv_dgrad_s2_kernel)
+  kPathStem3,           // XM_NO_STEM3           three-channel 7 x 7 / stride 2 stem kernel (conv_stem3_kernel: the teachers' conv1)
   kPathCount
 };
 bool path_on(Path p);

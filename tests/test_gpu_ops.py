@@ -1213,3 +1213,40 @@ def test_lds_dma_conv_configs(gpu, geom):
     finally:
         L.xm_debug_force_conv_cfg(-1)
         L.xm_debug_force_conv_splits(0)
+
+
+@pytest.mark.parametrize("case", [(224, 224, 2, (3, 3, 3, 3)), (134, 256, 1, (3, 3, 3, 3)), (224, 224, 1, (3, 2, 2, 3))])
+def test_conv_stem3_kernel(gpu, case):
+    """The teachers' first layer (7 x 7 / stride 2 over three channels, 64 filters) through conv_stem3_kernel -- the input patch
+    of a 128-pixel tile staged once in LDS, the 147 taps read from it with immediate offsets, filter rows padded to 8 --
+    against the oracle: plain (bias) and with the folded bnorm + relu epilogue of the frozen teacher, next to the
+    implicit-GEMM kernel on the same operands; the profiler hooks prove which kernel ran."""
+    from mcncrossmodalemotions_amd import vl, _lib
+    L = _lib.load()
+    H, W, N, pad = case
+    K = 64
+    rng = np.random.default_rng(H + W + N)
+    x, f, b = rnd(rng, H, W, 3, N), O.F(rng.standard_normal((7, 7, 3, K)) * 0.1), rnd(rng, K)
+    sc, sh = O.F(rng.uniform(0.5, 1.5, K)), rnd(rng, K)
+    y_ref = O.vl_nnconv(x, f, b, stride=2, pad=pad, acc64=True)
+    yf_ref = np.maximum(y_ref * sc.reshape(1, 1, K, 1) + sh.reshape(1, 1, K, 1), 0)
+    xd, fd, bd = vl.from_numpy(x), vl.from_numpy(f), vl.from_numpy(b.reshape(K, 1))
+    scd, shd = vl.from_numpy(sc.reshape(K, 1)), vl.from_numpy(sh.reshape(K, 1))
+    old = L.xm_debug_force_conv_stem3(1)
+    try:
+        y, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad))
+        assert "conv_stem3_kernel" in names, names
+        close(vl.to_numpy(y), y_ref, what="stem3 fwd")
+        yf, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad, scale=scd, shift=shd, relu=True))
+        assert "conv_stem3_kernel" in names, names
+        close(vl.to_numpy(yf), yf_ref, what="stem3 fwd + folded bnorm + relu")
+        L.xm_debug_force_conv_stem3(0)
+        y0, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad))
+        assert "conv_stem3_kernel" not in names, names
+        close(vl.to_numpy(y0), y_ref, what="implicit GEMM")
+        # 63 filters, or a pixel count that is not a multiple of 128 per sample, keep the implicit GEMM
+        L.xm_debug_force_conv_stem3(1)
+        _, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, vl.from_numpy(f[..., :63].copy(order="F")), None, stride=2, pad=pad))
+        assert "conv_stem3_kernel" not in names, names
+    finally:
+        L.xm_debug_force_conv_stem3(old)
