@@ -55,6 +55,7 @@ priority / variant A/Bs of rounds 3-4 -- `r03/schedule_experiments.txt`, `r04/sc
 | `{R}/bench_distill_gpus2_gloo0.json` | `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it: the command starts its two ranks itself (both on this box's one GPU, exchange over gloo: a functional run of the N > 1 path; `n_gpus` 2, `world` {g2.get('world')}, `rccl_ranks` {g2.get('rccl_ranks')} -- no RCCL communicator carried that exchange --, `control_group` {g2.get('control_group')}; the throughput means nothing) |
 | `{R}/wgrad_patch_s2_bench.txt` | round 5 (own gpurun calls, commit `736abaa`): conv2's filter derivative, generic kernel against `conv_wgrad_patch_s2_kernel<5, 2>` (DESIGN.md 2.1h) at 32 / 64 / 256 spectrograms, and the steps with the old kernels / + this kernel / + the 3 x 3 patch kernel from 4096 output columns; one stream against two at batch 256 |
 | `{R}/dgrad_s2_bench.txt` | round 5 (own gpurun call, commit `37160fb` before the launch-size rule): conv2's dgrad, merged stride-parity launch against `conv_dgrad_s2_kernel` forced at every batch (DESIGN.md 2.1i) |
+| `{R}/stem3_bench.txt` | round 5 (own gpurun calls, AFTER the collection: commit `abf5347`): the teachers' conv1 through the implicit GEMM and through `conv_stem3_kernel` (DESIGN.md 2.1k) at 32 / 128 / 256 faces, the steps with and without it, the kernel without its stores, with a start offset between the two blocks of a CU |
 | `{R}/dma_kernel_dissection.txt` | round 5 (own gpurun call, timing-only builds on `213741a`): per-layer table of the SE-ResNet50 at 256 faces, every tile configuration on the three 1 x 1 shapes, `conv_gemm_dma_kernel` without its A loads / B loads / epilogue / MFMAs, grid and ring variants; per-layer table of the student at 256 (DESIGN.md 2.1j) |
 | `{R}/deferred_stores_and_halo64.txt` | round 5 (own gpurun call; built, parity-green, measured, not kept): the LDS-DMA kernel with its epilogue stores spread over the next tile, a 64-row halo-patch variant for the res2 3 x 3 layers, and the steps with both (DESIGN.md 2.1j) |
 | `{R}/pmc_summary_senet50_b256.txt`, `pmc_traffic_senet50_b256.json` | round 5: the three PMC passes on north_star's batch: `conv_dgrad_s2_kernel` WRITE {tb['xm::conv_dgrad_s2_kernel<1>']['write_bytes']/1e6:.0f} MB per launch for 904 MB of dX (the merged launch: 2.1 x), `conv_wgrad_patch_s2_kernel` FETCH x 2 {tb['xm::conv_wgrad_patch_s2_kernel<5, 2>']['fetch_bytes_x2']/1e6:.0f} MB for 1489 MB of x + dY (the generic kernel: 4.2 x) |
@@ -106,7 +107,9 @@ from 6 rounds of blocks), the 3 x 3 patch filter derivative also for launches of
 stream {sh1['ms_per_step']} ms against {se256['ms_per_step']} ms on two, and a kernel's own gain arrives 1 : 1; at 32 pairs the two-stream step is work-conserving and the side
 stream's kernels are off the critical path ({ds['ms_per_step']} ms on one stream -> {d['ms_per_step']} ms overlapped), which is why the default line moved by less than the
 boxes differ.  What was measured and NOT kept (DESIGN.md 2.1j): deferred epilogue stores in the LDS-DMA kernel, a 64-row halo variant, fewer
-persistent DMA blocks per CU, a lower eight-wave threshold, register-double-buffered fragments in the patch kernel.
+persistent DMA blocks per CU, a lower eight-wave threshold, register-double-buffered fragments in the patch kernel, a finer decomposition of the
+dgrad kernel.  Added after the collection (commit `abf5347`, `stem3_bench.txt`): `conv_stem3_kernel` for the teachers' first layer (72-75 -> 82-84 TFLOP/s
+at 256 faces; north_star step - 0.1 ms) and the tuning-table entries that select it.
 `cpu_baseline`: the OpenMP team is now sized by min(affinity, cgroup CPU quota) -- {c['cores']} threads under a quota of {c.get('quota')} cores on this box:
 {c['value']} pairs/s, min {c.get('min')} / max {c.get('max')} (round 4: 128 threads under the same quota, 1.5 ... 3.6 pairs/s from box to box).
 
