@@ -1243,9 +1243,15 @@ static int launch_stem3(ConvGemmArgs a, const float *f, int R, hipStream_t st) {
   a.nbn = a.NP / 128;
   a.slab = nullptr;
   const double abytes = (double)a.xBytes + 4.0 * a.M * a.Rtrue + 4.0 * a.M * (double)a.NP;
-  ProfScope ps(12 * 100, 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
+  // 256-pixel block tiles (four accumulator chains per wave) where they divide a sample and span <= 4 output columns
+  static const bool wide_on = env_int("XM_STEM3_WIDE", 1) != 0;
+  const int pij = (int)a.divPIJ.d, pi = (int)a.divPI.d;
+  const bool wide = wide_on && pij % 256 == 0 && pi >= 86;
+  if (wide) a.nbn = a.NP / 256;
+  ProfScope ps(12 * 100 + (wide ? 1 : 0), 2.0 * a.M * (double)a.NP * a.Rtrue, st, abytes);
   const int grid = std::min(512, (a.nbn + 7) / 8 * 8);
-  hipLaunchKernelGGL(conv_stem3_kernel, dim3(grid), dim3(256), 0, st, a, a.nbn);
+  if (wide) hipLaunchKernelGGL(conv_stem3_kernel<2>, dim3(grid), dim3(256), 0, st, a, a.nbn);
+  else hipLaunchKernelGGL(conv_stem3_kernel<1>, dim3(grid), dim3(256), 0, st, a, a.nbn);
   XM_LAUNCH_CHECK();
   return XM_OK;
 }
@@ -2395,7 +2401,7 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     return XM_OK;
   }
   if (kind == 12) {
-    snprintf(buf, len, "conv_stem3_kernel");
+    snprintf(buf, len, key % 100 ? "conv_stem3_kernel<2>" : "conv_stem3_kernel<1>");
     return XM_OK;
   }
   if (kind == 11) {

@@ -1187,13 +1187,16 @@ conv_halo_multi_kernel(const ConvGemmMulti m) {
 // asm loads, issued before the MFMAs) and is parked between two barriers; the epilogue (bias / folded bnorm / relu; row
 // constants loaded once, they are the same for every tile) leaves through asm stores the waits do not count:
 // `s_waitcnt vmcnt(8)` in front of the patch store = the loads are in, this tile's 8 stores may still be in flight.
-constexpr int kStem3NSC = 11, kStem3CS = 232, kStem3G = 42;
+constexpr int kStem3CS = 232, kStem3G = 42;
 
+// TN = 32-pixel tiles per wave: 1 (128-pixel block tiles, 11 source columns) or 2 (256 pixels, 13 columns: FOUR independent
+// accumulator chains per wave instead of two)
+template <int TN>
 __global__ void __launch_bounds__(256, 2)
 conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
-  constexpr int NC = 3, FW = 7, S = 2, NSC = kStem3NSC, CS = kStem3CS, G = kStem3G, PR = CS / 2;
+  constexpr int NC = 3, FW = 7, S = 2, NSC = TN == 1 ? 11 : 13, CS = kStem3CS, G = kStem3G, PR = CS / 2, BP = 128 * TN;
   constexpr int PATCH = NC * NSC * CS;                     // 7656 floats
-  constexpr int NLD = (NC * NSC * PR + 255) / 256;         // 15 row-pair loads per thread and tile
+  constexpr int NLD = (NC * NSC * PR + 255) / 256;         // 15 / 18 row-pair loads per thread and tile
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float sA[G * 64 * 4];
   __shared__ __attribute__((aligned(16))) float sP[PATCH + 8];
@@ -1207,7 +1210,7 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
   for (int i = t; i < (PATCH + 8) / 4; i += 256) reinterpret_cast<f32x4 *>(sP)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int PI = (int)a.divPI.d, PIJ = (int)a.divPIJ.d;   // output rows per column, output pixels per sample
-  const int tps = PIJ / 128;                               // tiles per sample (host: PIJ % 128 == 0)
+  const int tps = PIJ / BP;                                // tiles per sample (host: PIJ % BP == 0)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, a.xBytes, 0x00020000);
   // XCD-contiguous tile ranges (as conv_stem_kernel): XCD x walks tiles [x * per, (x + 1) * per)
   const int per = (ntiles + 7) >> 3, tbase = (blockIdx.x & 7) * per, tstep = gridDim.x >> 3;
@@ -1243,7 +1246,7 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
 
   f32x2 ld[NLD];
   auto issue_loads = [&](int tile) {
-    const int n = tile / tps, q0 = (tile - n * tps) * 128, j0 = q0 / PI;
+    const int n = tile / tps, q0 = (tile - n * tps) * BP, j0 = q0 / PI;
     const int c0 = S * j0 + a.gw0;                         // source column of patch column 0 (gw0 = - left padding)
     const unsigned base = (unsigned)((n * a.xSampleStride + c0 * a.LimH) * 4);
 #pragma unroll
@@ -1256,19 +1259,24 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) *reinterpret_cast<f32x2 *>(sP + ldP[j]) = ld[j];
   };
+  // (an operand must not be listed twice: the tail of the list is its own statement for the wider tile)
 #define XM_S3_WAIT(N)                                                                                         \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                      \
-               : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[5]), "+v"(ld[6]), "+v"(ld[7]), \
-                 "+v"(ld[8]), "+v"(ld[9]), "+v"(ld[10]), "+v"(ld[11]), "+v"(ld[12]), "+v"(ld[13]), "+v"(ld[14])  \
-               :                                                                                              \
-               : "memory")
-  static_assert(NLD == 15, "XM_S3_WAIT lists the load registers");
+  {                                                                                                           \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                    \
+                 : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[5]), "+v"(ld[6]), "+v"(ld[7]), \
+                   "+v"(ld[8]), "+v"(ld[9]), "+v"(ld[10]), "+v"(ld[11]), "+v"(ld[12]), "+v"(ld[13]), "+v"(ld[14]) \
+                 :                                                                                            \
+                 : "memory");                                                                                 \
+    if (NLD > 15)                                                                                             \
+      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ld[NLD - 3]), "+v"(ld[NLD - 2]), "+v"(ld[NLD - 1]) : : "memory"); \
+  }
+  static_assert(NLD == 15 || NLD == 18, "XM_S3_WAIT lists the load registers");
 
   int q = blockIdx.x >> 3;
   __syncthreads();                                         // filter image and zero fill
   if (q < tend) {
     issue_loads(tbase + q);
-    XM_S3_WAIT(0);
+    XM_S3_WAIT(0)
     park_patch();
   }
   __syncthreads();
@@ -1278,14 +1286,22 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
     const bool more = q + tstep < tend;
     if (more) issue_loads(tile + tstep);
     // this lane's pixel
-    const int n = tile / tps, q0 = (tile - n * tps) * 128, j0 = q0 / PI;
-    const int qq = q0 + 32 * wave + l31, jj = qq / PI, ii = qq - jj * PI;
-    const float *pB = sP + (S * (jj - j0)) * CS + S * ii + (4 + a.gh0) + half;   // gh0 = - top padding; patch row 0 = source row -4
-    f32x16 acc[2];
+    const int n = tile / tps, q0 = (tile - n * tps) * BP, j0 = q0 / PI;
+    int qq[TN];
+    const float *pB[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      qq[j] = q0 + 32 * (wave * TN + j) + l31;
+      const int jj = qq[j] / PI, ii = qq[j] - jj * PI;
+      pB[j] = sP + (S * (jj - j0)) * CS + S * ii + (4 + a.gh0) + half;   // gh0 = - top padding; patch row 0 = source row -4
+    }
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       // group g: k' = 4 g ... 4 g + 3 = filter rows u0 ... u0 + 3 of filter column vc = g / 2, u0 = 4 (g & 1)
@@ -1295,13 +1311,19 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
       for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x2 *>(pA + g * 256 + i * 128);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float bf = pB[(c * NSC + v) * CS + u0 + 2 * e];
+        float bf[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf, acc[i], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) bf[j] = pB[j][(c * NSC + v) * CS + u0 + 2 * e];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);
       }
     }
     // ---- epilogue: y = act(acc * scale + (bias * scale + shift)), 16-byte stores through the in-quad transpose ----
-    float *yb = a.Y + (size_t)n * a.oSampleStride + (qq - iq);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+    float *yb = a.Y + (size_t)n * a.oSampleStride + (qq[j] - iq);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1309,7 +1331,7 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
         const int row = 32 * i + 8 * g4 + 4 * half + iq;
         float v4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v4[k] = acc[i][4 * g4 + k];
+        for (int k = 0; k < 4; ++k) v4[k] = acc[i][j][4 * g4 + k];
         quad_transpose4(v4, iq);
         f32x4 o = {v4[0] * rmul[i][g4] + radd[i][g4], v4[1] * rmul[i][g4] + radd[i][g4],
                    v4[2] * rmul[i][g4] + radd[i][g4], v4[3] * rmul[i][g4] + radd[i][g4]};
@@ -1319,11 +1341,16 @@ conv_stem3_kernel(const ConvGemmArgs a, const int ntiles) {
           o.z = fmaxf(o.z, 0.f);
           o.w = fmaxf(o.w, 0.f);
         }
-        xm_st16<true>(yb + (size_t)row * a.oChanStride, o);   // (host: exactly 64 filters, so every lane issues its 8 stores)
+        xm_st16<true>(yb + (size_t)row * a.oChanStride, o);   // (host: exactly 64 filters, so every lane issues its 8 TN stores)
       }
+    }
     __syncthreads();                                       // every wave has read its taps: the patch may be replaced
     if (more) {
-      XM_S3_WAIT(8);                                       // the next patch is in; this tile's 8 stores may still be in flight
+      if (TN == 1) {
+        XM_S3_WAIT(8);                                     // the next patch is in; this tile's 8 TN stores may still be in flight
+      } else {
+        XM_S3_WAIT(16);
+      }
       park_patch();
     }
     __syncthreads();

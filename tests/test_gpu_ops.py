@@ -1235,18 +1235,18 @@ def test_conv_stem3_kernel(gpu, case):
     old = L.xm_debug_force_conv_stem3(1)
     try:
         y, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad))
-        assert "conv_stem3_kernel" in names, names
+        assert any(n.startswith("conv_stem3_kernel") for n in names), names
         close(vl.to_numpy(y), y_ref, what="stem3 fwd")
         yf, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad, scale=scd, shift=shd, relu=True))
-        assert "conv_stem3_kernel" in names, names
+        assert any(n.startswith("conv_stem3_kernel") for n in names), names
         close(vl.to_numpy(yf), yf_ref, what="stem3 fwd + folded bnorm + relu")
         L.xm_debug_force_conv_stem3(0)
         y0, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, fd, bd, stride=2, pad=pad))
-        assert "conv_stem3_kernel" not in names, names
+        assert not any(n.startswith("conv_stem3_kernel") for n in names), names
         close(vl.to_numpy(y0), y_ref, what="implicit GEMM")
         # 63 filters, or a pixel count that is not a multiple of 128 per sample, keep the implicit GEMM
         L.xm_debug_force_conv_stem3(1)
         _, names = _kernels_run(L, lambda: vl.vl_nnconv(xd, vl.from_numpy(f[..., :63].copy(order="F")), None, stride=2, pad=pad))
-        assert "conv_stem3_kernel" not in names, names
+        assert not any(n.startswith("conv_stem3_kernel") for n in names), names
     finally:
         L.xm_debug_force_conv_stem3(old)
