@@ -13,7 +13,7 @@
  *                  is a candidate is the host's xm_set_exec_hint(XM_EXEC_SINGLE_STREAM), not an environment setting)
  *                  XM_WGRAD_PATCH_MIN_STAGES (conv_wgrad_patch_kernel without the one-stream hint: launches of at least this
  *                  many output columns, default 4096), XM_DGRAD_S2_MIN_BLOCKS (conv_dgrad_s2_kernel: launches of at least this
- *                  many blocks, default 6 x 768)
+ *                  many blocks, default 6 x 768), XM_STEM3_WIDE=0 (conv_stem3_kernel with 128- instead of 256-pixel block tiles)
  *   workspace log  XM_WS_VERBOSE
  *   kernel-path selectors (csrc/xm_common.h `enum Path`, read in ONE place, csrc/context.cpp): XM_NO_HYBRID, XM_NO_HALO,
  *                  XM_NO_SKINNY, XM_NO_SKINNY4, XM_NO_STEM, XM_NO_STEM_WGRAD, XM_NO_DMA, XM_NO_FUSED_STATS,
