@@ -446,7 +446,7 @@ def physical_core_cpus():
     return sorted(first.values()) or sorted(allowed)
 
 
-def cpu_quota():
+def cpu_quota(root="/sys/fs/cgroup"):
     """CPU bandwidth limit of this process' cgroup in cores (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us),
     or None when there is none.  A team of more threads than the quota pays for is throttled by the kernel for part
     of every period -- pinned threads then stall in turn and a timed baseline swings by 2-3 x between boxes."""
@@ -455,13 +455,13 @@ def cpu_quota():
             return open(path).read().split()
         except OSError:
             return None
-    v = read("/sys/fs/cgroup/cpu.max")
+    v = read(root + "/cpu.max")
     if v and len(v) == 2 and v[0] != "max":
         try:
             return float(v[0]) / float(v[1])
         except ValueError:
             return None
-    for d in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+    for d in (root + "/cpu", root + "/cpu,cpuacct"):
         q, per = read(d + "/cpu.cfs_quota_us"), read(d + "/cpu.cfs_period_us")
         if q and per:
             try:

@@ -367,3 +367,23 @@ def test_resample_restatement_vs_scipy():
         yt = O.resample(tone, p, q)
         want = np.sin(2 * np.pi * 0.05 * np.arange(yt.size) * q / p)
         assert np.abs(yt - want)[200:-200].max() < 2e-3, speed
+
+
+def test_cpu_quota_reads_cgroup_v2_and_v1(tmp_path):
+    """bench.py's cpu_baseline sizes its OpenMP team by min(affinity, cgroup CPU quota) (round-4 review: 128 pinned threads
+    under a 16-core quota swung 2.4 x between boxes): cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`."""
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert O.cpu_quota(str(v2)) == 16.0
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert O.cpu_quota(str(v2)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert O.cpu_quota(str(v1)) == 2.5
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert O.cpu_quota(str(v1)) is None
+    assert O.cpu_quota(str(tmp_path / "nothing")) is None
+    assert 1 <= len(O.baseline_cpus()) <= len(O.physical_core_cpus())
