@@ -35,6 +35,13 @@ def lib():
         _lib.orc_aud_samples.restype = C.c_double
         _lib.orc_aud_samples.argtypes = [C.c_int, C.c_double, C.c_double]
         _lib.orc_time2idx.argtypes = [C.c_double]
+        # OpenMP's default team is one thread per LOGICAL cpu of the host (256 on the GPU boxes) whatever the container may
+        # use: under the boxes' 16-core cgroup quota such a team is throttled for most of every period.  One thread per
+        # physical core, no more than the quota pays for (see cpu_quota); set_num_threads() overrides.
+        try:
+            _lib.orc_set_num_threads(max(1, len(baseline_cpus())))
+        except Exception:   # noqa: BLE001 -- an unreadable /proc or /sys must not break the checker
+            pass
     return _lib
 
 
@@ -483,7 +490,7 @@ def baseline_cpus():
 
 
 def set_num_threads(n=None):
-    lib().orc_set_num_threads(int(n or physical_cores()))
+    lib().orc_set_num_threads(int(n or len(baseline_cpus())))
     return num_threads()
 
 
