@@ -47,7 +47,7 @@ priority / variant A/Bs of rounds 3-4 -- `r03/schedule_experiments.txt`, `r04/sc
 | `{R}/bench_distill_senet50_n1.json` | the reference's default teacher (`run_distillation.m:82`): `--teacher senet50`, one face per pair |
 | `{R}/bench_distill_senet50_b256_n1.json`, `bench_distill_b256_n1.json` | north_star's batch 256 on ONE GPU (`--per-gpu-batch 256`), SE-ResNet-50 / ResNet-50 teacher |
 | `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
-| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only) |
+| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only); re-taken in its own gpurun call at `c0d2e5a`+ after the oracle's default OpenMP team became min(physical cores, cgroup quota) for every use ({c1['value']} img/s on {c1['cpu_baseline']['cores']} threads; the collection's line, 256 threads under the 16-core quota: 10.0) |
 | `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
 | `{R}/bench_distill_torch_1rank.json`, `bench_distill_capi_late_init.json` | the same single-rank run through `torch.distributed` ({tor1['value']} pairs/s), and with the library's communicator created AFTER the networks (`XM_PS_LATE=1`: {late['value']} pairs/s -- the call-order trap of `include/xmodal.h`) |
 | `{R}/bench_student_w400_n1.json`, `bench_distill_senet50_w400_n1.json` | round 5: the reference's REAL default shape -- `numSeconds = 4`, 512 x 400 spectrograms (`run_distillation.m:74`): student at batch 64 ({w400['value']} samples/s = {pct(w400['value'] * 22.33 / 1e3 / 157.3)} of peak at 22.33 GFLOP per sample; the line's own fraction field still used the W = 300 FLOPs, fixed after the collection) and the SE-ResNet50 distillation step ({dw400['value']} pairs/s) |
