@@ -48,7 +48,7 @@ enum { XM_FUSE_RELU = 1, XM_BN_BATCH_MOMENTS = 2, XM_FUSE_SIGMOID = 4 };
 
 /* ABI revision: 100 = round 1; 101 = xm_nnbnorm_relu_pool_backward gained `y_pool`, exchange entry points return
  * XM_EINVAL without a communicator; 102 = + xm_nnconv_forward_moments, xm_nnbnorm_backward_dxsum, xm_nnconv_forward_gated;
- * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply, xm_se_squeeze_bn, xm_scale_axpy_bn; 105 = + xm_set_exec_hint / xm_get_exec_hint (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
+ * 103 = + xm_nnpool_global_avg_backward_accum; 104 = + xm_nnconv_backward_filter_bnrelupool, xm_nndropout_forward / _apply, xm_resample, xm_se_tail_backward_reduce / _apply, xm_se_squeeze_bn, xm_scale_axpy_bn; 105 = + xm_set_exec_hint / xm_get_exec_hint; 106 = + xm_nnconv_bnorm_relu_pool_forward, xm_stem_gram, xm_stem_gram_moments, xm_nnconv_backward_filter_bnrelupool_gram (additions never change the revision's meaning for older bindings).  A binding checks xm_version() >= the revision it was written against. */
 int xm_version(void);
 const char *xm_last_error(void);
 /* Device memory for hosts that have no device-array type of their own (MATLAB's gpuArray is CUDA-only: on an
@@ -172,6 +172,45 @@ int xm_nnconv_backward_filter_bnrelupool(const float *x, int H, int W, int C, in
                                          int ppr, const unsigned char *argmax, const float *y_pool,
                                          const float *dzdy_pool, float *dzdf_out, float *dzdb_out, float *dg_out,
                                          float *db_out, void *stream);
+/* Extension (ABI revision 106): the same derivatives WITHOUT a pass over the convolution's output.  A single-channel
+ * first layer is Y[m][p] = sum_t F~[m][t] P~[p][t] over the im2col patches P~ of X (+ a column of ones for the bias), so
+ * everything vl_nnbnorm's train-mode derivative needs from Y is a contraction with the (FH FW + 1)^2 Gram matrix
+ * G = P~' P~ of the INPUT (xm_stem_gram, fp64 [64][64], row-major; row / column t = u + FH v, t = FH FW: the ones):
+ *     A = DZ P~ (DZ: the pooled derivative routed through `argmax`, masked by y_pool > 0; built on chip),
+ *     DG = (F~.A - mu A[:, ones]) / sigma, DB = A[:, ones],
+ *     [DZDF, DZDB] = g/sigma (A - DB/P G[ones, :] - DG/(sigma P) ((F~ G) - mu G[ones, :]))          (train)
+ * with [mu, sigma] = `moments` (the forward call's).  F and B (may be NULL) take Y's place in the argument list; `gram`
+ * NULL = computed here; y_pool NULL = the table marks closed windows itself (code 255).  Same routing / ReLU decisions as the composition; the sums are another summation order
+ * (fp32 MFMA chains per wave, fp64 across waves and in the closed form).  xm_stem_gram_moments gives the batch moments
+ * of Y from G (mean = F~ G[:, ones] / P, E[y^2] = F~ G F~' / P; fp64), i.e. vl_nnbnorm's MOMENTS output for Y without Y.
+ * XM_ENOTSUP outside: one input channel, <= 96 filters, 16 ... 63 taps in <= 8 x 7, stride 1 / 2, size(X,1) % 4 == 0,
+ * 3 x 3 / stride-2 unpadded max pooling with >= 4 window rows. */
+/* Extension (106): Y_POOL, ARGMAX, MOMENTS of
+ *     vl_nnpool(vl_nnrelu(vl_nnbnorm(vl_nnconv(X, F, B), G, BB, 'epsilon', e)), [3 3], 'stride', 2, 'method', 'max')
+ * for a single-channel first layer (7 x 7 / stride 2, K % 8 == 0) in ONE kernel: the convolution's output -- 3.7 GB at 256
+ * spectrograms -- is never written.  Train mode (moments_in NULL): `gram` (caller-owned fp64 [64][64]) receives
+ * xm_stem_gram(X), the batch moments come from it (xm_stem_gram_moments) before the kernel starts, and MOMENTS_OUT is
+ * vl_nnbnorm's third output; test mode: moments_in as given.  The normalisation is folded into the MFMA operand
+ * (g/sigma F, constant term on a spare reduction index), i.e. another rounding order than bnorm(conv(x)): 1e-6 relative.
+ * ARGMAX: code = dh + 3 dw of the FIRST maximum in column-major scan order, or 255 where the window's maximum did not
+ * pass the ReLU (y_pool == 0; the derivative of such a window is zero wherever it is routed) -- the form
+ * xm_nnconv_backward_filter_bnrelupool_gram(..., y_pool = NULL, ...) takes. */
+int xm_nnconv_bnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW, int FC,
+                                      int K, const float *bias, int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx,
+                                      const float *bn_g, const float *bn_b, float epsilon, const float *moments_in, int ph,
+                                      int pw, int psy, int psx, int ppt, int ppb, int ppl, int ppr, double *gram,
+                                      float *y_pool, unsigned char *argmax, float *moments_out, void *stream);
+int xm_stem_gram(const float *x, int H, int W, int N, int FH, int FW, int sy, int sx, int pt, int pb, int pl, int pr,
+                 double *gram, void *stream);
+int xm_stem_gram_moments(const double *gram, const float *f, const float *b, int FH, int FW, int K, float epsilon,
+                         float *moments_out, void *stream);
+int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                                              int FC, int K, const float *bias, int sy, int sx, int pt, int pb, int pl,
+                                              int pr, int dy, int dx, const float *bn_g, const float *moments, int train,
+                                              int ph, int pw, int psy, int psx, int ppt, int ppb, int ppl, int ppr,
+                                              const unsigned char *argmax, const float *y_pool, const float *dzdy_pool,
+                                              const double *gram, float *df_out, float *dbias_out, float *dg_out,
+                                              float *db_out, void *stream);
 
 /* ---- vl_nnpool  (matlab/vl_nnpool.m; pool6 resized at emoVoxZoo.m:256-269) ------------------
  * Y = vl_nnpool(X, [ph pw], 'stride', .., 'pad', .., 'method', 'max'|'avg') */

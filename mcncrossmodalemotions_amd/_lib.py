@@ -52,6 +52,12 @@ SIGNATURES = {
     "xm_nnconv_prepare_backward": [_i] * 4 + [c_fp] + [_i] * 12 + [_vp],
     "xm_nnconv_backward_filter_bnrelupool": [c_fp] + [_i] * 16 + [c_fp, c_fp, c_fp, c_fp] + [_i] * 9 +
                                             [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_stem_gram": [c_fp] + [_i] * 11 + [_vp, _vp],
+    "xm_stem_gram_moments": [_vp, c_fp, c_fp, _i, _i, _i, _f, c_fp, _vp],
+    "xm_nnconv_backward_filter_bnrelupool_gram": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp] + [_i] * 8 +
+                                                 [c_fp, c_fp] + [_i] * 9 + [c_fp, c_fp, c_fp, _vp, c_fp, c_fp, c_fp, c_fp, _vp],
+    "xm_nnconv_bnorm_relu_pool_forward": [c_fp] + [_i] * 4 + [c_fp] + [_i] * 4 + [c_fp] + [_i] * 8 + [c_fp, c_fp, _f, c_fp] +
+                                         [_i] * 8 + [_vp, c_fp, c_fp, c_fp, _vp],
     "xm_params_changed": [],
     "xm_nnpool_forward": [c_fp] + [_i] * 13 + [c_fp, _vp],
     "xm_nnpool_backward": [c_fp] + [_i] * 13 + [c_fp, c_fp, _vp],

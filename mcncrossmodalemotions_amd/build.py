@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 TAG = os.environ.get("XM_BUILD_TAG", "")
 OUT = os.path.join(HERE, "libxmodal_hip%s.so" % ("_" + TAG if TAG else ""))
 SOURCES = ["context.cpp", "conv.hip", "norm_pool.hip", "misc.hip", "comm.cpp"]
-HEADERS = ["xm_common.h", "conv_kernels.h", os.path.join("..", "..", "include", "xmodal.h")]
+HEADERS = ["xm_common.h", "conv_kernels.h", "stem_pool_kernels.h", os.path.join("..", "..", "include", "xmodal.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("XM_DEBUG_CYCLES"):   # per-block clock trace in the conv kernels (tools/conv_bench.py --cycles)
     FLAGS.append("-DXM_DEBUG_CYCLES")

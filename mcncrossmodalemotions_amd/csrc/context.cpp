@@ -98,7 +98,7 @@ const void *cached_device_table(const void *host, size_t bytes) {
 
 extern "C" {
 
-int xm_version(void) { return 105; }   // 101: xm_nnbnorm_relu_pool_backward takes y_pool (round 2 signature)
+int xm_version(void) { return 106; }   // 101: xm_nnbnorm_relu_pool_backward takes y_pool (round 2 signature)
 const char *xm_last_error(void) { return xm::err_buf(); }
 
 int xm_workspace_reserve(size_t bytes) {

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "conv_kernels.h"
+#include "stem_pool_kernels.h"
 
 namespace xm {
 
@@ -2213,6 +2214,66 @@ static int conv_wgrad(const float *x, const float *dzdy, float *dfo, const Geo &
   return run(ci);
 }
 
+// ---- conv1 -> bnorm -> relu -> pool through the Gram matrix of the input patches (stem_pool_kernels.h) -------------------
+static bool stem_pool_ok(const Geo &g, const float *x) {
+  if (!path_on(kPathStem)) return false;
+  if (g.C != 1 || g.G != 1 || g.FC != 1 || g.dy != 1 || g.dx != 1) return false;
+  if (g.FH > 8 || g.FW > kStemNV || g.FH * g.FW < 16 || g.FH * g.FW > 63 || g.Kg > 96) return false;
+  if ((g.sy != 1 && g.sy != 2) || g.sx + g.FW > kSpNC) return false;      // two output columns sit on <= 9 source columns
+  if (g.H % 4 != 0 || g.H > kStemHP - 8 || ((uintptr_t)x & 15) != 0) return false;
+  if (g.pt > 4 || 4 * ((g.sy * (g.Ho - 1) - g.pt + 4 + 7) >> 2) + 3 >= kStemHP) return false;
+  return g.Ho >= 32;
+}
+
+static int stem_pool_units(const Geo &g) { return g.N * ((g.Wo + 1) / 2) * ((g.Ho + 255) / 256); }
+static void stem_pool_args(StemPoolArgs &a, const float *x, const Geo &g) {
+  a.X = x;
+  a.M = g.Kg;
+  a.R = g.R;
+  a.nU = g.FH;
+  a.nV = g.FW;
+  a.PI = g.Ho;
+  a.PJ = g.Wo;
+  const int G = (g.Ho + 255) / 256;
+  a.divJG = make_fastdiv((uint32_t)(((g.Wo + 1) / 2) * G));
+  a.divG = make_fastdiv((uint32_t)G);
+  a.gsx = g.sx;
+  a.gh0 = -g.pt;
+  a.gw0 = -g.pl;
+  a.LimH = g.H;
+  a.LimW = g.W;
+  a.xSampleStride = g.H * g.W;
+}
+
+static int stem_pool_grid(int nunits, int occ) { return std::min(256 * occ, (nunits + 7) / 8 * 8); }
+static size_t stem_gram_need(const Geo &g) {
+  return WsCarver::need((size_t)stem_pool_grid(stem_pool_units(g), 3) * 64 * 64, 4);
+}
+
+// G (fp64 [64][64]) of the patches of x; scratch from the caller's carver
+static int launch_stem_gram(WsCarver &ws, const float *x, const Geo &g, double *gram, hipStream_t st) {
+  StemPoolArgs a{};
+  stem_pool_args(a, x, g);
+  const int nunits = stem_pool_units(g), grid = stem_pool_grid(nunits, 3);
+  a.part = ws.take<float>((size_t)grid * 64 * 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    XM_HIP(hipFuncSetAttribute((const void *)stem_gram_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpGramSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)stem_gram_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpGramSmem));
+    attr_done = true;
+  }
+  {
+    // three of the four 32 x 32 tiles of the padded 64 x 64 product are computed
+    ProfScope ps(13 * 100, 2.0 * (g.R + 1) * (g.R + 1) * (double)g.Ho * g.Wo * g.N, st, 4.0 * g.H * g.W * g.N);
+    if (g.sy == 2) hipLaunchKernelGGL(stem_gram_kernel<2>, dim3(grid), dim3(256), kSpGramSmem, st, a, nunits);
+    else hipLaunchKernelGGL(stem_gram_kernel<1>, dim3(grid), dim3(256), kSpGramSmem, st, a, nunits);
+  }
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(stem_gram_reduce_kernel, dim3(64), dim3(1024), 0, st, a.part, gram, grid);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -2408,6 +2469,10 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     snprintf(buf, len, "conv_dgrad_s2_kernel<1>");
     return XM_OK;
   }
+  if (kind == 13 || kind == 14 || kind == 15) {
+    snprintf(buf, len, kind == 13 ? "stem_gram_kernel<2>" : kind == 14 ? "conv_stem_wgrad_pool_kernel<2>" : "conv_stem_bnpool_fwd_kernel");
+    return XM_OK;
+  }
   if (kind == 5 || kind == 6) {
     snprintf(buf, len, kind == 5 ? "conv_stem_kernel<2>" : (key % 100 ? "conv_stem_wgrad_bnp_kernel<2, 2>" : "conv_stem_wgrad_kernel<2>"));
     return XM_OK;
@@ -2535,6 +2600,162 @@ int xm_nnconv_backward_filter_bnrelupool(const float *x, int H, int W, int C, in
   if (rc) return rc;
   StemBnp bnp{dzdy_pool, argmax, rowc, pHo, pWo, dbias_out};
   return launch_stem_wgrad(x, y, df_out, g, spart, grid, st, &bnp);
+}
+
+// G = P~' P~ of the im2col patches (+ a column of ones) of a single-channel first-layer convolution: fp64 [64][64],
+// row / column t = u + FH v (t < FH FW), t = FH FW: the ones column; entries beyond are zero.
+int xm_stem_gram(const float *x, int H, int W, int N, int FH, int FW, int sy, int sx, int pt, int pb, int pl, int pr,
+                 double *gram, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, 1, N, FH, FW, 1, 1, sy, sx, pt, pb, pl, pr, 1, 1);
+  if (rc) return rc;
+  if (!x || !gram) return fail(XM_EINVAL, "xm_stem_gram: NULL tensor");
+  if (!stem_pool_ok(g, x)) return fail(XM_ENOTSUP, "xm_stem_gram: geometry not covered");
+  hipStream_t st = (hipStream_t)stream;
+  WsCarver ws;
+  rc = ws.init(stem_gram_need(g), st);
+  if (rc) return rc;
+  return launch_stem_gram(ws, x, g, gram, st);
+}
+
+// Batch moments [mean, sqrt(var + eps)] of Y = vl_nnconv(X, F, B) for a single-channel first layer, from G alone
+int xm_stem_gram_moments(const double *gram, const float *f, const float *b, int FH, int FW, int K, float epsilon,
+                         float *moments_out, void *stream) {
+  if (!gram || !f || !moments_out) return fail(XM_EINVAL, "xm_stem_gram_moments: NULL tensor");
+  if (FH * FW < 1 || FH * FW > 63 || K < 1) return fail(XM_EINVAL, "xm_stem_gram_moments: bad shape");
+  hipLaunchKernelGGL(stem_gram_moments_kernel, dim3(K), dim3(64), 0, (hipStream_t)stream, gram, f, b, K, FH * FW,
+                     (double)epsilon, moments_out);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+// Y_POOL, ARGMAX, MOMENTS of vl_nnpool(vl_nnrelu(vl_nnbnorm(vl_nnconv(X, F, B), G, BB)), [3 3], 'stride', 2) for a
+// single-channel first layer in one kernel (conv_stem_bnpool_fwd_kernel): the convolution's output is never written.
+// Train mode (moments_in NULL): G = xm_stem_gram(X) is left in `gram` (fp64 [64][64], caller-owned: the backward call
+// takes it) and the batch moments come from it.  The table marks windows whose maximum did not pass the ReLU with 255.
+int xm_nnconv_bnorm_relu_pool_forward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW, int FC,
+                                      int K, const float *bias, int sy, int sx, int pt, int pb, int pl, int pr, int dy, int dx,
+                                      const float *bn_g, const float *bn_b, float epsilon, const float *moments_in, int ph,
+                                      int pw, int psy, int psx, int ppt, int ppb, int ppl, int ppr, double *gram,
+                                      float *y_pool, unsigned char *argmax, float *moments_out, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!x || !f || !bn_g || !bn_b || !y_pool || !argmax || (!moments_in && (!gram || !moments_out)))
+    return fail(XM_EINVAL, "vl_nnconv + bnorm + relu + pool (fused forward): NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int pHo = out_size(g.Ho, ppt, ppb, ph, 1, psy), pWo = out_size(g.Wo, ppl, ppr, pw, 1, psx);
+  const long long pooled = (long long)pHo * pWo * g.K * g.N;
+  const bool ok = stem_pool_ok(g, x) && g.K == g.Kg && g.sy == 2 && g.sx == 2 && g.FH <= 7 && g.FW == kStemNV && g.K % 8 == 0 &&
+                  ph == 3 && pw == 3 && psy == 2 && psx == 2 && ppt == 0 && ppb == 0 && ppl == 0 && ppr == 0 && pHo >= 1 &&
+                  pWo >= 1 && pooled < (1LL << 30) && g_force_stem != 0 && (((uintptr_t)y_pool) & 3) == 0;
+  if (!ok)
+    return fail(XM_ENOTSUP, "vl_nnconv + bnorm + relu + pool (fused forward): geometry not covered by the fused kernel");
+  const float *moments = moments_in;
+  if (!moments_in) {
+    WsCarver ws;
+    rc = ws.init(stem_gram_need(g), st);
+    if (rc) return rc;
+    rc = launch_stem_gram(ws, x, g, gram, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stem_gram_moments_kernel, dim3(g.K), dim3(64), 0, st, gram, f, bias, g.K, g.R, (double)epsilon,
+                       moments_out);
+    XM_LAUNCH_CHECK();
+    moments = moments_out;
+  }
+  StemFwdArgs a{};
+  a.X = x, a.F = f, a.bias = bias, a.bn_g = bn_g, a.bn_b = bn_b, a.moments = moments;
+  a.Y = y_pool, a.amax = argmax;
+  a.M = g.K, a.R = g.R, a.nU = g.FH, a.nV = g.FW;
+  a.PI = g.Ho, a.PJ = g.Wo, a.pHo = pHo, a.pWo = pWo;
+  a.NS = (pHo + 62) / 63;
+  const int slots = 256 * XM_SF_OCC * 4;
+  a.SG = std::max(1, std::min(std::min(16, pWo), (slots + g.N * a.NS * 3 - 1) / (g.N * a.NS * 3)));
+  a.nunits = g.N * a.NS * a.SG * 3;
+  a.div3 = make_fastdiv(3u), a.divSG = make_fastdiv((uint32_t)a.SG), a.divNS = make_fastdiv((uint32_t)a.NS);
+  a.gh0 = -g.pt, a.gw0 = -g.pl, a.LimH = g.H, a.LimW = g.W, a.xSampleStride = g.H * g.W;
+  a.yBytes = (unsigned)(pooled * 4), a.amBytes = (unsigned)pooled;
+  static bool attr_done = false;
+  if (!attr_done) {
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_bnpool_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSfSmem));
+    attr_done = true;
+  }
+  const int grid = std::min(256 * XM_SF_OCC, (a.nunits + 3) / 4);
+  {
+    ProfScope ps(15 * 100, 2.0 * g.K * (double)g.Ho * g.Wo * g.N * g.R, st, 4.0 * g.H * g.W * g.N + 5.0 * (double)pooled);
+    hipLaunchKernelGGL(conv_stem_bnpool_fwd_kernel, dim3(grid), dim3(256), kSfSmem, st, a);
+  }
+  XM_LAUNCH_CHECK();
+  return XM_OK;
+}
+
+// xm_nnconv_backward_filter_bnrelupool without a pass over the convolution's output (stem_pool_kernels.h): the
+// filter bank F (and bias B) take Y's place; `gram` = xm_stem_gram of X (NULL: computed here).
+int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,
+                                              int FC, int K, const float *bias, int sy, int sx, int pt, int pb, int pl,
+                                              int pr, int dy, int dx, const float *bn_g, const float *moments, int train,
+                                              int ph, int pw, int psy, int psx, int ppt, int ppb, int ppl, int ppr,
+                                              const unsigned char *argmax, const float *y_pool, const float *dzdy_pool,
+                                              const double *gram, float *df_out, float *dbias_out, float *dg_out,
+                                              float *db_out, void *stream) {
+  Geo g;
+  int rc = make_geo(g, H, W, C, N, FH, FW, FC, K, sy, sx, pt, pb, pl, pr, dy, dx);
+  if (rc) return rc;
+  if (!x || !f || !bn_g || !moments || !argmax || !dzdy_pool || !df_out)
+    return fail(XM_EINVAL, "vl_nnconv(filter derivative through bnorm+relu+pool, gram): NULL tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int pHo = out_size(g.Ho, ppt, ppb, ph, 1, psy), pWo = out_size(g.Wo, ppl, ppr, pw, 1, psx);
+  const long long pooled = (long long)pHo * pWo * g.K * g.N;
+  const bool ok = stem_pool_ok(g, x) && g.K == g.Kg && ph == 3 && pw == 3 && psy == 2 && psx == 2 && ppt == 0 && ppb == 0 &&
+                  ppl == 0 && ppr == 0 && pHo >= 4 && pWo >= 1 && pooled < (1LL << 30) && g_force_stem != 0 &&
+                  ((((uintptr_t)dzdy_pool | (uintptr_t)y_pool) & 3) == 0);   // (y_pool NULL: the table marks closed windows itself)
+  if (!ok)
+    return fail(XM_ENOTSUP, "vl_nnconv(filter derivative through bnorm+relu+pool, gram): geometry not covered by the fused kernel");
+  StemPoolArgs a{};
+  stem_pool_args(a, x, g);
+  const int nunits = stem_pool_units(g), grid = stem_pool_grid(nunits, 2);
+  WsCarver ws;
+  rc = ws.init(WsCarver::need((size_t)grid * 96 * 64, 4) + WsCarver::need(64 * 64, 8) + stem_gram_need(g), st);
+  if (rc) return rc;
+  a.part = ws.take<float>((size_t)grid * 96 * 64);
+  double *gr = ws.take<double>(64 * 64);
+  if (train && !gram) {
+    rc = launch_stem_gram(ws, x, g, gr, st);
+    if (rc) return rc;
+    gram = gr;
+  }
+  a.dP = dzdy_pool;
+  a.yP = y_pool ? y_pool : dzdy_pool;
+  a.amax = argmax;
+  a.pHo = pHo;
+  a.pWo = pWo;
+  a.dpBytes = (unsigned)(pooled * 4);
+  a.amBytes = (unsigned)pooled;
+  a.dbg = (int)env_int("XM_SP_DBG", 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
+    attr_done = true;
+  }
+  {
+    const double abytes = 4.0 * g.H * g.W * g.N + (y_pool ? 9.0 : 5.0) * (double)pooled + 4.0 * a.M * a.R;
+    ProfScope ps(14 * 100, 2.0 * a.M * (double)g.Ho * g.Wo * g.N * a.R, st, abytes);
+#define XM_SPW_LAUNCH(SY_, G_) hipLaunchKernelGGL((conv_stem_wgrad_pool_kernel<SY_, G_>), dim3(grid), dim3(256), kSpSmem, st, a, nunits)
+    if (g.sy == 2) {
+      if (y_pool) XM_SPW_LAUNCH(2, true); else XM_SPW_LAUNCH(2, false);
+    } else {
+      if (y_pool) XM_SPW_LAUNCH(1, true); else XM_SPW_LAUNCH(1, false);
+    }
+#undef XM_SPW_LAUNCH
+  }
+  XM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(stem_pool_finalize_kernel, dim3(g.K), dim3(256), 0, st, a.part, grid, gram, f, bias, bn_g, moments, g.K,
+                     g.R, train ? 1 : 0, df_out, dbias_out, dg_out, db_out);
+  XM_LAUNCH_CHECK();
+  return XM_OK;
 }
 
 int xm_nnconv_backward(const float *x, int H, int W, int C, int N, const float *f, int FH, int FW,

@@ -476,6 +476,8 @@ class DagNN:
         # first-layer Conv -> BatchNorm -> ReLU -> Pooling: the bnorm's DZDX is rebuilt inside the convolution's
         # filter-derivative kernel instead of being written and read back (vl.conv_backward_filter_bnrelupool)
         self.fuseStemBackward = os.environ.get("XM_NO_FUSED_STEM_BWD") is None
+        # ... and without reading the convolution's output either (vl.conv_backward_filter_bnrelupool_gram, round 6)
+        self.fuseStemGram = os.environ.get("XM_NO_STEM_GRAM") is None
         self.fuseForkSums = os.environ.get("XM_NO_FORK_SUMS") is None   # global-avg backward adds the fork's other derivative
         self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
         # training plans: relu mask + excite + squeeze + bnorm backward of an SE block's tail in two fused calls
@@ -1184,10 +1186,19 @@ class _BnReluPoolStep(_Step):
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
-            res = vl.conv_backward_filter_bnrelupool(
-                xin, blk.size, x, g, b, moments, am, out.value, out.der, pb.poolSize, stride=blk.stride, pad=blk.pad,
-                dilate=blk.dilate, pool_stride=pb.stride, pool_pad=pb.pad, train=not test, df_out=cdo[0],
-                dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1], has_bias=blk.hasBias)
+            res = None
+            if net.fuseStemGram:
+                # round 6: no pass over the convolution's output at all (the Gram matrix of the input patches)
+                cpar = cs._params(net)
+                res = vl.conv_backward_filter_bnrelupool_gram(
+                    xin, cpar[0], cpar[1] if blk.hasBias else None, g, moments, am, out.value, out.der, pb.poolSize,
+                    stride=blk.stride, pad=blk.pad, dilate=blk.dilate, pool_stride=pb.stride, pool_pad=pb.pad,
+                    train=not test, df_out=cdo[0], dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1])
+            if res is None:
+                res = vl.conv_backward_filter_bnrelupool(
+                    xin, blk.size, x, g, b, moments, am, out.value, out.der, pb.poolSize, stride=blk.stride, pad=blk.pad,
+                    dilate=blk.dilate, pool_stride=pb.stride, pool_pad=pb.pad, train=not test, df_out=cdo[0],
+                    dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1], has_bias=blk.hasBias)
             if res is not None and net.gradHook is not None:
                 if side is None and net._side_pending:
                     main.wait_stream(net.wgradStream)

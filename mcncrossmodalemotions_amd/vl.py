@@ -424,6 +424,103 @@ def conv_backward_filter_bnrelupool(x, filter_shape, y, g, b, moments, argmax, y
     return df, dbias, dg, db
 
 
+def stem_gram(x, filter_shape, stride=1, pad=0):
+    """Extension (xm_stem_gram): fp64 [64][64] Gram matrix of the im2col patches (+ ones) of a single-channel first
+    layer; None when the geometry is not covered."""
+    x = _chk(x, "X")
+    H, W, Cc, N = _shape4(x)
+    FH, FW = int(filter_shape[0]), int(filter_shape[1])
+    sy, sx = _pair(stride, "STRIDE")
+    pt, pb, pl, pr = _pad4(pad)
+    if Cc != 1:
+        return None
+    gram = torch.empty(64 * 64, dtype=torch.float64, device=x.device)
+    rc = _L().xm_stem_gram(_ptr(x), H, W, N, FH, FW, sy, sx, pt, pb, pl, pr, C.c_void_p(gram.data_ptr()), _stream())
+    if rc == XM_ENOTSUP:
+        return None
+    _lib.check(rc)
+    return gram
+
+
+def stem_gram_moments(gram, f, b, epsilon=1e-4, moments_out=None):
+    """Extension (xm_stem_gram_moments): vl_nnbnorm's MOMENTS of Y = vl_nnconv(X, F, B) from the Gram matrix of X."""
+    f = _chk(f, "F")
+    FH, FW, FC, K = _shape4(f)
+    mo = moments_out if moments_out is not None else mat_empty(K, 2, device=f.device)
+    _lib.check(_L().xm_stem_gram_moments(C.c_void_p(gram.data_ptr()), _ptr(f), _ptr(None if b is None else _chk(b, "B")),
+                                         FH, FW, K, float(epsilon), _ptr(mo), _stream()))
+    return mo
+
+
+def conv_bnorm_relu_pool(x, f, bias, g, b, pool, stride=1, pad=0, dilate=1, pool_stride=1, pool_pad=0, epsilon=1e-4,
+                         moments=None, moments_out=None, gram=None):
+    """Extension (xm_nnconv_bnorm_relu_pool_forward): vl_nnpool(vl_nnrelu(vl_nnbnorm(vl_nnconv(x, f, bias), g, b))) for a
+    single-channel first layer in one kernel -- the convolution's output is never written.  Returns
+    (y_pool, argmax_table, moments, gram) or None when the shapes are not covered.  `moments` given = test mode (no Gram
+    matrix); the table marks closed windows with 255 (include/xmodal.h)."""
+    x, f, g, b = _chk(x, "X"), _chk(f, "F"), _chk(g, "G"), _chk(b, "B")
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = _shape4(f)
+    sy, sx = _pair(stride, "STRIDE")
+    dy, dx = _pair(dilate, "DILATE")
+    pt, pb, pl, pr = _pad4(pad)
+    ph, pw = _pair(pool, "POOL")
+    psy, psx = _pair(pool_stride, "STRIDE")
+    ppt, ppb, ppl, ppr = _pad4(pool_pad)
+    L = _L()
+    Ho, Wo = L.xm_out_size(H, pt, pb, FH, dy, sy), L.xm_out_size(W, pl, pr, FW, dx, sx)
+    pHo, pWo = L.xm_out_size(Ho, ppt, ppb, ph, 1, psy), L.xm_out_size(Wo, ppl, ppr, pw, 1, psx)
+    if Ho <= 0 or Wo <= 0 or pHo <= 0 or pWo <= 0:
+        return None
+    y = mat_empty(pHo, pWo, K, N, device=x.device)
+    am = torch.empty(pHo * pWo * K * N, dtype=torch.uint8, device=x.device)
+    mi = None if moments is None else _chk(moments, "MOMENTS")
+    mo = None
+    if mi is None:
+        mo = moments_out if moments_out is not None else mat_empty(K, 2, device=x.device)
+        if gram is None:
+            gram = torch.empty(64 * 64, dtype=torch.float64, device=x.device)
+    rc = L.xm_nnconv_bnorm_relu_pool_forward(
+        _ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, None if bias is None else _ptr(_chk(bias, "B")), sy, sx, pt, pb, pl, pr,
+        dy, dx, _ptr(g), _ptr(b), float(epsilon), _ptr(mi), ph, pw, psy, psx, ppt, ppb, ppl, ppr,
+        None if gram is None else C.c_void_p(gram.data_ptr()), _ptr(y), C.c_void_p(am.data_ptr()), _ptr(mo), _stream())
+    if rc == XM_ENOTSUP:
+        return None
+    _lib.check(rc)
+    return y, am, (mi if mo is None else mo), gram
+
+
+def conv_backward_filter_bnrelupool_gram(x, f, bias, g, moments, argmax, y_pool, dzdy, pool, stride=1, pad=0, dilate=1,
+                                         pool_stride=1, pool_pad=0, train=True, gram=None, df_out=None, dbias_out=None,
+                                         dg_out=None, db_out=None):
+    """Extension (xm_nnconv_backward_filter_bnrelupool_gram): conv_backward_filter_bnrelupool without the convolution's
+    output -- F / B take its place, the bnorm's sums and the normalisation's correction terms come from the Gram matrix of
+    the input patches (include/xmodal.h).  Returns (df, dbias, dg, db) or None when the shapes are not covered."""
+    x, f, g, dzdy = _chk(x, "X"), _chk(f, "F"), _chk(g, "G"), _chk(dzdy, "DZDY")
+    H, W, Cc, N = _shape4(x)
+    FH, FW, FC, K = _shape4(f)
+    sy, sx = _pair(stride, "STRIDE")
+    dy, dx = _pair(dilate, "DILATE")
+    pt, pb, pl, pr = _pad4(pad)
+    ph, pw = _pair(pool, "POOL")
+    psy, psx = _pair(pool_stride, "STRIDE")
+    ppt, ppb, ppl, ppr = _pad4(pool_pad)
+    has_bias = bias is not None
+    df = df_out if df_out is not None else mat_empty(FH, FW, FC, K, device=x.device)
+    dbias = (dbias_out if dbias_out is not None else mat_empty(K, 1, device=x.device)) if has_bias else None
+    dg = dg_out if dg_out is not None else mat_empty(K, 1, device=x.device)
+    db = db_out if db_out is not None else mat_empty(K, 1, device=x.device)
+    rc = _L().xm_nnconv_backward_filter_bnrelupool_gram(
+        _ptr(x), H, W, Cc, N, _ptr(f), FH, FW, FC, K, _ptr(_chk(bias, "B")) if has_bias else None, sy, sx, pt, pb, pl, pr,
+        dy, dx, _ptr(g), _ptr(_chk(moments, "MOMENTS")), 1 if train else 0, ph, pw, psy, psx, ppt, ppb, ppl, ppr,
+        C.c_void_p(argmax.data_ptr()), None if y_pool is None else _ptr(_chk(y_pool, "Y_POOL")), _ptr(dzdy),
+        None if gram is None else C.c_void_p(gram.data_ptr()), _ptr(df), _ptr(dbias), _ptr(dg), _ptr(db), _stream())
+    if rc == XM_ENOTSUP:
+        return None
+    _lib.check(rc)
+    return df, dbias, dg, db
+
+
 # --------------------------------------------------------------------------------------------
 # elementwise
 # --------------------------------------------------------------------------------------------

@@ -48,8 +48,30 @@ def fused():
                                               pool_stride=2, pool_pad=0) is not None
 
 
+def gram_only():
+    return vl.stem_gram(x_in, (7, 7), stride=2, pad=1)
+
+
+def fused_gram():
+    assert vl.conv_backward_filter_bnrelupool_gram(x_in, f, bias, g, mo, am, yp, dzp, [3, 3], stride=2, pad=1, pool_stride=2,
+                                                   pool_pad=0) is not None
+
+
+gm = gram_only()
+
+
+def fused_gram_given():
+    assert vl.conv_backward_filter_bnrelupool_gram(x_in, f, bias, g, mo, am, yp, dzp, [3, 3], stride=2, pad=1, pool_stride=2,
+                                                   pool_pad=0, gram=gm) is not None
+
+
+if os.environ.get("ONLY_GRAM"):
+    print("N=%d dbg=%s: Gram %.1f us, pool kernel + finalize with G given %.1f us" % (N, os.environ.get("XM_SP_DBG", "0"), t(gram_only), t(fused_gram_given)))
+    sys.exit(0)
 ta = t(apply_only)
 tw = t(wgrad_only)
 tf = t(fused)
 print("conv1 backward chain at %d spectrograms (DX %.0f MB): bnorm+relu+pool backward %.1f us + filter derivative %.1f us "
       "= %.1f us;  fused (DX never written) %.1f us" % (N, y.numel() * 4 / 1e6, ta, tw, ta + tw, tf))
+tg, tfg, tfgg = t(gram_only), t(fused_gram), t(fused_gram_given)
+print("  Gram route (conv1's output not read): Gram matrix %.1f us, whole call %.1f us, with G given %.1f us" % (tg, tfg, tfgg))
