@@ -2470,7 +2470,7 @@ int xm_prof_kernel_name(int key, char *buf, int len) {
     return XM_OK;
   }
   if (kind == 13 || kind == 14 || kind == 15) {
-    snprintf(buf, len, kind == 13 ? "stem_gram_kernel<2>" : kind == 14 ? "conv_stem_wgrad_pool_kernel<2>" : "conv_stem_bnpool_fwd_kernel");
+    snprintf(buf, len, kind == 13 ? "stem_gram_kernel<2>" : kind == 14 ? (key % 100 ? "conv_stem_wgrad_pool_kernel<2, true>" : "conv_stem_wgrad_pool_kernel<2, false>") : "conv_stem_bnpool_fwd_kernel");
     return XM_OK;
   }
   if (kind == 5 || kind == 6) {
@@ -2713,11 +2713,18 @@ int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int 
     return fail(XM_ENOTSUP, "vl_nnconv(filter derivative through bnorm+relu+pool, gram): geometry not covered by the fused kernel");
   StemPoolArgs a{};
   stem_pool_args(a, x, g);
-  const int nunits = stem_pool_units(g), grid = stem_pool_grid(nunits, 2);
+  // wave units (sample, column pair, 64-row chunk pair) x 3 row tiles of filters; grid: whole XCD rows of blocks whose
+  // waves split evenly over the row tiles (a multiple of 24 blocks), two blocks per CU
+  const int ncp = (g.Ho + 63) / 64, npair = (g.Wo + 1) / 2;
+  const int nunits = g.N * npair * ncp;
+  a.divJG = make_fastdiv((uint32_t)npair);
+  a.divG = make_fastdiv((uint32_t)ncp);
+  const int grid = std::min(504, ((nunits * 3 + 3) / 4 + 23) / 24 * 24);      // two blocks per CU, 63 per XCD
+  const int nwc = grid * 4 / 3;
   WsCarver ws;
-  rc = ws.init(WsCarver::need((size_t)grid * 96 * 64, 4) + WsCarver::need(64 * 64, 8) + stem_gram_need(g), st);
+  rc = ws.init(WsCarver::need((size_t)grid * 4 * 32 * 64, 4) + WsCarver::need(64 * 64, 8) + stem_gram_need(g), st);
   if (rc) return rc;
-  a.part = ws.take<float>((size_t)grid * 96 * 64);
+  a.part = ws.take<float>((size_t)grid * 4 * 32 * 64);
   double *gr = ws.take<double>(64 * 64);
   if (train && !gram) {
     rc = launch_stem_gram(ws, x, g, gr, st);
@@ -2731,19 +2738,18 @@ int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int 
   a.pWo = pWo;
   a.dpBytes = (unsigned)(pooled * 4);
   a.amBytes = (unsigned)pooled;
-  a.dbg = (int)env_int("XM_SP_DBG", 0);
   static bool attr_done = false;
   if (!attr_done) {
-    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
-    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
-    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
-    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSpSmem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSp3Smem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSp3Smem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSp3Smem));
+    XM_HIP(hipFuncSetAttribute((const void *)conv_stem_wgrad_pool_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSp3Smem));
     attr_done = true;
   }
   {
     const double abytes = 4.0 * g.H * g.W * g.N + (y_pool ? 9.0 : 5.0) * (double)pooled + 4.0 * a.M * a.R;
-    ProfScope ps(14 * 100, 2.0 * a.M * (double)g.Ho * g.Wo * g.N * a.R, st, abytes);
-#define XM_SPW_LAUNCH(SY_, G_) hipLaunchKernelGGL((conv_stem_wgrad_pool_kernel<SY_, G_>), dim3(grid), dim3(256), kSpSmem, st, a, nunits)
+    ProfScope ps(14 * 100 + (y_pool ? 1 : 0), 2.0 * a.M * (double)g.Ho * g.Wo * g.N * a.R, st, abytes);
+#define XM_SPW_LAUNCH(SY_, G_) hipLaunchKernelGGL((conv_stem_wgrad_pool_kernel<SY_, G_>), dim3(grid), dim3(256), kSp3Smem, st, a, nunits)
     if (g.sy == 2) {
       if (y_pool) XM_SPW_LAUNCH(2, true); else XM_SPW_LAUNCH(2, false);
     } else {
@@ -2752,7 +2758,7 @@ int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int 
 #undef XM_SPW_LAUNCH
   }
   XM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stem_pool_finalize_kernel, dim3(g.K), dim3(256), 0, st, a.part, grid, gram, f, bias, bn_g, moments, g.K,
+  hipLaunchKernelGGL(stem_pool_finalize_kernel, dim3(g.K), dim3(256), 0, st, a.part, nwc, gram, f, bias, bn_g, moments, g.K,
                      g.R, train ? 1 : 0, df_out, dbias_out, dg_out, db_out);
   XM_LAUNCH_CHECK();
   return XM_OK;

@@ -33,14 +33,14 @@ struct StemPoolArgs {
   float *part;                       // gram: [grid][64][64], wgrad: [grid][96][64]
   int M, R, nU, nV;                  // filters, taps (nU * nV), filter rows / columns
   int PI, PJ;                        // output pixel grid
-  FastDiv divJG, divG;               // (column pairs) * (256-row groups), 256-row groups: block unit -> (sample, pair, group)
+  FastDiv divJG, divG;               // stem_gram_kernel: (column pairs) * (256-row groups), 256-row groups: block unit -> (sample, pair, group)
+                                     // conv_stem_wgrad_pool_kernel: column pairs per sample, 64-row chunk pairs per column: wave unit -> (sample, pair, chunk pair)
   int gsx, gh0, gw0, LimH, LimW;     // forward gather geometry (as ConvGemmArgs)
   int xSampleStride;
   const float *dP, *yP;              // pooled DZDY, pooled forward output [pHo][pWo][M][N]
   const unsigned char *amax;         // routing table (first maximum, code = dh + 3 dw)
   unsigned dpBytes, amBytes;
   int pHo, pWo;
-  int dbg;                           // experiment switches (XM_SP_DBG; 0 in the product)
 };
 
 // ---- work decomposition ------------------------------------------------------------------------------------------------------
@@ -236,257 +236,330 @@ stem_gram_reduce_kernel(const float *__restrict__ part, double *__restrict__ gra
 }
 
 // ---- A = dz P~ with dz scattered from the pooled derivative ---------------------------------------------------------------
-// Per row tile rt of 32 filters a wave loads, for window columns p = 0: jp - 1 and p = 1: jp, the 32 window rows
-// [32 cp, 32 cp + 32) of its 64 output rows as 16-byte quads (lane -> filter lane / 4 (+ 16), quad lane % 4 of chunk h) --
-// pooled derivative, pooled forward output (ReLU gate) and routing codes -- plus the single window row 32 cp - 1 in front
-// (lanes 0-31: p = 0, lanes 32-63: p = 1).  A quad that would reach past its pooled column is shifted back (no load
-// leaves the tensor) and its first `shift` elements are ignored.  The derivatives are gated once (y_pool > 0) and stay in
-// registers for the four (column, chunk) steps of the row tile; each step zero-fills the wave's dz region [32 filters][32
-// pixels], scatters the elements whose code names this column (dw) with ds_add_f32 -- window row r of the chunk lands on
-// pixel 2 r + dh; row 15 with dh = 2 on pixel 0 of the NEXT chunk -- and multiplies: 32 MFMAs per step.
-// Output column 2 jp takes dw = 0 of window column jp and dw = 2 of jp - 1; column 2 jp + 1 takes dw = 1 of jp.
+// A WAVE owns one row tile of 32 filters (rt = logical wave index % 3, fixed for the kernel: its 32 accumulator registers
+// hold its share of A for the whole launch) and walks (sample, column pair jp, 64-row chunk pair cp) units.  Per unit it
+// loads, for window columns p = 0: jp - 1 and p = 1: jp, the 32 window rows [32 cp, 32 cp + 32) of its 64 output rows as
+// 16-byte quads (lane -> filter lane / 4 (+ 16), quad lane % 4 of chunk h) -- pooled derivative, routing codes and (GATE)
+// the pooled forward output -- plus the single window row 32 cp - 1 in front (lanes 0-31: p = 0, lanes 32-63: p = 1).  A
+// quad that would reach past its pooled column is shifted back (no load leaves the tensor) and its first `shift` elements
+// are ignored.  The derivatives are gated once and stay in registers for the four (column, chunk) steps of the unit; each
+// step zero-fills the wave's dz region [32 filters][32 pixels], scatters the elements whose code names this column (dw) with
+// ds_add_f32 -- window row r of the chunk lands on pixel 2 r + dh; row 15 with dh = 2 on pixel 0 of the NEXT chunk -- and
+// multiplies: 32 MFMAs per step.  Output column 2 jp takes dw = 0 of window column jp and dw = 2 of jp - 1; column
+// 2 jp + 1 takes dw = 1 of jp.  The next unit's operands and patch are requested under the last step's MFMAs.
+// (Second version: 96 accumulators per wave and the row tiles as an inner loop left two waves per SIMD whose load, scatter
+// and MFMA phases simply added up -- 1.8 ms at 256 spectrograms with every phase under 1 ms alone.  A third of the
+// registers per wave = three waves per SIMD to fill each other's phases.)
 // GATE: the ReLU gate is taken from y_pool (> 0); false: the table marks closed windows itself (code 255, as
 // conv_stem_bnpool_fwd_kernel writes it) and y_pool is not read.
+// Logical wave index: XCD x (blocks b % 8 == x) holds a contiguous range, so that the waves that work on neighbouring
+// units at the same time -- and share pooled lines and source columns -- share an L2.
+constexpr int kSp3Wave = 2 * kSpPatch + 32 * kSpTP;      // two patches (the next unit's is parked while the current one is read) + the dz region
+constexpr int kSp3Smem = (4 * kSp3Wave + kSpCst) * 4;    // 67 KB per block: two blocks per CU
 template <int SY, bool GATE>
 __global__ void __launch_bounds__(256, 2)
 conv_stem_wgrad_pool_kernel(const StemPoolArgs a, const int nunits) {
-  constexpr int TM = 3, TP = kSpTP;
+  constexpr int TP = kSpTP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  XM_SP_COMMON(a)
-  for (int i = t; i < 4 * kSpWave / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float *const sW0 = smem + wave * kSpWave;           // this wave's two source patches
-  float *const reg = sW0 + 2 * kSpPatch;              // this wave's dz region [32][TP]
-  float *const cst = smem + 4 * kSpWave;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
+  const int lc = lane >> 3, lk = lane & 7;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int nb8 = gridDim.x >> 3;                                            // blocks per XCD (grid % 24 == 0)
+  const int wl = ((blockIdx.x & 7) * nb8 + (blockIdx.x >> 3)) * 4 + wv;      // logical wave
+  const int rt = wl % 3, wc = wl / 3, nwc = (gridDim.x * 4) / 3;
+  for (int i = t; i < 4 * kSp3Wave / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float *const sW = smem + wave * kSp3Wave;           // this wave's source patch
+  float *const reg = sW + kSpPatch;                   // this wave's dz region [32][TP]
+  float *const cst = smem + 4 * kSp3Wave;
   for (int i = t; i < kSpCst; i += 256) cst[i] = i < 32 ? 1.f : 0.f;
   const __amdgpu_buffer_rsrc_t dprsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dP, 0, a.dpBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yprsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.yP, 0, a.dpBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t amrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.amax, 0, a.amBytes, 0x00020000);
   const int pHW = a.pHo * a.pWo;
   const int cl = lane >> 2, qd = lane & 3;
+  const bool mok[2] = {32 * rt + cl < a.M, 32 * rt + 16 + cl < a.M};      // filters that do not exist: nothing is routed
+  const bool emok = 32 * rt + l31 < a.M;
+
+  auto unit_of = [&](int u) {
+    SpUnit c;
+    const uint32_t uu = (uint32_t)min(u, nunits - 1);
+    const uint32_t q = xm_div(uu, a.divG);                // divG here: chunk pairs per column
+    c.cp = (int)(uu - q * a.divG.d);
+    c.n = (int)xm_div(q, a.divJG);                        // divJG here: column pairs per sample
+    c.jp = (int)(q - (uint32_t)c.n * a.divJG.d);
+    c.live = u < nunits;
+    c.col1 = 2 * c.jp + 1 < a.PJ;
+    c.chunk1 = 64 * c.cp + 32 < a.PI;
+    return c;
+  };
+  f32x4 ld[6];
+  int ldst[6];
+  bool ldz[6];
+  auto issue_patch = [&](const SpUnit &c) {
+    const int iF = 64 * c.cp, iL = min(iF + 63, a.PI - 1);
+    const int lo4 = (SY * iF + a.gh0 + 4) >> 2;
+    const int n0 = c.live ? ((SY * iL + a.gh0 + 4 + 7) >> 2) - lo4 + 1 : 0;
+    const int ncol = a.gsx + a.nV;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int col = it < 5 ? lc : 8, q = it < 5 ? lk + 8 * it : lane;
+      const bool wr = col < ncol && q < n0 && (it < 5 || lane < 40);
+      const int cc = a.gsx * 2 * c.jp + a.gw0 + col, r = 4 * (lo4 + q) - 4;
+      const bool in = wr && cc >= 0 && cc < a.LimW && r >= 0 && r < a.LimH;
+      ldst[it] = wr ? col * kSpHW + 4 * q : kSpNC * kSpHW;
+      ldz[it] = !in;
+      ld[it] = *reinterpret_cast<const f32x4 *>(in ? a.X + (size_t)c.n * a.xSampleStride + (size_t)cc * a.LimH + r : a.X);
+    }
+  };
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) *reinterpret_cast<f32x4 *>(sW + ldst[it]) = ldz[it] ? f32x4{0.f, 0.f, 0.f, 0.f} : ld[it];
+  };
+  int tapoff[2], cstoff[2];
+  bool isTap[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int n = l31 + 32 * jt;
+    const int v = n < a.R ? n / a.nU : 0, u = n < a.R ? n - v * a.nU : 0;
+    tapoff[jt] = u + kSpHW * v;
+    isTap[jt] = n < a.R;
+    cstoff[jt] = n == a.R ? 0 : 32;
+  }
 
   // ---- per-unit lane geometry of the candidates ---------------------------------------------------------------------------
   struct Cand {
     unsigned voff[2];     // per chunk h: element offset of the lane's quad inside a (sample, 16-filter group, window column 0) block
-    unsigned lim[2];      // per chunk: 4 x 8 bit, element e routes into the chunk iff (code - 3 dw) < lim[e]  (0: ignore the element)
-    int rowb[2];          // per chunk: LDS float offset of pixel row (2 e + dh) = 0 of the lane's quad inside a 16-filter group
-    bool x15;             // this lane's element 3 of chunk 0 is window row 15: with dh = 2 it lands on pixel 0 of chunk 1
-    unsigned exoff;       // the window row 32 cp - 1: element offset inside a (sample, row tile) block, or out of range
+    unsigned vmask;       // bit 4 h + e: element e of the chunk-h quad is a window row of this column (< pHo)
+    int shift[2];         // != 0 only for the LAST pooled column of the tensor: the quad was loaded `shift` rows early
+    bool anyshift;        // (wave-uniform) some lane of this unit has a shifted quad
+    unsigned exoff;       // the window row 32 cp - 1 (lanes with qd < 2: window column p = qd): element offset inside a
+                          // (sample, 16-filter group) block, or out of range
     bool ok[2];           // window column p exists (wave-uniform)
-    int sbase;            // element offset of (sample, filter 0, window column 0, window row 0)
+    int sbase;            // element offset of (sample, filter 32 rt, window column 0, window row 0)
     int jp;
   };
-  auto cand_of = [&](const SpUnit &c, bool on) {
+  auto cand_of = [&](const SpUnit &c) {
     Cand k;
     k.jp = c.jp;
-    k.ok[1] = on && c.live && c.jp < a.pWo;
-    k.ok[0] = on && c.live && c.jp >= 1 && c.jp - 1 < a.pWo;
-    k.x15 = false;
+    k.ok[1] = c.live && c.jp < a.pWo;
+    k.ok[0] = c.live && c.jp >= 1 && c.jp - 1 < a.pWo;
+    // a quad that reaches past its pooled column reads the head of the next one (ignored: vmask) -- except in the very last
+    // column of the tensor, where it would leave the buffer: there it is loaded early and re-aligned after the load
+    const bool lastplane = c.n * a.M + 32 * rt + 32 >= (a.dpBytes >> 2) / (unsigned)pHW;      // (wave-uniform)
+    k.anyshift = lastplane && c.jp >= a.pWo - 1 && 32 * c.cp + 32 > a.pHo;
+    k.vmask = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int ph0 = 32 * c.cp + 16 * h + 4 * qd;        // nominal first window row of the lane's quad
-      const int phs = min(ph0, a.pHo - 4);                // shifted back so that the quad stays inside its pooled column
-      const int shift = ph0 - phs;                        // elements e < shift belong to the quad before
+      const int ph0 = 32 * c.cp + 16 * h + 4 * qd;        // first window row of the lane's quad
+      const int phs = k.anyshift ? min(ph0, a.pHo - 4) : ph0;
+      k.shift[h] = ph0 - phs;
       k.voff[h] = (unsigned)(cl * pHW + phs);
-      unsigned lim = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int rel = phs + e - 32 * c.cp - 16 * h;     // window row relative to the chunk: pixel row = 2 rel + dh
-        const bool valid = e >= shift && shift < 4;
-        lim |= (valid ? (rel == 15 ? 2u : 3u) : 0u) << (8 * e);
-        if (h == 0 && e == 3 && valid && rel == 15) k.x15 = true;
-      }
-      k.lim[h] = lim;
-      k.rowb[h] = cl * TP + 2 * (phs - 32 * c.cp - 16 * h);
+      for (int e = 0; e < 4; ++e) k.vmask |= (ph0 + e < a.pHo ? 1u : 0u) << (4 * h + e);
     }
-    const bool exok = c.cp > 0 && (half ? k.ok[1] : k.ok[0]);
-    k.exoff = exok ? (unsigned)((l31 * a.pWo + c.jp - 1 + half) * a.pHo + 32 * c.cp - 1) : 0x3FFFFFFFu;
-    k.sbase = c.n * a.M * pHW;
+    const bool exok = c.cp > 0 && qd < 2 && (qd ? k.ok[1] : k.ok[0]);
+    k.exoff = exok ? (unsigned)((cl * a.pWo + c.jp - 1 + qd) * a.pHo + 32 * c.cp - 1) : 0x3FFFFFFFu;
+    k.sbase = (c.n * a.M + 32 * rt) * pHW;
     return k;
   };
-  // pooled operands of row tile rt: [window column p][group of 16 filters][chunk]
-  f32x4 cdp[2][2][2], cyp[2][2][2];
-  unsigned ccd[2][2][2];
-  float edp, eyp = 0.f;
-  unsigned ecd;
-  auto issue_cand = [&](const Cand &k, int rt) {
+  // pooled operands of a unit: [window column p][group of 16 filters][chunk].  n*: as loaded, for the NEXT unit (requested a
+  // whole unit ahead); c*: gated, the unit being multiplied.  e*: the window row in front of the unit's first one
+  f32x4 cdp[2][2][2], ndp[2][2][2], nyp[2][2][2];
+  unsigned ccd[2][2][2], ncd[2][2][2];
+  float edp[2], nedp[2] = {0.f, 0.f}, neyp[2] = {0.f, 0.f};
+  unsigned ecd[2], necd[2] = {0u, 0u};
+  auto issue_cand = [&](const Cand &k) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (k.ok[p] && !(a.dbg & 1)) {
+    for (int it = 0; it < 2; ++it) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+      for (int p = 0; p < 2; ++p) {
+        if (k.ok[p]) {
           typedef unsigned u4 __attribute__((ext_vector_type(4)));
-          const int so = k.sbase + (32 * rt + 16 * it) * pHW + (k.jp - 1 + p) * a.pHo;     // scalar part (elements)
+          const int so = k.sbase + 16 * it * pHW + (k.jp - 1 + p) * a.pHo;     // scalar part (elements)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            cdp[p][it][h] = __builtin_bit_cast(f32x4, (u4)__builtin_amdgcn_raw_buffer_load_b128(dprsrc, (int)(k.voff[h] * 4u), so * 4, 0));
-            if (GATE) cyp[p][it][h] = __builtin_bit_cast(f32x4, (u4)__builtin_amdgcn_raw_buffer_load_b128(yprsrc, (int)(k.voff[h] * 4u), so * 4, 0));
-            ccd[p][it][h] = __builtin_amdgcn_raw_buffer_load_b32(amrsrc, (int)k.voff[h], so, 0);
+            ndp[p][it][h] = __builtin_bit_cast(f32x4, (u4)__builtin_amdgcn_raw_buffer_load_b128(dprsrc, (int)(k.voff[h] * 4u), so * 4, 0));
+            if (GATE) nyp[p][it][h] = __builtin_bit_cast(f32x4, (u4)__builtin_amdgcn_raw_buffer_load_b128(yprsrc, (int)(k.voff[h] * 4u), so * 4, 0));
+            ncd[p][it][h] = __builtin_amdgcn_raw_buffer_load_b32(amrsrc, (int)k.voff[h], so, 0);
           }
         }
       }
+      const int so = k.sbase + 16 * it * pHW;
+      nedp[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dprsrc, (int)(k.exoff * 4u), so * 4, 0));
+      if (GATE) neyp[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yprsrc, (int)(k.exoff * 4u), so * 4, 0));
+      necd[it] = __builtin_amdgcn_raw_buffer_load_b8(amrsrc, (int)k.exoff, so, 0);
     }
-    const int so = k.sbase + 32 * rt * pHW;
-    if (a.dbg & 1) return;
-    edp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dprsrc, (int)(k.exoff * 4u), so * 4, 0));
-    if (GATE) eyp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yprsrc, (int)(k.exoff * 4u), so * 4, 0));
-    ecd = __builtin_amdgcn_raw_buffer_load_b8(amrsrc, (int)k.exoff, so, 0);
   };
-  // the ReLU gate, once per row tile: the derivative of a window whose maximum did not pass the ReLU is zero
-  auto gate_cand = [&](const Cand &k, int rt) {
+  // gate, once per unit: the derivative of a window whose maximum did not pass the ReLU, of a filter or a window row that
+  // does not exist, is zero
+  auto gate_cand = [&](const Cand &k) {
+    if (k.anyshift) {
+      // (one unit per launch) quads loaded `shift` rows early: element j of the quad is loaded element j + shift
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-      if (k.ok[p]) {
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const bool mok = 32 * rt + 16 * it + cl < a.M;       // (filters that do not exist: nothing is routed)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cdp[p][it][h][e] = (mok && (!GATE || cyp[p][it][h][e] > 0.f)) ? cdp[p][it][h][e] : 0.f;
-        }
-      }
-    edp = ((!GATE || eyp > 0.f) && 32 * rt + l31 < a.M) ? edp : 0.f;
-  };
-  // dz of (row tile rt, column jj, chunk h) into the wave's region.  Order of the <= 4 additions to a pixel: the window
-  // row in front (row 32 cp - 1 / row 15 of chunk 0) first, then window column jp - 1, then jp.
-  auto scatter = [&](const Cand &k, int rt, int jj, int h) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<f32x4 *>(reg + (lc + 8 * kk) * TP + 4 * lk) = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (h == 0) {
-      // lanes 0-31: window column jp - 1 (dw = 2: column 2 jp only), lanes 32-63: window column jp (dw = jj)
-      const unsigned want = half ? 3u * (unsigned)jj + 2u : 8u;
-      const bool act = half || jj == 0;
-      if (act && ecd == want && edp != 0.f) __hip_atomic_fetch_add(reg + l31 * TP, edp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int st = 0; st < 3; ++st)
+              if (k.shift[h] > st) {
+                ndp[p][it][h] = f32x4{ndp[p][it][h].y, ndp[p][it][h].z, ndp[p][it][h].w, 0.f};
+                if (GATE) nyp[p][it][h] = f32x4{nyp[p][it][h].y, nyp[p][it][h].z, nyp[p][it][h].w, 0.f};
+                ncd[p][it][h] >>= 8;
+              }
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if ((p == 1 || jj == 0) && k.ok[p]) {
-        const unsigned d3 = p == 1 ? 3u * (unsigned)jj : 6u;
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          if (h == 1) {
-            // window row 15 of chunk 0 with dh = 2: pixel 0 of this chunk
-            const unsigned code = ccd[p][it][0] >> 24;
-            if (k.x15 && code - d3 == 2u && cdp[p][it][0][3] != 0.f)
-              __hip_atomic_fetch_add(reg + (16 * it + cl) * TP, cdp[p][it][0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-          float *const rb = reg + 16 * it * TP + k.rowb[h];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned code = (ccd[p][it][h] >> (8 * e)) & 0xFFu, d = code - d3;
-            const bool hit = cdp[p][it][h][e] != 0.f && d < ((k.lim[h] >> (8 * e)) & 0xFFu);
-            if (hit) __hip_atomic_fetch_add(rb + 2 * e + (int)d, cdp[p][it][h][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-        }
-      }
-    }
-  };
-
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jt][r] = 0.f;
-
-  int q = blockIdx.x >> 3;
-  __syncthreads();                       // zero fill complete
-  SpUnit cur = wave_unit(tbase + min(q, max(tend, 1) - 1));
-  Cand kc = cand_of(cur, q < tend);
-  int pbuf = 0;
-  if (q < tend) {
-    issue_patch(cur);
-    issue_cand(kc, 0);
-    write_patch(sW0);
-  }
-  for (; q < tend; q += tstep) {
-    const int unit = tbase + q;
-    const bool more = q + tstep < tend;
-    const SpUnit nxt = wave_unit(more ? unit + tstep : unit);
-    const float *const sW = sW0 + pbuf * kSpPatch;
-    const float *tr = reg + l31 * TP + 16 * half;      // A operand: row l31, pixels 16 half + 4 c .. + 3
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      gate_cand(kc, i);                                 // (waits for this row tile's operands)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
+      for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bool run = cur.live && (jj == 0 || cur.col1) && (h == 0 || cur.chunk1);
-          if (run && !(a.dbg & 2)) scatter(kc, i, jj, h);
-          __builtin_amdgcn_sched_barrier(0);
-          // the next unit's patch: requested under the first step's MFMAs (few registers are live here), parked in the
-          // other patch buffer behind them
-          if (i == 0 && jj == 0 && h == 0) issue_patch(nxt);
-          if (jj == 1 && h == 1) {
-            // the row tile's operands are dead: request the next row tile's (the next unit's after the last one) under
-            // the last step's MFMAs
-            if (i < TM - 1) issue_cand(kc, i + 1);
-            else {
-              kc = cand_of(nxt, more);
-              issue_cand(kc, 0);
-            }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool v = k.ok[p] && mok[it] && ((k.vmask >> (4 * h + e)) & 1u) && (!GATE || nyp[p][it][h][e] > 0.f);
+            cdp[p][it][h][e] = v ? ndp[p][it][h][e] : 0.f;
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if (run && !(a.dbg & 4)) {
-            const int pbo = patch_base(cur, jj, h);
-            const float *pl[2];
+          ccd[p][it][h] = ncd[p][it][h];
+        }
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt) pl[jt] = isTap[jt] ? sW + pbo + tapoff[jt] : cst + cstoff[jt];
+    for (int it = 0; it < 2; ++it) {
+      edp[it] = (mok[it] && (!GATE || neyp[it] > 0.f)) ? nedp[it] : 0.f;      // (a row that does not exist was loaded out of range: 0)
+      ecd[it] = necd[it];
+    }
+  };
+  // dz of (column jj, chunk h) into the wave's region, composed in REGISTERS: lane (cl, qd) owns window rows 4 qd .. 4 qd + 3
+  // of the chunk for filters cl and 16 + cl, i.e. pixel rows 8 qd .. 8 qd + 8 -- element e with code dh + 3 dw adds to row
+  // 2 e + dh when dw names this column (three compare / select / add per element, no LDS atomics, no zero fill, no
+  // lane predicate) -- the ninth row belongs to the next lane (DPP inside the quad of lanes) or, from lane qd = 3, to pixel
+  // row 0 of the next chunk (kept in c8 from step h = 0 to step h = 1; the unit's first chunk takes the window row in front
+  // of the unit, e*).  Two 16-byte LDS stores per filter.
+  // (First version: ds_add_f32 per routed element behind a lane predicate, ~60 per unit and wave: 0.4 ms of the launch.)
+  float c8[2] = {0.f, 0.f};
+  float r9[9];
+  // slice idx = 0 .. 15 of the composition of step (jj, h): filter group it = idx / 8, window column p = (idx / 4) % 2,
+  // element e = idx % 4; the slice behind a group's last element finishes the group (carry rows, two 16-byte stores)
+  auto compose_slice = [&](int jj, int h, int idx, float *dst) {
+    const int it = idx >> 3, p = (idx >> 2) & 1, e = idx & 3;
+    if ((idx & 7) == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const f32x4 af = *reinterpret_cast<const f32x4 *>(tr + 4 * c);
+      for (int i = 0; i < 9; ++i) r9[i] = 0.f;
+    }
+    if (p == 1 || jj == 0) {
+      const unsigned d3 = p == 1 ? 3u * (unsigned)jj : 6u;
+      const unsigned d = ((ccd[p][it][h] >> (8 * e)) & 0xFFu) - d3;
+      const float v = cdp[p][it][h][e];
+      r9[2 * e] += d == 0u ? v : 0.f;
+      r9[2 * e + 1] += d == 1u ? v : 0.f;
+      r9[2 * e + 2] += d == 2u ? v : 0.f;
+    }
+    if ((idx & 7) == 7) {
+      // pixel row 0: the ninth row of the lane before (quad of lanes), of lane qd = 3 in the chunk before, or the window
+      // row in front of the unit
+      const float fromprev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r9[8]), 0x90 /* quad_perm [0,0,1,2] */, 0xf, 0xf, false));
+      float first;
+      if (h == 0) {
+        // lanes qd = 0 / 1 hold the row in front for window column jp - 1 (dw = 2: column 2 jp only) / jp (dw = jj)
+        const unsigned want = qd ? 3u * (unsigned)jj + 2u : 8u;
+        const float xv = ((qd || jj == 0) && ecd[it] == want) ? edp[it] : 0.f;
+        first = xv + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xv), 0xF5 /* quad_perm [1,1,3,3] */, 0xf, 0xf, false));
+      } else {
+        first = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c8[it]), 0xFF /* quad_perm [3,3,3,3] */, 0xf, 0xf, false));
+      }
+      r9[0] += qd == 0 ? first : fromprev;
+      if (h == 0) c8[it] = r9[8];
+      float *const d = dst + (16 * it + cl) * TP + 8 * qd;
+      *reinterpret_cast<f32x4 *>(d) = f32x4{r9[0], r9[1], r9[2], r9[3]};
+      *reinterpret_cast<f32x4 *>(d + 4) = f32x4{r9[4], r9[5], r9[6], r9[7]};
+    }
+  };
+  auto compose = [&](int jj, int h, float *dst) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float b0 = pl[0][SY * (4 * c + e)], b1 = pl[1][SY * (4 * c + e)];
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b1, acc[i][1], 0, 0, 0);
-              }
-            }
-          }
-          if (i == 0 && jj == 0 && h == 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            write_patch(sW0 + (pbuf ^ 1) * kSpPatch);
+    for (int idx = 0; idx < 16; ++idx) compose_slice(jj, h, idx, dst);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+
+  __syncthreads();                       // zero fill and constants complete
+  int u = wc;
+  SpUnit cur = unit_of(u), nxt = unit_of(u + nwc);
+  Cand kn = cand_of(nxt);                               // geometry of the unit whose operands are in flight (n*)
+  if (u < nunits) {
+    const Cand k0 = cand_of(cur);
+    issue_patch(cur);
+    issue_cand(k0);
+    write_patch();
+    gate_cand(k0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_cand(kn);                                     // the next unit's operands and patch: a whole unit ahead
+    if (!GATE) issue_patch(nxt);                        // (GATE: y_pool's quads leave no registers for a patch in flight)
+  }
+  const float *tr = reg + l31 * TP + 16 * half;        // A operand: row l31, pixels 16 half + 4 c .. + 3
+  for (; u < nunits; u += nwc) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int jj = st >> 1, h = st & 1;
+      const bool run = (jj == 0 || cur.col1) && (h == 0 || cur.chunk1);
+      if (run) compose(jj, h, reg);
+      __builtin_amdgcn_sched_barrier(0);
+      if (run) {
+        const int iF = 64 * cur.cp;
+        const int pbo = (iF + 32 * h + 16 * half) * SY + a.gh0 + 4 - 4 * ((SY * iF + a.gh0 + 4) >> 2) + a.gsx * jj * kSpHW;
+        const float *pl[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) pl[jt] = isTap[jt] ? sW + pbo + tapoff[jt] : cst + cstoff[jt];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 af = *reinterpret_cast<const f32x4 *>(tr + 4 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float b0 = pl[0][SY * (4 * c + e)], b1 = pl[1][SY * (4 * c + e)];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b1, acc[1], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_s_setprio(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // this unit's operands are dead: gate the next unit's (requested a unit ago), request the ones after them, park the
+    // next unit's patch behind this unit's last B reads (LDS operations of a wave execute in order)
+    if (GATE) issue_patch(nxt);
+    gate_cand(kn);
+    write_patch();
+    __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
-    pbuf ^= 1;
+    nxt = unit_of(u + 2 * nwc);
+    kn = cand_of(nxt);
+    issue_cand(kn);
+    if (!GATE) issue_patch(nxt);
   }
-  // the four waves add their accumulators in LDS in wave order; the block leaves one partial [96][64]
-  float *const sD = smem;
-  for (int wq = 0; wq < 4; ++wq) {
-    __syncthreads();
-    if (wave == wq) {
+  // the wave's partial [32][64]
+  float *out = a.part + (size_t)wl * (32 * 64);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+  for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float *d = sD + (32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * jt + l31;
-            *d = wq ? *d + acc[i][jt][r] : acc[i][jt][r];
-          }
-    }
-  }
-  __syncthreads();
-  float *out = a.part + (size_t)blockIdx.x * (96 * 64);
-  for (int i = t; i < 96 * 64 / 4; i += 256) reinterpret_cast<f32x4 *>(out)[i] = reinterpret_cast<const f32x4 *>(sD)[i];
+    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * jt + l31] = acc[jt][r];
 }
 
 // ---- dF~, dg, db from A and G (fp64; one block per filter) -----------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-stem_pool_finalize_kernel(const float *__restrict__ part, int nblk, const double *__restrict__ gram,
+stem_pool_finalize_kernel(const float *__restrict__ part, int nwc, const double *__restrict__ gram,
                           const float *__restrict__ f, const float *__restrict__ bias, const float *__restrict__ bn_g,
                           const float *__restrict__ moments, int M, int R, int train, float *__restrict__ df,
                           float *__restrict__ dbias, float *__restrict__ dg, float *__restrict__ db) {
+  // part: [logical wave 3 wc + rt][32][64] (conv_stem_wgrad_pool_kernel); filter m sits in row m % 32 of the waves rt = m / 32
   __shared__ double red[4][64];
   __shared__ double sA[64], sF[64], sS[2];
   const int tt = threadIdx.x & 63, grp = threadIdx.x >> 6, m = blockIdx.x;
+  const int rt = m >> 5, row = m & 31;
   double v = 0.0;
-  for (int b = grp; b < nblk; b += 4) v += (double)part[(size_t)b * (96 * 64) + m * 64 + tt];
+  for (int b = grp; b < nwc; b += 4) v += (double)part[(size_t)(3 * b + rt) * (32 * 64) + row * 64 + tt];
   red[grp][tt] = v;
   __syncthreads();
   if (grp == 0) {
@@ -635,23 +708,25 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
         ladd[tb][e] = (unsigned)(((off & 3) * kSfPlane + (off >> 2) + l31) * 4);
       }
     const f32x4 *const pa = reinterpret_cast<const f32x4 *>(sA) + rt * 64 + half * 32 + l31;   // + v * TM * 64
-    // staging of two source columns: lane -> (column idx / 68, unit idx % 68), idx = lane + 64 it
-    auto load_cols = [&](f32x4 (&nl)[3], int scA, int count) {
+    // staging of two source columns, 68 units of 16 bytes each: loads 0 / 2 take units 0 .. 63 of column A / B (lane =
+    // unit), loads 1 / 3 units 64 .. 67 (lanes 0 .. 3) -- every instruction has ONE destination slot, so the LDS address is
+    // lane base + immediate
+    auto load_cols = [&](f32x4 (&nl)[4], int scA, int count) {
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = lane + 64 * it, cs = idx >= kSfPlane ? 1 : 0, k = idx - kSfPlane * cs;
+      for (int it = 0; it < 4; ++it) {
+        const int cs = it >> 1, k = lane + 64 * (it & 1);
         const int sc = scA + cs, r = 4 * (U0 + k);
-        const bool in = cs < count && idx < 2 * kSfPlane && sc >= 0 && sc < a.LimW && r >= 0 && r < a.LimH;
+        const bool in = cs < count && k < kSfPlane && sc >= 0 && sc < a.LimW && r >= 0 && r < a.LimH;
         nl[it] = *reinterpret_cast<const f32x4 *>(in ? a.X + (size_t)n * a.xSampleStride + (size_t)sc * a.LimH + r : a.X);
         if (!in) nl[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     };
-    auto write_cols = [&](const f32x4 (&nl)[3], int slotA, int slotB) {
+    auto write_cols = [&](const f32x4 (&nl)[4], int slotA, int slotB) {
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int idx = lane + 64 * it, cs = idx >= kSfPlane ? 1 : 0, k = idx - kSfPlane * cs;
-        if (idx < 2 * kSfPlane && (cs ? slotB : slotA) >= 0) {
-          float *d = ring + (cs ? slotB : slotA) * kSfSlot + k;
+      for (int it = 0; it < 4; ++it) {
+        const int slot = (it >> 1) ? slotB : slotA;
+        if (slot >= 0 && ((it & 1) == 0 || lane < kSfPlane - 64)) {
+          float *d = ring + slot * kSfSlot + 64 * (it & 1) + lane;
           d[0] = nl[it].x, d[kSfPlane] = nl[it].y, d[2 * kSfPlane] = nl[it].z, d[3 * kSfPlane] = nl[it].w;
         }
       }
@@ -659,7 +734,7 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
     // prologue: the seven source columns under the first output column into slots 0 .. 6
     const int sc0 = 2 * (2 * pw0) + a.gw0;
     {
-      f32x4 nl[3];
+      f32x4 nl[4];
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
         load_cols(nl, sc0 + 2 * pr, pr < 3 ? 2 : 1);
@@ -684,9 +759,11 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
     }
     const int sbase = (n * a.M + 32 * rt) * pHW;
 
-    auto column = [&](auto rtag, int c) {
+    const int ngrp = min(4, (a.M - 32 * rt) >> 3);           // groups of 8 filters of this row tile that exist (M % 8 == 0)
+    auto column = [&](auto rtag, auto fulltag, int c) {
       constexpr int r = decltype(rtag)::value;               // position in the ring period: slots (2 r + v) % 7
-      f32x4 nl[3];
+      constexpr bool FULL = decltype(fulltag)::value;        // all 32 filters of the row tile exist
+      f32x4 nl[4];
       load_cols(nl, sc0 + 2 * c + 7, c + 1 < ncol ? 2 : 0);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[2][2];
@@ -696,6 +773,9 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[w][tb][i] = 0.f;
+      // (the wave in its MFMA phase goes first: two waves of a SIMD that start together then settle half a period apart,
+      // one multiplying while the other pools and stores -- without it both phases of both waves simply added up)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
 #pragma unroll
@@ -716,60 +796,67 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       write_cols(nl, (2 * r) % 7, (2 * r + 1) % 7);          // (LDS operations of a wave execute in order: behind the B reads)
       // ---- pooling ------------------------------------------------------------------------------------------------------
-      const bool odd = c & 1;
-      const int pw = pw0 + (c >> 1) - 1;                     // the window column an even output column closes
+      // on the bnorm's RAW output: max and the ReLU commute, and the first maximum of the rectified window is the first
+      // maximum of the raw one whenever it is positive -- a window whose maximum is <= 0 is closed (value 0, code 255)
+      const int pwoff = (pw0 + (c >> 1) - 1) * a.pHo;        // the window column an even output column closes
+      // MODE 0: odd column (update), 1: first column of the segment (open a window), 2: even column (close one, open the next)
+      auto pool = [&](auto modetag) {
+        constexpr int MODE = decltype(modetag)::value;
 #pragma unroll
-      for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < 2; ++w) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float av = fmaxf(acc[w][0][i], 0.f), bv = fmaxf(acc[w][1][i], 0.f);
-          float an = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, av), 0x130, 0xf, 0xf, false));
-          if (w == 0) {
-            // a[q + 1] of lanes 31 / 63: lanes 0 / 32 of the second even tile
-            const float a1 = fmaxf(acc[1][0][i], 0.f);
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), 32));
-            asm volatile("v_writelane_b32 %0, %1, 31\n\tv_writelane_b32 %0, %2, 63" : "+v"(an) : "s"(s0), "s"(s1));
-          }
-          const float m1 = fmaxf(av, bv);
-          unsigned dh = bv > av ? 1u : 0u;
-          const float V = fmaxf(m1, an);
-          dh = an > m1 ? 2u : dh;
-          const int ci = (w * 16 + i) >> 2, sh = 8 * ((w * 16 + i) & 3);
-          const unsigned cur = (codes[ci] >> sh) & 0xFFu;
-          if (odd) {
-            const bool take = V > best[w][i];
-            best[w][i] = take ? V : best[w][i];
-            codes[ci] = take ? (codes[ci] & ~(0xFFu << sh)) | ((dh + 3u) << sh) : codes[ci];
-          } else {
-            if (c > 0) {
+          for (int i = 0; i < 16; ++i) {
+            const float av = acc[w][0][i], bv = acc[w][1][i];
+            float an = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, av), 0x130, 0xf, 0xf, false));
+            if (w == 0) {
+              // a[q + 1] of lanes 31 / 63: lanes 0 / 32 of the second even tile
+              // (everything in asm: with the readlane builtin on a vector element the compiler read element 0 for every i)
+              asm volatile("v_readlane_b32 s6, %1, 0\n\tv_readlane_b32 s7, %1, 32\n\ts_nop 3\n\t"
+                           "v_writelane_b32 %0, s6, 31\n\tv_writelane_b32 %0, s7, 63"
+                           : "+v"(an) : "v"(acc[1][0][i]) : "s6", "s7");
+            }
+            const float V = fmaxf(fmaxf(av, bv), an);
+            unsigned dh = V == bv ? 1u : 2u;
+            dh = V == av ? 0u : dh;
+            const int ci = (w * 16 + i) >> 2, sh = 8 * ((w * 16 + i) & 3);
+            if (MODE == 0) {
               const bool take = V > best[w][i];
-              const float yv = take ? V : best[w][i];
-              const unsigned cv = yv > 0.f ? (take ? dh + 6u : cur) : 255u;
-              if (32 * rt + 8 * (i >> 2) < a.M) {            // (wave-uniform: M % 8 == 0)
-                const int so = sbase + (8 * (i >> 2) + (i & 3)) * pHW + pw * a.pHo;
+              best[w][i] = fmaxf(V, best[w][i]);
+              codes[ci] = take ? (codes[ci] & ~(0xFFu << sh)) | ((dh + 3u) << sh) : codes[ci];
+            } else {
+              if (MODE == 2 && (FULL || (i >> 2) < ngrp)) {
+                const bool take = V > best[w][i];
+                const float yv = fmaxf(fmaxf(V, best[w][i]), 0.f);
+                const unsigned cur = (codes[ci] >> sh) & 0xFFu;
+                const unsigned cv = yv > 0.f ? (take ? dh + 6u : cur) : 255u;
+                const int so = sbase + (8 * (i >> 2) + (i & 3)) * pHW + pwoff;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yrsrc, (int)(vy[w] * 4u), so * 4, 0);
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)cv, amrsrc, (int)vy[w], so, 0);
               }
+              best[w][i] = V;
+              codes[ci] = (codes[ci] & ~(0xFFu << sh)) | (dh << sh);
             }
-            best[w][i] = V;
-            codes[ci] = (codes[ci] & ~(0xFFu << sh)) | (dh << sh);
           }
         }
-      }
+      };
+      if (c & 1) pool(std::integral_constant<int, 0>{});
+      else if (c == 0) pool(std::integral_constant<int, 1>{});
+      else pool(std::integral_constant<int, 2>{});
     };
+    const bool full = 32 * rt + 32 <= a.M;
+#define XM_SF_COL(R_)                                                                          \
+  if (c0 + R_ < ncol) {                                                                        \
+    if (full) column(std::integral_constant<int, R_>{}, std::true_type{}, c0 + R_);            \
+    else column(std::integral_constant<int, R_>{}, std::false_type{}, c0 + R_);                \
+  }
     for (int c0 = 0; c0 < ncol; c0 += 7) {
-      if (c0 + 0 < ncol) column(std::integral_constant<int, 0>{}, c0 + 0);
-      if (c0 + 1 < ncol) column(std::integral_constant<int, 1>{}, c0 + 1);
-      if (c0 + 2 < ncol) column(std::integral_constant<int, 2>{}, c0 + 2);
-      if (c0 + 3 < ncol) column(std::integral_constant<int, 3>{}, c0 + 3);
-      if (c0 + 4 < ncol) column(std::integral_constant<int, 4>{}, c0 + 4);
-      if (c0 + 5 < ncol) column(std::integral_constant<int, 5>{}, c0 + 5);
-      if (c0 + 6 < ncol) column(std::integral_constant<int, 6>{}, c0 + 6);
+      XM_SF_COL(0) XM_SF_COL(1) XM_SF_COL(2) XM_SF_COL(3) XM_SF_COL(4) XM_SF_COL(5) XM_SF_COL(6)
     }
+#undef XM_SF_COL
   }
 }
 

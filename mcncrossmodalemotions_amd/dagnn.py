@@ -478,6 +478,8 @@ class DagNN:
         self.fuseStemBackward = os.environ.get("XM_NO_FUSED_STEM_BWD") is None
         # ... and without reading the convolution's output either (vl.conv_backward_filter_bnrelupool_gram, round 6)
         self.fuseStemGram = os.environ.get("XM_NO_STEM_GRAM") is None
+        # ... and the forward pass of conv -> bnorm -> relu -> pool as one kernel (vl.conv_bnorm_relu_pool)
+        self.fuseStemForward = os.environ.get("XM_NO_STEM_FWD") is None
         self.fuseForkSums = os.environ.get("XM_NO_FORK_SUMS") is None   # global-avg backward adds the fork's other derivative
         self.fuseSE = os.environ.get("XM_NO_FUSED_SE") is None   # test mode: SE squeeze from the projection's input, excite in its epilogue
         # training plans: relu mask + excite + squeeze + bnorm backward of an SE block's tail in two fused calls
@@ -814,6 +816,7 @@ class _Step:
         self.bias_conv = None    # bnorm steps: _Step of the biased Conv that produced the input (its dzdb = sum of our dx)
         self.bias_conv_done = False
         self.se_bn = None        # training plans: the _SEBnTrainStep whose fused backward covers this step (its squeeze / excite)
+        self.stem_into = None    # training plans: the _BnReluPoolStep that can run this (first-layer) convolution inside its own kernel
 
     def _bias_der_slot(self, net):
         """flat derivative slot of the producing convolution's bias when this bnorm step may fill it (sum of dx)"""
@@ -841,6 +844,8 @@ class _Step:
             f = self.se_bn.fwd      # the squeeze of a fused SE tail: straight from the bnorm's input
             net.vars[r.outputs[0]].value = vl.se_squeeze_bn(f["u"], f["g"], f["b"], f["moments"])
             return
+        if self.stem_into is not None and self.stem_into.stem_forward(net, self):
+            return      # conv -> bnorm -> relu -> pool ran as one kernel; this convolution's output is never written
         ins = [net.vars[v].value for v in r.inputs]
         if net._training and net.wgradStream is not None and isinstance(r.block, Conv) and \
                 net.vars[r.inputs[0]].fanin > 0 and net.prepareBackward:
@@ -1107,8 +1112,54 @@ class _BnReluPoolStep(_Step):
         self.bias_conv_done = False
         self.producer_conv = None         # _Step of the Conv whose ONLY consumer is this BN (training plans, build_plan)
         self._stem_fused = True           # cleared when the library reports the shapes as not covered
+        self._stem_fwd_ok = True          # ... the fused forward (conv + bnorm + relu + pool in one kernel)
+        self._stem_fwd = None             # set by stem_forward: {"gram": G or None} -- the convolution's output does not exist
         if bias_conv is not None:
             bias_conv.bias_from = self
+
+    def _stem_conditions(self, net):
+        """what both fused directions need from the plan: the producing convolution is a first layer that feeds only this
+        step, and every derivative has its own slot in the flat buffer"""
+        cs = self.producer_conv
+        if cs is None or net._flat is None or net.accumulateParamDers:
+            return None
+        cr, r = cs.rec, self.rec
+        if net.vars[cr.inputs[0]].fanin > 0 or net.vars[cr.outputs[0]].precious:
+            return None
+        do, cdo = net._direct_der(r), net._direct_der(cr)
+        if do is None or cdo is None or any(net.params[p].fanout != 1 for p in cr.params):
+            return None
+        return cs, do, cdo
+
+    def stem_forward(self, net, cs):
+        """Called by the producing convolution's step in its place (round 6): conv -> bnorm -> relu -> pool as ONE kernel
+        from the convolution's input; the batch moments come from the Gram matrix of the input patches, which the backward
+        call takes as well (vl.conv_bnorm_relu_pool).  False = not applicable, the convolution runs as usual."""
+        self._stem_fwd = None
+        if not (self._stem_fwd_ok and self._stem_fused and net.fuseStemForward and net.fuseStemGram and
+                net.fuseStemBackward and net._training and net.fuseStats):
+            return False
+        ok = self._stem_conditions(net)
+        if ok is None or ok[0] is not cs:
+            return False
+        _, do, _ = ok
+        r, pb, blk = self.rec, self.pool_rec.block, cs.rec.block
+        g, b, mom = self._params(net)
+        test = net.mode == "test"
+        cpar = cs._params(net)
+        res = vl.conv_bnorm_relu_pool(net.vars[cs.rec.inputs[0]].value, cpar[0], cpar[1] if blk.hasBias else None, g, b,
+                                      pb.poolSize, stride=blk.stride, pad=blk.pad, dilate=blk.dilate, pool_stride=pb.stride,
+                                      pool_pad=pb.pad, epsilon=r.block.epsilon, moments=mom if test else None,
+                                      moments_out=None if test else do[2])
+        if res is None:
+            self._stem_fwd_ok = False
+            return False
+        y, am, mo, gram = res
+        r.block.moments = None if test else mo
+        self._saved = (am, mo)
+        self._stem_fwd = {"gram": gram}
+        net.vars[self.pool_rec.outputs[0]].value = y
+        return True
 
     @staticmethod
     def eligible(pool_block):
@@ -1117,6 +1168,8 @@ class _BnReluPoolStep(_Step):
         return pool_block.method == "max" and -(-ph // sy) <= 2 and -(-pw // sx) <= 2 and ph * pw <= 255
 
     def forward(self, net):
+        if self._stem_fwd is not None:
+            return      # stem_forward did it all at the convolution's position
         r, pb = self.rec, self.pool_rec.block
         x = net.vars[r.inputs[0]].value
         g, b, mom = self._params(net)
@@ -1169,16 +1222,15 @@ class _BnReluPoolStep(_Step):
         fused call leaves its filter / bias derivative and this bnorm's dg / db; the bnorm's DZDX is never written.
         Runs on the side stream when there is one (nothing on the main stream depends on it).  False = not applicable,
         the two separate steps run."""
-        cs = self.producer_conv
-        if cs is None or not self._stem_fused or not net.fuseStemBackward or net._flat is None or \
-                net.accumulateParamDers or do is None:
+        fwd, self._stem_fwd = self._stem_fwd, None
+        ok = self._stem_conditions(net) if (self._stem_fused and net.fuseStemBackward and do is not None) else None
+        if ok is None:
+            if fwd is not None:
+                raise RuntimeError("fused stem: the forward pass skipped the convolution's output but the fused backward "
+                                   "cannot run (%s)" % self.rec.name)
             return False
+        cs, _, cdo = ok
         cr = cs.rec
-        if net.vars[cr.inputs[0]].fanin > 0 or net.vars[cr.outputs[0]].precious:
-            return False
-        cdo = net._direct_der(cr)
-        if cdo is None or any(net.params[p].fanout != 1 for p in cr.params):
-            return False
         blk, pb = cr.block, self.pool_rec.block
         xin = net.vars[cr.inputs[0]].value
         side = net.wgradStream
@@ -1187,13 +1239,17 @@ class _BnReluPoolStep(_Step):
             side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
             res = None
-            if net.fuseStemGram:
-                # round 6: no pass over the convolution's output at all (the Gram matrix of the input patches)
+            if net.fuseStemGram or fwd is not None:
+                # round 6: no pass over the convolution's output at all (the Gram matrix of the input patches); after the
+                # fused forward the table marks the closed windows itself and y_pool is not read either
                 cpar = cs._params(net)
                 res = vl.conv_backward_filter_bnrelupool_gram(
-                    xin, cpar[0], cpar[1] if blk.hasBias else None, g, moments, am, out.value, out.der, pb.poolSize,
-                    stride=blk.stride, pad=blk.pad, dilate=blk.dilate, pool_stride=pb.stride, pool_pad=pb.pad,
-                    train=not test, df_out=cdo[0], dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1])
+                    xin, cpar[0], cpar[1] if blk.hasBias else None, g, moments, am, None if fwd is not None else out.value,
+                    out.der, pb.poolSize, stride=blk.stride, pad=blk.pad, dilate=blk.dilate, pool_stride=pb.stride,
+                    pool_pad=pb.pad, train=not test, gram=fwd["gram"] if fwd is not None else None, df_out=cdo[0],
+                    dbias_out=cdo[1] if blk.hasBias else None, dg_out=do[0], db_out=do[1])
+                if res is None and fwd is not None:
+                    raise RuntimeError("fused stem: the library took the forward call but not the backward one (%s)" % cr.name)
             if res is None:
                 res = vl.conv_backward_filter_bnrelupool(
                     xin, blk.size, x, g, b, moments, am, out.value, out.der, pb.poolSize, stride=blk.stride, pad=blk.pad,
@@ -1207,8 +1263,9 @@ class _BnReluPoolStep(_Step):
             self._stem_fused = False
             return False
         if side is not None:
-            for t in (xin, x, am, out.value, out.der, moments):
-                t.record_stream(side)
+            for t in (xin, x, am, out.value, out.der, moments) + ((fwd["gram"],) if fwd is not None else ()):
+                if t is not None:
+                    t.record_stream(side)
             net._side_pending = True
         self.bias_conv_done = True
         return True
@@ -1465,6 +1522,7 @@ def build_plan(net, training):
                     cs.moments_for = r
                     if type(st) is _BnReluPoolStep:
                         st.producer_conv = cs
+                        cs.stem_into = st
         # SE blocks: the plain bnorm behind the projection, its squeeze and its excite (+ relu) share one fused backward
         by_rec = {id(st.rec): st for st in steps}
         for i, st in enumerate(steps):

@@ -626,7 +626,8 @@ def test_profiler_names_are_the_kernels_that_exist(gpu):
         names.add(name)
         assert ("xm::%s(" % name) in syms, "%r (key %d) is not a kernel of %s" % (name, keys[i], _lib.SO_PATH)
     fam = {nm.split("<")[0] for nm in names}
-    assert {"conv_gemm_kernel", "conv_wgrad_kernel", "conv_stem_wgrad_bnp_kernel"} <= fam and len(fam) >= 5, fam
+    assert {"conv_gemm_kernel", "conv_wgrad_kernel", "conv_stem_bnpool_fwd_kernel", "conv_stem_wgrad_pool_kernel", "stem_gram_kernel"} <= fam \
+        and len(fam) >= 6, fam
     # the merged strided dgrad (the kernel whose key was mis-decoded): the student's conv2 geometry at 16 samples (the
     # classes merge into one launch when they have >= 512 tiles together)
     x = torch.randn((16, 96, 73, 126), device="cuda").permute(3, 2, 1, 0)

@@ -25,6 +25,7 @@ import importlib.util
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from oracle import graphs as G
@@ -93,6 +94,17 @@ class GateRecorder:
             self.calls.append((out[0], out[1]))
             return out
         monkeypatch.setattr(vl, "bnorm_relu_pool", wrapped)
+        real2 = vl.conv_bnorm_relu_pool
+
+        def wrapped2(*a, **k):
+            # the first layer's conv -> bnorm -> relu -> pool in one kernel (round 6): its table marks windows whose maximum
+            # did not pass the ReLU with 255; all entries of such a window are zero after the ReLU, so the first-maximum
+            # rule gives code 0 there -- recorded in that form
+            out = real2(*a, **k)
+            if out is not None:
+                self.calls.append((out[0], torch.where(out[1] == 255, torch.zeros_like(out[1]), out[1])))
+            return out
+        monkeypatch.setattr(vl, "conv_bnorm_relu_pool", wrapped2)
         plan = net._plan(True)
         self.pooled = [st for st in plan if isinstance(st, dagnn._BnReluPoolStep)]
         swallowed = {st.relu_rec.name for st in self.pooled}

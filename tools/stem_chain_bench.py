@@ -44,6 +44,10 @@ def fwd_new():
     assert st["new"] is not None
 
 
+if os.environ.get("ONLY_FWD"):
+    fwd_new()
+    print("N=%d XM_SF_DBG=%s: fused forward incl. Gram %.1f us" % (N, os.environ.get("XM_SF_DBG", "0"), t(fwd_new)))
+    sys.exit(0)
 fwd_old(); fwd_new()
 yp, am, mo = st["old"]
 yp2, am2, mo2, gram = st["new"]
