@@ -2670,7 +2670,9 @@ int xm_nnconv_bnorm_relu_pool_forward(const float *x, int H, int W, int C, int N
   a.PI = g.Ho, a.PJ = g.Wo, a.pHo = pHo, a.pWo = pWo;
   a.NS = (pHo + 62) / 63;
   const int slots = 256 * XM_SF_OCC * 4;
-  a.SG = std::max(1, std::min(std::min(16, pWo), (slots + g.N * a.NS * 3 - 1) / (g.N * a.NS * 3)));
+  // segments of window columns per (sample, strip, row tile): as many as fill ONE round of the resident waves (a second,
+  // partly filled round costs a whole one: 11 segments at 32 spectrograms = 2112 units for 2048 waves ran 285 us instead of 190)
+  a.SG = std::max(1, std::min(std::min(16, pWo), slots / (g.N * a.NS * 3)));
   a.nunits = g.N * a.NS * a.SG * 3;
   a.div3 = make_fastdiv(3u), a.divSG = make_fastdiv((uint32_t)a.SG), a.divNS = make_fastdiv((uint32_t)a.NS);
   a.gh0 = -g.pt, a.gw0 = -g.pl, a.LimH = g.H, a.LimW = g.W, a.xSampleStride = g.H * g.W;
@@ -2758,7 +2760,7 @@ int xm_nnconv_backward_filter_bnrelupool_gram(const float *x, int H, int W, int 
 #undef XM_SPW_LAUNCH
   }
   XM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stem_pool_finalize_kernel, dim3(g.K), dim3(256), 0, st, a.part, nwc, gram, f, bias, bn_g, moments, g.K,
+  hipLaunchKernelGGL(stem_pool_finalize_kernel, dim3(g.K), dim3(1024), 0, st, a.part, nwc, gram, f, bias, bn_g, moments, g.K,
                      g.R, train ? 1 : 0, df_out, dbias_out, dg_out, db_out);
   XM_LAUNCH_CHECK();
   return XM_OK;

@@ -223,8 +223,17 @@ stem_gram_reduce_kernel(const float *__restrict__ part, double *__restrict__ gra
   __shared__ double red[16][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x;
   const int si = (i < 32 && j >= 32) ? j : i, sj = (i < 32 && j >= 32) ? i : j;
+  // (eight loads in flight per thread: with one, the 48 partials of a thread were 48 serial memory round trips -- 26 us)
   double v = 0.0;
-  for (int b = g; b < nblk; b += 16) v += (double)part[(size_t)b * (64 * 64) + si * 64 + sj];
+  int b = g;
+  for (; b + 16 * 7 < nblk; b += 16 * 8) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = part[(size_t)(b + 16 * k) * (64 * 64) + si * 64 + sj];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += (double)x[k];
+  }
+  for (; b < nblk; b += 16) v += (double)part[(size_t)b * (64 * 64) + si * 64 + sj];
   red[g][j] = v;
   __syncthreads();
   if (g == 0) {
@@ -548,22 +557,34 @@ conv_stem_wgrad_pool_kernel(const StemPoolArgs a, const int nunits) {
 }
 
 // ---- dF~, dg, db from A and G (fp64; one block per filter) -----------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 stem_pool_finalize_kernel(const float *__restrict__ part, int nwc, const double *__restrict__ gram,
                           const float *__restrict__ f, const float *__restrict__ bias, const float *__restrict__ bn_g,
                           const float *__restrict__ moments, int M, int R, int train, float *__restrict__ df,
                           float *__restrict__ dbias, float *__restrict__ dg, float *__restrict__ db) {
-  // part: [logical wave 3 wc + rt][32][64] (conv_stem_wgrad_pool_kernel); filter m sits in row m % 32 of the waves rt = m / 32
-  __shared__ double red[4][64];
+  // part: [logical wave 3 wc + rt][32][64] (conv_stem_wgrad_pool_kernel); filter m sits in row m % 32 of the waves rt = m / 32.
+  // Sixteen groups of 64 taps, eight loads in flight per thread, fixed summation order.
+  __shared__ double red[16][64];
   __shared__ double sA[64], sF[64], sS[2];
   const int tt = threadIdx.x & 63, grp = threadIdx.x >> 6, m = blockIdx.x;
   const int rt = m >> 5, row = m & 31;
   double v = 0.0;
-  for (int b = grp; b < nwc; b += 4) v += (double)part[(size_t)(3 * b + rt) * (32 * 64) + row * 64 + tt];
+  int b = grp;
+  for (; b + 16 * 7 < nwc; b += 16 * 8) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = part[(size_t)(3 * (b + 16 * k) + rt) * (32 * 64) + row * 64 + tt];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += (double)x[k];
+  }
+  for (; b < nwc; b += 16) v += (double)part[(size_t)(3 * b + rt) * (32 * 64) + row * 64 + tt];
   red[grp][tt] = v;
   __syncthreads();
   if (grp == 0) {
-    sA[tt] = (red[0][tt] + red[1][tt]) + (red[2][tt] + red[3][tt]);
+    double sum = red[0][tt];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) sum += red[k][tt];
+    sA[tt] = sum;
     sF[tt] = tt < R ? (double)f[(size_t)m * R + tt] : (tt == R && bias ? (double)bias[m] : 0.0);
   }
   __syncthreads();

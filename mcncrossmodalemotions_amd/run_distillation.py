@@ -50,10 +50,9 @@ def run_distillation(gpus=(2,), cont=True, miniVal=0.2, numSeconds=4, batchSize=
     import torch
     import torch.distributed as dist
     if parameterServer == "tmove":
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        own_device = (multi and torch.cuda.is_available() and os.environ.get("XM_DEBUG_DIST") != "gloo0" and
-                      torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size())))
-        parameterServer = "rccl-capi" if (multi and (dist.get_backend() == "nccl" or own_device)) else "torch"
+        # decided once for all workers from the (host, device) pairs they post to the store (train.ParameterServer.
+        # choose_backend): the library's communicator when every worker has its own device, torch.distributed otherwise
+        parameterServer = train.ParameterServer.choose_backend()
     if isinstance(parameterServer, train.ParameterServer):
         parserv = parameterServer
         parserv.start()

@@ -64,10 +64,15 @@ class ParameterServer:
     def _wait_keys(cls, store, keys):
         """True when every key is there within store_timeout_s (a worker that died never writes its own)"""
         import datetime
+        import sys
         try:
             store.wait(list(keys), datetime.timedelta(seconds=cls.store_timeout_s))
             return True
-        except Exception:   # noqa: BLE001 -- torch raises RuntimeError / DistStoreError depending on the store
+        except Exception as e:   # noqa: BLE001 -- torch raises RuntimeError / DistStoreError depending on the store
+            # a timeout is an answer ("that worker is gone"); anything else (broken store, lost connection) is reported
+            # as what it is before it is treated the same way
+            if "timeout" not in str(e).lower() and "timed out" not in str(e).lower():
+                print("ParameterServer: store.wait failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
             return False
 
     def start(self):
@@ -86,24 +91,41 @@ class ParameterServer:
                 # every worker uses the same key whatever happens to it, and a worker 0 that cannot produce the id
                 # says so under that key instead of leaving the others waiting for it.
                 ParameterServer._generation += 1
-                key = "xm_comm_id/%d" % ParameterServer._generation
+                gen = ParameterServer._generation
+                key = "xm_comm_id/%d" % gen
                 store = self._store()
-                if self.rank == 0:
-                    try:
-                        rc = _lib.load().xm_comm_unique_id(buf)
-                    except Exception:
-                        store.set(key, b"no")
-                        raise
-                    store.set(key, b"ok" + bytes(buf) if rc == 0 else b"no")
-                    _lib.check(rc)
-                if not self._wait_keys(store, [key]):
-                    raise RuntimeError("ParameterServer: no communicator id from worker 0 within %.0f s"
-                                       % self.store_timeout_s)
-                got = bytes(store.get(key))
-                if not got.startswith(b"ok"):
-                    raise RuntimeError("ParameterServer: worker 0 could not create the communicator id")
-                raw = got[2:130]
-                L = _lib.load()
+                err, L = None, None
+                try:
+                    if self.rank == 0:
+                        try:
+                            rc = _lib.load().xm_comm_unique_id(buf)
+                        except Exception:
+                            store.set(key, b"no")
+                            raise
+                        store.set(key, b"ok" + bytes(buf) if rc == 0 else b"no")
+                        _lib.check(rc)
+                    if not self._wait_keys(store, [key]):
+                        raise RuntimeError("ParameterServer: no communicator id from worker 0 within %.0f s"
+                                           % self.store_timeout_s)
+                    got = bytes(store.get(key))
+                    if not got.startswith(b"ok"):
+                        raise RuntimeError("ParameterServer: worker 0 could not create the communicator id")
+                    raw = got[2:130]
+                    L = _lib.load()
+                except Exception as e:   # noqa: BLE001 -- posted below, re-raised after the ready round
+                    err = e
+                # READY round (round-5 advisor): xm_comm_init is ncclCommInitRank, which blocks in the RCCL bootstrap
+                # until EVERY rank has called it.  A worker that failed above (no library, no id) never will, so the
+                # healthy ones must not enter it: each worker posts whether it holds the library and the id, and the
+                # communicator is created only when all of them do.
+                ready = ["xm_comm_ready/%d/%d" % (gen, r) for r in range(self.world)]
+                store.set(ready[self.rank], b"0" if err is not None else b"1")
+                all_ready = self._wait_keys(store, ready) and all(bytes(store.get(k)) == b"1" for k in ready)
+                if err is not None:
+                    raise err
+                if not all_ready:
+                    raise RuntimeError("ParameterServer: another worker cannot create the communicator (it holds no "
+                                       "library or no id); xm_comm_init not entered")
             else:
                 L = _lib.load()
                 _lib.check(L.xm_debug_comm_force_single(1))
@@ -111,6 +133,34 @@ class ParameterServer:
                 raw = bytes(buf)
             _lib.check(L.xm_comm_init(C.c_char_p(raw), self.rank, self.world))
         self._started = True
+
+    _choice = 0          # choose_backend() rounds of this process so far
+
+    @classmethod
+    def choose_backend(cls):
+        """'rccl-capi' or 'torch' for parameterServer = 'tmove', decided ONCE FOR ALL workers from what they post to the
+        process group's store (round-5 advisor: each worker used to infer it locally from device_count() and
+        LOCAL_WORLD_SIZE; workers that disagreed -- heterogeneous nodes, several workers on one device -- left some of
+        them in the agreement round's store timeouts): every worker posts (host name, its current device); the library's
+        communicator carries the exchange only when every worker sits on its OWN device of its host, because RCCL refuses
+        two ranks on one device.  Same inputs on every worker => same answer on every worker."""
+        import os
+        import socket
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return "torch"
+        cls._choice += 1
+        store, world, rank = cls._store(), dist.get_world_size(), dist.get_rank()
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        if os.environ.get("XM_DEBUG_DIST") == "gloo0":
+            dev = -1                       # all workers share cuda:0 on purpose (functional runs over gloo)
+        keys = ["xm_ps_where/%d/%d" % (cls._choice, r) for r in range(world)]
+        store.set(keys[rank], ("%s|%d" % (socket.gethostname(), dev)).encode())
+        if not cls._wait_keys(store, keys):
+            return "torch"
+        where = [bytes(store.get(k)).decode() for k in keys]
+        distinct = len(set(where)) == world and all(not w.endswith("|-1") for w in where)
+        return "rccl-capi" if distinct else "torch"
 
     @classmethod
     def start_agreed(cls, backend="rccl-capi", force=False):
@@ -135,7 +185,8 @@ class ParameterServer:
         except Exception as e:   # noqa: BLE001 -- reported, then agreed on with the other workers
             print("ParameterServer(%s) failed to start: %s" % (backend, e), file=sys.stderr, flush=True)
             ok = 0
-        if backend != "torch" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # (the round runs whatever the backend: workers that were asked for different backends still meet here)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             store, world, rank = cls._store(), dist.get_world_size(), dist.get_rank()
             for phase in ("ok", "verdict"):
                 keys = ["xm_ps_%s/%d/%d" % (phase, gen, r) for r in range(world)]

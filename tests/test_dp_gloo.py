@@ -129,7 +129,18 @@ def _agree_worker(rank, world, port, out, fail="init@1"):
                 raise OSError("simulated: libxmodal_hip.so cannot be loaded")
             return fake
         _lib.load = load
-        fake.xm_comm_init = lambda raw, r, w: (ids.append(b"x"), 0)[1]
+
+        def blocking_init(raw, r, w):
+            # like ncclCommInitRank: returns only when EVERY rank has called it (round-5 advisor: with the immediate fake
+            # the test could not see healthy workers stuck in the bootstrap of a communicator the failed worker never joins)
+            from torch.distributed.distributed_c10d import _get_default_store
+            import datetime
+            st = _get_default_store()
+            st.set("fake_init/%d" % r, b"1")
+            st.wait(["fake_init/%d" % q for q in range(w)], datetime.timedelta(seconds=20))
+            ids.append(b"x")
+            return 0
+        fake.xm_comm_init = blocking_init
     train.ParameterServer.store_timeout_s = 30.0   # a lost key fails the test instead of hanging it
     try:
         ps = train.ParameterServer.start_agreed("rccl-capi")
