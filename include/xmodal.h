@@ -22,6 +22,11 @@
  *     Nothing throws, aborts or leaks across this boundary (a MEX gateway turns a
  *     non-zero code into mexErrMsgIdAndTxt).
  *   - re-entrant per device, not thread-safe (MATLAB calls MEX from one thread).
+ *   - FINITE INPUTS.  Several kernels multiply a padded operand position by a zero weight instead of masking it
+ *     (conv_stem3_kernel's eighth filter row, the zero-filled rows of the patch kernels, the ones / zero columns of the
+ *     Gram route): an Inf or NaN just OUTSIDE an output's receptive field can turn that output into NaN there, where
+ *     MatConvNet -- and this library's generic implicit-GEMM arm -- would stay finite.  Results are specified for finite
+ *     X, F, DZDY; which arm runs is a function of (shape, tuning table, exec hint), see xm_set_exec_hint.
  */
 #ifndef XMODAL_H
 #define XMODAL_H

@@ -153,8 +153,16 @@ def test_north_star_step_at_256_pairs(gpu, Z, M, monkeypatch):
     from mcncrossmodalemotions_amd import vl, zoo
     from test_gpu_nets_full import build_teacher
     N, W = 256, 300
-    if _host_memory_gb() < 96:
-        pytest.skip("the oracle's pass over 256 spectrograms keeps ~50 GB of activations: host has %.0f GB" % _host_memory_gb())
+    mem = _host_memory_gb()
+    if mem < 96:
+        # (round-5 review: no silent skip) the oracle's pass over 256 spectrograms keeps ~50 GB of activations.  A smaller
+        # host still runs the step at 128 pairs -- the eight-wave configuration, the >= 1024-tile rule and conv_dgrad_s2_kernel
+        # fire there as well (conv3: 1530 tiles, conv2's dgrad: 4736 blocks >= 6 rounds); only the >= 4096-column rule of the
+        # 3 x 3 patch filter derivative needs the full 256 -- and says so.
+        import warnings
+        N = 128
+        warnings.warn("test_north_star_step_at_256_pairs runs at 128 pairs: host has %.0f GB for the oracle (needs 96)" % mem)
+        assert mem >= 40, "host memory %.0f GB: not even the 128-pair oracle pass fits -- the north_star step is UNTESTED here" % mem
     teacher = build_teacher(Z, M, "se50", True, 300)
     teacher.move("gpu")
     teacher.mode = "test"
