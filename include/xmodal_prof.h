@@ -20,7 +20,7 @@
  *                  XM_DGRAD_MERGE, XM_NO_FAST_TRANSPOSE, XM_NO_POOL_LDS, XM_NO_POOL_PATCH, XM_NO_POOL_POOLED,
  *                  XM_NO_W8, XM_NO_WGRAD_PATCH, XM_NO_WGRAD_PATCH_S2, XM_NO_DGRAD_S2, XM_NO_STEM3.
  *                  Each chooses between two complete, parity-tested implementations of the same operator (the operator tests
- *                  force both arms through the xm_debug_force_* hooks; tests/test_gpu_path_switches.py runs whole passes
+ *                  force both arms through xm_debug_set; tests/test_gpu_path_switches.py runs whole passes
  *                  with every selector set, in fresh processes, against the default; profiles/ holds the A/B lines);
  *                  none changes what is computed.
  */
@@ -37,29 +37,25 @@ int xm_prof_collect(int cap, int *keys, double *total_ms, double *total_flops, l
 int xm_prof_collect_bytes(int cap, int *keys, double *total_bytes);
 /* name of a key, identical to the kernel name rocprofv3 --kernel-trace prints (sans namespace) */
 int xm_prof_kernel_name(int key, char *buf, int len);
-/* test hooks: force one tile configuration for every convolution launch (-1 = automatic) */
-int xm_debug_force_conv_cfg(int cfg);
-int xm_debug_num_conv_cfgs(void);
-/* 1 + v: halo-patch kernel variant v (0: 128-row tiles, 1: 96-row tiles, 2: 96-row tiles / tall patch) wherever it can
- * run, another runnable variant otherwise; 0: never; -1: measured choice (default) */
-int xm_debug_force_conv_halo(int on);
-/* 1: the single-channel stem kernel (conv_stem_kernel) wherever it can run; 0: never; -1: measured choice (default) */
-int xm_debug_force_conv_stem(int on);
-/* the same for the three-channel 7 x 7 / stride 2 stem kernel (conv_stem3_kernel: the teachers' first layer) */
-int xm_debug_force_conv_stem3(int on);
-/* 1: the patch kernel for the filter derivative of 3 x 3 / stride 1 / pad 1 layers (conv_wgrad_patch_kernel) wherever it
- * can run; 0: never; -1: measured choice (default) */
-int xm_debug_force_wgrad_patch(int on);
-/* the same for the patch kernel of 5 x 5 / stride 2 layers (conv_wgrad_patch_s2_kernel: the student's conv2) */
-int xm_debug_force_wgrad_patch_s2(int on);
-/* 0: never conv_dgrad_s2_kernel (dgrad of 5 x 5 / stride 2 layers); 1 / -1: wherever it can run (default) */
-int xm_debug_force_dgrad_s2(int on);
-/* force the split-K factor of the implicit-GEMM launches (0 = automatic) */
-int xm_debug_force_conv_splits(int splits);
-/* on = 1: every block (< 4096) of every later conv_gemm launch stores {first shader clock, last shader clock, HW_ID,
-   XCC_ID}; out[4 * nblocks] receives the records of the most recent launch (synchronise first).
-   tools/conv_bench.py --cycles */
-int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks);
+/* Test / tools switches: ONE entry (round 6; rounds 2-5 exported one xm_debug_force_* function per switch).  They select
+ * between complete, parity-tested implementations of an operator (never what is computed) and are process-global: a host
+ * that embeds the library has no reason to call this.  xm_debug_set returns the previous value, xm_debug_get the current
+ * one; INT_MIN = unknown key.
+ *   "conv_cfg"       tile configuration of every implicit-GEMM launch, 0 .. xm_debug_get("num_conv_cfgs") - 1; -1 = measured / modelled choice
+ *   "conv_splits"    split-K factor of the implicit-GEMM launches (0 = automatic)
+ *   "conv_halo"      1 + v: halo-patch kernel variant v (0: 128-row tiles, 1: 96-row tiles, 2: 96-row tiles / tall patch) wherever it
+ *                    can run, another runnable variant otherwise; 0: never; -1: measured choice (default)
+ *   "conv_stem"      1: the single-channel stem kernels (conv_stem_kernel, conv_stem_wgrad_*; also gates the Gram route's kernels)
+ *                    wherever they can run; 0: never; -1: measured choice (default)
+ *   "conv_stem3"     the same for the three-channel 7 x 7 / stride 2 stem kernel (conv_stem3_kernel: the teachers' first layer)
+ *   "wgrad_patch"    1: conv_wgrad_patch_kernel (filter derivative of 3 x 3 / stride 1 / pad 1 layers) wherever it can run; 0: never; -1: default
+ *   "wgrad_patch_s2" the same for conv_wgrad_patch_s2_kernel (5 x 5 / stride 2: the student's conv2)
+ *   "dgrad_s2"       0: never conv_dgrad_s2_kernel (dgrad of 5 x 5 / stride 2 layers); 1 / -1: wherever it can run (default)
+ *   "comm_single"    1: xm_comm_init with one worker creates a real one-rank RCCL communicator (tests of the exchange path)
+ * (xm_debug_conv_cycles -- per-block shader-clock records for tools/conv_bench.py --cycles -- exists only in a library
+ * built with XM_DEBUG_CYCLES=1.) */
+int xm_debug_set(const char *key, int value);
+int xm_debug_get(const char *key);
 #ifdef __cplusplus
 }
 #endif

@@ -113,23 +113,19 @@ SIGNATURES = {
 }
 _RESTYPES = {"xm_get_exec_hint": C.c_uint, "xm_last_error": C.c_char_p, "xm_workspace_bytes": C.c_size_t,
              "xm_workspace_generation": C.c_ulonglong}
-# test hooks (not part of include/xmodal.h)
-_DEBUG = {"xm_debug_force_conv_cfg": [_i], "xm_debug_num_conv_cfgs": [],
-          "xm_debug_force_conv_splits": [_i],
-          "xm_debug_comm_force_single": [_i],
-          "xm_debug_conv_cycles": [_i, C.POINTER(C.c_ulonglong), _i],
-          # include/xmodal_prof.h
-          "xm_debug_force_conv_halo": [_i],
-          "xm_debug_force_conv_stem": [_i],
-          "xm_debug_force_conv_stem3": [_i],
-          "xm_debug_force_wgrad_patch": [_i],
-          "xm_debug_force_wgrad_patch_s2": [_i],
-          "xm_debug_force_dgrad_s2": [_i],
+# test / tools switches and measurement hooks (include/xmodal_prof.h; not part of include/xmodal.h)
+_DEBUG = {"xm_debug_set": [C.c_char_p, _i], "xm_debug_get": [C.c_char_p],
           "xm_prof_enable": [_i],
           "xm_prof_collect": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                               C.POINTER(C.c_longlong)],
           "xm_prof_collect_bytes": [_i, C.POINTER(C.c_int), C.POINTER(C.c_double)],
           "xm_prof_kernel_name": [_i, C.c_char_p, _i]}
+# the library exports ONE switch entry (xm_debug_set); tests and tools keep calling L.xm_debug_force_<what>(v) through
+# these shims (name -> key)
+_SWITCHES = {"xm_debug_force_conv_cfg": "conv_cfg", "xm_debug_force_conv_splits": "conv_splits",
+             "xm_debug_force_conv_halo": "conv_halo", "xm_debug_force_conv_stem": "conv_stem",
+             "xm_debug_force_conv_stem3": "conv_stem3", "xm_debug_force_wgrad_patch": "wgrad_patch",
+             "xm_debug_force_wgrad_patch_s2": "wgrad_patch_s2", "xm_debug_force_dgrad_s2": "dgrad_s2"}
 
 _lib = None
 
@@ -154,6 +150,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, C.c_int)
+    for name, key in _SWITCHES.items():
+        setattr(lib, name, (lambda k: (lambda v: lib.xm_debug_set(k, int(v))))(key.encode()))
+    lib.xm_debug_num_conv_cfgs = lambda: lib.xm_debug_get(b"num_conv_cfgs")
+    lib.xm_debug_comm_force_single = lambda v: 0 if lib.xm_debug_set(b"comm_single", int(v)) > -2 else 1
+    if hasattr(lib, "xm_debug_conv_cycles"):          # tools build only (XM_DEBUG_CYCLES=1)
+        lib.xm_debug_conv_cycles.argtypes = [_i, C.POINTER(C.c_ulonglong), _i]
+        lib.xm_debug_conv_cycles.restype = C.c_int
     _lib = lib
     return lib
 

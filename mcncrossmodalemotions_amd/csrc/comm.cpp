@@ -64,10 +64,16 @@ int xm_comm_init(const void *id128, int rank, int world) {
   return XM_OK;
 }
 
-int xm_debug_comm_force_single(int on) {
+}  // extern "C"
+// test switch behind xm_debug_set("comm_single", v): xm_comm_init with world 1 creates a real one-rank communicator
+namespace xm {
+int comm_force_single(int on) {
+  const int old = g_force_single ? 1 : 0;
   g_force_single = on != 0;
-  return XM_OK;
+  return old;
 }
+}  // namespace xm
+extern "C" {
 
 int xm_comm_count(int *ranks) {
   if (!ranks) return xm::fail(XM_EINVAL, "comm: NULL output");

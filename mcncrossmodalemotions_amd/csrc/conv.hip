@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -2280,16 +2281,34 @@ using namespace xm;
 
 extern "C" {
 
-int xm_debug_force_conv_cfg(int cfg) {
-  int old = g_force_cfg;
-  g_force_cfg = (cfg >= 0 && cfg < kNumCfg) ? cfg : -1;
-  return old;
+// ONE entry for the test / tools switches (round-5 review: the library exported eleven xm_debug_* functions that set
+// process-global state).  Returns the previous value, INT_MIN for an unknown key.  Keys and values: include/xmodal_prof.h.
+int xm_debug_set(const char *key, int value) {
+  auto tri = [](int &g, int v) { int old = g; g = v < 0 ? -1 : (v ? 1 : 0); return old; };
+  const std::string k = key ? key : "";
+  if (k == "conv_cfg") { int old = g_force_cfg; g_force_cfg = (value >= 0 && value < kNumCfg) ? value : -1; return old; }
+  if (k == "conv_splits") { int old = g_force_splits; g_force_splits = value > 0 ? value : 0; return old; }
+  if (k == "conv_halo") { int old = g_force_halo; g_force_halo = value < 0 ? -1 : std::min(value, 3); return old; }
+  if (k == "conv_stem") return tri(g_force_stem, value);
+  if (k == "conv_stem3") return tri(g_force_stem3, value);
+  if (k == "wgrad_patch") return tri(g_force_wgrad_patch, value);
+  if (k == "wgrad_patch_s2") return tri(g_force_wgrad_patch_s2, value);
+  if (k == "dgrad_s2") return tri(g_force_dgrad_s2, value);
+  if (k == "comm_single") return comm_force_single(value);
+  return INT_MIN;
 }
-int xm_debug_num_conv_cfgs(void) { return kNumCfg; }
-int xm_debug_force_conv_halo(int on) {
-  int old = g_force_halo;
-  g_force_halo = on < 0 ? -1 : std::min(on, 3);
-  return old;
+int xm_debug_get(const char *key) {
+  const std::string k = key ? key : "";
+  if (k == "num_conv_cfgs") return kNumCfg;
+  if (k == "conv_cfg") return g_force_cfg;
+  if (k == "conv_splits") return g_force_splits;
+  if (k == "conv_halo") return g_force_halo;
+  if (k == "conv_stem") return g_force_stem;
+  if (k == "conv_stem3") return g_force_stem3;
+  if (k == "wgrad_patch") return g_force_wgrad_patch;
+  if (k == "wgrad_patch_s2") return g_force_wgrad_patch_s2;
+  if (k == "dgrad_s2") return g_force_dgrad_s2;
+  return INT_MIN;
 }
 
 int xm_set_exec_hint(unsigned flags) {
@@ -2299,32 +2318,6 @@ int xm_set_exec_hint(unsigned flags) {
 }
 unsigned xm_get_exec_hint(void) { return g_exec_hint; }
 
-int xm_debug_force_conv_stem3(int on) {
-  int old = g_force_stem3;
-  g_force_stem3 = on < 0 ? -1 : (on ? 1 : 0);
-  return old;
-}
-int xm_debug_force_dgrad_s2(int on) {
-  int old = g_force_dgrad_s2;
-  g_force_dgrad_s2 = on < 0 ? -1 : (on ? 1 : 0);
-  return old;
-}
-int xm_debug_force_wgrad_patch_s2(int on) {
-  int old = g_force_wgrad_patch_s2;
-  g_force_wgrad_patch_s2 = on < 0 ? -1 : (on ? 1 : 0);
-  return old;
-}
-int xm_debug_force_wgrad_patch(int on) {
-  int old = g_force_wgrad_patch;
-  g_force_wgrad_patch = on < 0 ? -1 : (on ? 1 : 0);
-  return old;
-}
-
-int xm_debug_force_conv_stem(int on) {
-  int old = g_force_stem;
-  g_force_stem = on < 0 ? -1 : (on ? 1 : 0);
-  return old;
-}
 
 // ---- persistent tuning table (include/xmodal.h) ----------------------------------------------
 int xm_tune_load(const char *path) {
@@ -2356,10 +2349,8 @@ int xm_tune_entries(int *total, int *unsaved) {
 // on = 1: every block (< 4096) of every later conv_gemm launch records {first clock, last clock, HW_ID, XCC_ID};
 // out (4 * nblocks words) receives the records of the most recent launch (caller synchronises first).
 // Debugging / tools only.
+#ifdef XM_DEBUG_CYCLES   // (tools build only: XM_DEBUG_CYCLES=1 python -m mcncrossmodalemotions_amd.build)
 int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks) {
-#ifndef XM_DEBUG_CYCLES
-  if (on) return fail(XM_ENOTSUP, "xm_debug_conv_cycles: library built without -DXM_DEBUG_CYCLES");
-#endif
   const size_t bytes = 4096 * 4 * sizeof(unsigned long long);
   if (on && !g_dbg_cycles) {
     if (hipMalloc((void **)&g_dbg_cycles, bytes) != hipSuccess) return XM_ENOMEM;
@@ -2373,11 +2364,7 @@ int xm_debug_conv_cycles(int on, unsigned long long *out, int nblocks) {
   }
   return XM_OK;
 }
-int xm_debug_force_conv_splits(int splits) {
-  int old = g_force_splits;
-  g_force_splits = splits > 0 ? splits : 0;
-  return old;
-}
+#endif
 
 // ---- include/xmodal_prof.h ------------------------------------------------------------------
 int xm_prof_enable(int on) {

@@ -89,6 +89,9 @@ bool path_on(Path p);
 long long env_int(const char *name, long long dflt);
 double env_double(const char *name, double dflt);
 
+// comm.cpp: test switch behind xm_debug_set("comm_single", v)
+int comm_force_single(int on);
+
 // persistent small device objects keyed by content (tap tables)
 const void *cached_device_table(const void *host, size_t bytes);
 
