@@ -2657,9 +2657,20 @@ int xm_nnconv_bnorm_relu_pool_forward(const float *x, int H, int W, int C, int N
   a.PI = g.Ho, a.PJ = g.Wo, a.pHo = pHo, a.pWo = pWo;
   a.NS = (pHo + 62) / 63;
   const int slots = 256 * XM_SF_OCC * 4;
-  // segments of window columns per (sample, strip, row tile): as many as fill ONE round of the resident waves (a second,
-  // partly filled round costs a whole one: 11 segments at 32 spectrograms = 2112 units for 2048 waves ran 285 us instead of 190)
-  a.SG = std::max(1, std::min(std::min(16, pWo), slots / (g.N * a.NS * 3)));
+  // segments of window columns per (sample, strip, row tile): the count that minimises (rounds of the resident waves) x
+  // (output columns of a unit, one of them computed twice per segment).  A partly filled last round costs a whole one:
+  // 11 segments at 32 spectrograms = 2112 units for 2048 waves ran 285 us, 10 segments 206 us; at 256 spectrograms one
+  // segment leaves a quarter of the waves idle and two make 1.5 rounds, four make exactly three.
+  {
+    const long long base = (long long)g.N * a.NS * 3;
+    long long best = -1;
+    a.SG = 1;
+    for (int sg = 1; sg <= std::min(16, pWo); ++sg) {
+      const long long rounds = (base * sg + slots - 1) / slots;
+      const long long cost = rounds * (2 * ((pWo + sg - 1) / sg) + 1);
+      if (best < 0 || cost < best) best = cost, a.SG = sg;
+    }
+  }
   a.nunits = g.N * a.NS * a.SG * 3;
   a.div3 = make_fastdiv(3u), a.divSG = make_fastdiv((uint32_t)a.SG), a.divNS = make_fastdiv((uint32_t)a.NS);
   a.gh0 = -g.pt, a.gw0 = -g.pl, a.LimH = g.H, a.LimW = g.W, a.xSampleStride = g.H * g.W;
