@@ -1,14 +1,15 @@
 #!/bin/bash
 # Evidence for profiles/<round>/ : run on the GPU box (gpurun), writes gpurun_out/<round>/.
 # usage: tools/collect_profiles.sh r02 [commit]
-R=${1:-r05}
+R=${1:-r06}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$R
 mkdir -p $O
 B="python bench.py"
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
+( time python -m pytest tests -q -m gpu --durations=8 ) 2>&1 | grep -E "passed|failed|error|^real|s call" | tail -14 > $O/pytest_gpu.txt
+python __graft_entry__.py smoke 2>&1 | grep smoke >> $O/pytest_gpu.txt
 $B                                                          | tail -1 > $O/bench_distill_n1.json
 $B --steps 20 --warmup 5 --no-cpu-baseline                  | tail -1 > $O/bench_distill_driver_flags_n1.json   # the driver's command line
 $B --serial --exec-hint 0 --no-cpu-baseline                 | tail -1 > $O/bench_distill_serial_n1.json   # the timed region's kernels on one stream
@@ -33,6 +34,10 @@ $B --teacher senet50 --width 400 --no-cpu-baseline --north-star 0 | tail -1 > $O
 $B --serial --teacher senet50 --per-gpu-batch 256 --no-cpu-baseline --no-roofline | tail -1 > $O/bench_distill_senet50_b256_serial_hint1.json
 # (the schedule / priority / variant A/Bs of rounds 3-4 are not repeated: profiles/r03, profiles/r04 hold them; this
 # round's kernel A/Bs -- run inside the round, each in one gpurun call -- are the *_bench.txt / dma_kernel_dissection.txt files)
+# round 6: the student's conv1 -> bn1 -> relu1 -> pool1 chain, composed operators against the Gram route
+for n in 32 64 256; do python tools/stem_chain_bench.py $n 2>&1 | grep -v amdgpu.ids; done > $O/stem_chain_bench.txt
+XM_NO_STEM_FWD=1 XM_NO_STEM_GRAM=1 $B --teacher senet50 --per-gpu-batch 256 --no-cpu-baseline --no-roofline | tail -1 > $O/bench_distill_senet50_b256_round5_stem.json   # the other arm: round-5 stem kernels
+XM_NO_STEM_FWD=1 XM_NO_STEM_GRAM=1 $B --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_round5_stem.json
 # per-kernel durations of the serial pass (what roofline.avg_launch_ms is compared with)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o run -- $B --serial --exec-hint 0 --no-cpu-baseline --steps 60 --warmup 10 \
     > $O/bench_under_rocprof.json 2> $O/rocprof_kt.log
