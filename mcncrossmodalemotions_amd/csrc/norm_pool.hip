@@ -571,8 +571,10 @@ pool_fwd_lds_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned
                     PoolGeo g, FastDiv divHo, int wob, size_t total, const float *__restrict__ bn_g,
                     const float *__restrict__ bn_b, const float *__restrict__ bn_mom, int C) {
   extern __shared__ float tile[];
-  const int plane = blockIdx.y;
-  const int wo0 = blockIdx.x * wob;
+  // (planes on grid.x: grid.y stops at 65535, and 256 filters x 256 spectrograms -- the student's pool2 at the north_star
+  // batch -- are 65536 planes: that one launch fell back to the one-thread-per-output kernel, 290 us instead of ~150)
+  const int plane = blockIdx.x;
+  const int wo0 = blockIdx.y * wob;
   const int nwo = min(wob, g.Wo - wo0);
   const int wlo = max(wo0 * g.sx - g.pl, 0);
   const int whi = min((wo0 + nwo - 1) * g.sx - g.pl + PW, g.W);
@@ -789,8 +791,7 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
     return XM_OK;
   }
   // LDS-staged kernel: max pooling, 3x3 window, planes large enough to fill a block, 16-byte aligned tensor
-  if (method == XM_POOL_MAX && ph == 3 && pw == 3 && ((uintptr_t)x & 15) == 0 && (long long)C * N <= 65535 &&
-      g.Ho * g.Wo >= 256 && path_on(kPathPoolLds)) {
+  if (method == XM_POOL_MAX && ph == 3 && pw == 3 && ((uintptr_t)x & 15) == 0 && g.Ho * g.Wo >= 256 && path_on(kPathPoolLds)) {
     const int maxcols = 16 * 256 / H;  // 16 KB of LDS per block: 10 blocks per CU, measured best of 8 / 16 / 32 / 64
     int wob = maxcols >= pw ? (maxcols - pw) / sx + 1 : 0;
     wob = std::min(wob, g.Wo);
@@ -800,7 +801,7 @@ static int pool_forward(const float *x, int H, int W, int C, int N, int ph, int 
       wob = (g.Wo + groups - 1) / groups;
       const int ncols = (wob - 1) * sx + pw;
       const size_t lds = ((size_t)ncols * H + 8) * sizeof(float);
-      hipLaunchKernelGGL((pool_fwd_lds_kernel<3, 3>), dim3(groups, C * N), dim3(256), lds, st, x, y, amax, g,
+      hipLaunchKernelGGL((pool_fwd_lds_kernel<3, 3>), dim3(C * N, groups), dim3(256), lds, st, x, y, amax, g,
                          make_fastdiv((uint32_t)g.Ho), wob, (size_t)H * W * C * N, bn_g, bn_b, bn_mom, C);
       XM_LAUNCH_CHECK();
       return XM_OK;

@@ -2,7 +2,7 @@
 """Regenerates profiles/README.md from the JSON / text evidence under profiles/<round>/.
 usage: python tools/make_profiles_readme.py r02"""
 import json, os, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(root, "profiles", R)
 def L(n): return json.loads(open(os.path.join(P, n + ".json")).read().strip().splitlines()[-1])
@@ -15,9 +15,15 @@ tor1, late = L("bench_distill_torch_1rank"), L("bench_distill_capi_late_init")
 w400, dw400, sh1, g2 = (L("bench_student_w400_n1"), L("bench_distill_senet50_w400_n1"), L("bench_distill_senet50_b256_serial_hint1"),
                         L("bench_distill_gpus2_gloo0"))
 tb = json.load(open(os.path.join(P, "pmc_traffic_senet50_b256.json")))
+o256, o32 = L("bench_distill_senet50_b256_round5_stem"), L("bench_distill_round5_stem")
+chain = open(os.path.join(P, "stem_chain_bench.txt")).read().strip().splitlines()
+ks256 = open(os.path.join(P, "kernel_stats_senet50_b256.txt")).read()
+def kus(name):
+    m_ = re.search(re.escape(name) + r".*?\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\n", ks256)
+    return float(m_.group(3)) if m_ else float("nan")
 ns = d.get("north_star_b256") or {}
 r, c = d["roofline"], d["cpu_baseline"]
-tests = open(os.path.join(P, "pytest_gpu.txt")).read().strip().splitlines()[-1]
+tests = [l for l in open(os.path.join(P, "pytest_gpu.txt")).read().strip().splitlines() if "passed" in l][-1]
 ks = open(os.path.join(P, "kernel_stats.txt")).read()
 m = re.search(re.escape(r["kernel"]) + r".*?\s(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\n", ks)
 rocavg = float(m.group(3)) if m else float("nan")
@@ -31,9 +37,11 @@ txt = f"""# profiles/ — measured evidence, round {int(R[1:])} (MI355X, 1 GPU, 
 
 Everything under `{R}/` (except the files marked "own gpurun call" below) comes from ONE `gpurun` call on a fresh MI355X box at commit `{meta.get('commit')}`:
 `bash tools/collect_profiles.sh {R} <commit>` (the script lists every command); this file is generated from
-those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r04/` are the previous rounds' evidence, unchanged (the schedule /
-priority / variant A/Bs of rounds 3-4 -- `r03/schedule_experiments.txt`, `r04/schedule_experiments.txt`, `phase_marks.txt`, `w8_bench.txt`,
-`halo_bench.txt`, `stem_bench.txt` ... -- were not repeated: no kernel they cover changed).
+those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r05/` are the previous rounds' evidence, unchanged (the schedule /
+priority / variant A/Bs of rounds 3-5 -- `r03/schedule_experiments.txt`, `r04/w8_bench.txt`, `r05/dma_kernel_dissection.txt`,
+`r05/wgrad_patch_s2_bench.txt` ... -- were not repeated: no kernel they cover changed).  The boxes of the pool differ by up to 4 % from call to
+call (this collection's box is a slow one: the round-5 kernels, run as the other arm IN THE SAME CALL, give {o256['value']} pairs/s on north_star's
+line where round 5's collection had 4344); every comparison below is same-call.
 
 | file | what |
 |---|---|
@@ -47,18 +55,16 @@ priority / variant A/Bs of rounds 3-4 -- `r03/schedule_experiments.txt`, `r04/sc
 | `{R}/bench_distill_senet50_n1.json` | the reference's default teacher (`run_distillation.m:82`): `--teacher senet50`, one face per pair |
 | `{R}/bench_distill_senet50_b256_n1.json`, `bench_distill_b256_n1.json` | north_star's batch 256 on ONE GPU (`--per-gpu-batch 256`), SE-ResNet-50 / ResNet-50 teacher |
 | `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
-| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only); re-taken in its own gpurun call at `c0d2e5a`+ after the oracle's default OpenMP team became min(physical cores, cgroup quota) for every use ({c1['value']} img/s on {c1['cpu_baseline']['cores']} threads; the collection's line, 256 threads under the 16-core quota: 10.0) |
+| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only): {c1['value']} img/s on {c1['cpu_baseline']['cores']} threads |
 | `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
 | `{R}/bench_distill_torch_1rank.json`, `bench_distill_capi_late_init.json` | the same single-rank run through `torch.distributed` ({tor1['value']} pairs/s), and with the library's communicator created AFTER the networks (`XM_PS_LATE=1`: {late['value']} pairs/s -- the call-order trap of `include/xmodal.h`) |
-| `{R}/bench_student_w400_n1.json`, `bench_distill_senet50_w400_n1.json` | round 5: the reference's REAL default shape -- `numSeconds = 4`, 512 x 400 spectrograms (`run_distillation.m:74`): student at batch 64 ({w400['value']} samples/s = {pct(w400['value'] * 22.33 / 1e3 / 157.3)} of peak at 22.33 GFLOP per sample; the line's own fraction field still used the W = 300 FLOPs, fixed after the collection) and the SE-ResNet50 distillation step ({dw400['value']} pairs/s) |
-| `{R}/bench_distill_senet50_b256_serial_hint1.json` | round 5: north_star's batch on ONE stream with the host's `XM_EXEC_SINGLE_STREAM` hint (what a MATLAB / MEX host runs): {sh1['value']} pairs/s ({sh1['ms_per_step']} ms) against {se256['value']} two-stream |
-| `{R}/bench_distill_gpus2_gloo0.json` | `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it: the command starts its two ranks itself (both on this box's one GPU, exchange over gloo: a functional run of the N > 1 path; `n_gpus` 2, `world` {g2.get('world')}, `rccl_ranks` {g2.get('rccl_ranks')} -- no RCCL communicator carried that exchange --, `control_group` {g2.get('control_group')}; the throughput means nothing) |
-| `{R}/wgrad_patch_s2_bench.txt` | round 5 (own gpurun calls, commit `736abaa`): conv2's filter derivative, generic kernel against `conv_wgrad_patch_s2_kernel<5, 2>` (DESIGN.md 2.1h) at 32 / 64 / 256 spectrograms, and the steps with the old kernels / + this kernel / + the 3 x 3 patch kernel from 4096 output columns; one stream against two at batch 256 |
-| `{R}/dgrad_s2_bench.txt` | round 5 (own gpurun call, commit `37160fb` before the launch-size rule): conv2's dgrad, merged stride-parity launch against `conv_dgrad_s2_kernel` forced at every batch (DESIGN.md 2.1i) |
-| `{R}/stem3_bench.txt` | round 5 (own gpurun calls, AFTER the collection: commit `abf5347`): the teachers' conv1 through the implicit GEMM and through `conv_stem3_kernel` (DESIGN.md 2.1k) at 32 / 128 / 256 faces, the steps with and without it, the kernel without its stores, with a start offset between the two blocks of a CU |
-| `{R}/dma_kernel_dissection.txt` | round 5 (own gpurun call, timing-only builds on `213741a`): per-layer table of the SE-ResNet50 at 256 faces, every tile configuration on the three 1 x 1 shapes, `conv_gemm_dma_kernel` without its A loads / B loads / epilogue / MFMAs, grid and ring variants; per-layer table of the student at 256 (DESIGN.md 2.1j) |
-| `{R}/deferred_stores_and_halo64.txt` | round 5 (own gpurun call; built, parity-green, measured, not kept): the LDS-DMA kernel with its epilogue stores spread over the next tile, a 64-row halo-patch variant for the res2 3 x 3 layers, and the steps with both (DESIGN.md 2.1j) |
-| `{R}/pmc_summary_senet50_b256.txt`, `pmc_traffic_senet50_b256.json` | round 5: the three PMC passes on north_star's batch: `conv_dgrad_s2_kernel` WRITE {tb['xm::conv_dgrad_s2_kernel<1>']['write_bytes']/1e6:.0f} MB per launch for 904 MB of dX (the merged launch: 2.1 x), `conv_wgrad_patch_s2_kernel` FETCH x 2 {tb['xm::conv_wgrad_patch_s2_kernel<5, 2>']['fetch_bytes_x2']/1e6:.0f} MB for 1489 MB of x + dY (the generic kernel: 4.2 x) |
+| `{R}/bench_student_w400_n1.json`, `bench_distill_senet50_w400_n1.json` | the reference's REAL default shape -- `numSeconds = 4`, 512 x 400 spectrograms (`run_distillation.m:74`): student at batch 64 ({w400['value']} samples/s = {pct(w400['model_frac_of_fp32_mfma_peak'])} of peak at 22.33 GFLOP per sample: re-taken with the fixed FLOP count) and the SE-ResNet50 distillation step ({dw400['value']} pairs/s) |
+| `{R}/bench_distill_senet50_b256_serial_hint1.json` | north_star's batch on ONE stream with the host's `XM_EXEC_SINGLE_STREAM` hint (what a MATLAB / MEX host runs): {sh1['value']} pairs/s ({sh1['ms_per_step']} ms) against {se256['value']} two-stream |
+| `{R}/bench_distill_gpus2_gloo0.json` | `XM_DEBUG_DIST=gloo0 python bench.py --gpus 2` with NO launcher around it (both ranks on this box's one GPU, exchange over gloo: a functional run of the N > 1 path; `n_gpus` 2, `world` {g2.get('world')}, `rccl_ranks` {g2.get('rccl_ranks')}, `control_group` {g2.get('control_group')}; the 8-rank run is `tests/test_bench_launch.py::test_gpus_8_functional_run_on_one_gpu`) |
+| `{R}/stem_chain_bench.txt` | round 6 (DESIGN.md 2.4): the student's conv1 -> bn1 -> relu1 -> pool1 chain at 32 / 64 / 256 spectrograms, composed operators (round-5 kernels) against the Gram route, forward and backward, per launch on an idle device |
+| `{R}/bench_distill_senet50_b256_round5_stem.json`, `bench_distill_round5_stem.json` | the other arm in the same call (`XM_NO_STEM_FWD=1 XM_NO_STEM_GRAM=1`: the round-5 stem kernels): north_star line {o256['value']} pairs/s ({o256['ms_per_step']} ms) against {se256['value']} ({se256['ms_per_step']} ms); default line {o32['value']} ({o32['ms_per_step']} ms) against {d['value']} ({d['ms_per_step']} ms) |
+| `{R}/stem_chain_dissection.txt` | round 6 (own gpurun calls on the way): the six versions of `conv_stem_wgrad_pool_kernel` and the forward kernel with parts switched off -- what bounded each version (DESIGN.md 2.4) |
+| `{R}/pmc_summary_senet50_b256.txt`, `pmc_traffic_senet50_b256.json` | the three PMC passes on north_star's batch: `conv_stem_bnpool_fwd_kernel` WRITE {tb['xm::conv_stem_bnpool_fwd_kernel']['write_bytes']/1e6:.0f} MB per launch for 1151 MB of pooled output + table, `conv_stem_wgrad_pool_kernel` FETCH x 2 {tb['xm::conv_stem_wgrad_pool_kernel<2, false>']['fetch_bytes_x2']/1e6:.0f} MB for 1151 MB of pooled derivative + table + 157 MB of input (the round-5 chain moved 15.2 GB) |
 | `{R}/kernel_stats_senet50_b256.txt` | rocprofv3 per-kernel summary of north_star's configuration (SE-ResNet50 teacher, 256 pairs, serial mode) |
 | `{R}/pmc_summary.txt`, `{R}/pmc_traffic.json` | `rocprofv3 --pmc` passes (SQ counters; FETCH_SIZE; WRITE_SIZE — three separate runs, kernel trace only), per-launch averages per kernel (`tools/pmc_table.py`); `bench.py` reads `roofline.traffic` (+ the commit) from the JSON |
 
@@ -98,20 +104,20 @@ priority / variant A/Bs of rounds 3-4 -- `r03/schedule_experiments.txt`, `r04/sc
 | 8f-1: 13 frames/pair, SE-ResNet50 teacher + student step | 32 pairs (416 faces) | {mf['value']} pairs/s | {mf['ms_per_step']} | {pct(mf['model_frac_of_fp32_mfma_peak'])} |
 | 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
-Round 4 -> round 5 (`r04/` -> `{R}/`, both builder-run on boxes of the same pool, which differ by 1-2 %): default line 3951 -> {d['value']} pairs/s;
-north_star batch 256 (SE-ResNet50) 4257 -> {se256['value']} (`north_star_b256` on the default line: 4260 -> {ns.get('value')} = {pct(ns.get('model_frac') or 0)}); batch 256 with the
-ResNet-50 teacher 4334 -> {r256['value']} ({pct(r256['model_frac_of_fp32_mfma_peak'])}); student batch 64: 5866 -> {st['value']}; config-5 shard 1851 -> {jo['value']}; config 3 12083 -> {te['value']} (no kernel of
-that path changed).  Where it came from (DESIGN.md 2.1h, 2.1i): conv2's filter derivative from an LDS patch (`conv_wgrad_patch_s2_kernel`: 114 -> 125 TFLOP/s
-at 256 spectrograms, 101 -> 113 at 32), conv2's dgrad with both row parities per wave and whole-line stores (`conv_dgrad_s2_kernel`: 115 -> 124 at 256; taken
-from 6 rounds of blocks), the 3 x 3 patch filter derivative also for launches of >= 4096 output columns.  At batch 256 every kernel fills the chip: one
-stream {sh1['ms_per_step']} ms against {se256['ms_per_step']} ms on two, and a kernel's own gain arrives 1 : 1; at 32 pairs the two-stream step is work-conserving and the side
-stream's kernels are off the critical path ({ds['ms_per_step']} ms on one stream -> {d['ms_per_step']} ms overlapped), which is why the default line moved by less than the
-boxes differ.  What was measured and NOT kept (DESIGN.md 2.1j): deferred epilogue stores in the LDS-DMA kernel, a 64-row halo variant, fewer
-persistent DMA blocks per CU, a lower eight-wave threshold, register-double-buffered fragments in the patch kernel, a finer decomposition of the
-dgrad kernel.  Added after the collection (commit `abf5347`, `stem3_bench.txt`): `conv_stem3_kernel` for the teachers' first layer (72-75 -> 82-84 TFLOP/s
-at 256 faces; north_star step - 0.1 ms) and the tuning-table entries that select it.
-`cpu_baseline`: the OpenMP team is now sized by min(affinity, cgroup CPU quota) -- {c['cores']} threads under a quota of {c.get('quota')} cores on this box:
-{c['value']} pairs/s, min {c.get('min')} / max {c.get('max')} (round 4: 128 threads under the same quota, 1.5 ... 3.6 pairs/s from box to box).
+Round 5 -> round 6, same call (the round-5 stem kernels are the `XM_NO_STEM_FWD=1 XM_NO_STEM_GRAM=1` arm): north_star's line {o256['value']} -> **{se256['value']} pairs/s
+({o256['ms_per_step']} -> {se256['ms_per_step']} ms, {pct(se256['value'] / o256['value'] - 1)} more)**, default line {o32['value']} -> {d['value']} ({pct(d['value'] / o32['value'] - 1)} more).  On the boxes the A/Bs of the round ran on
+(`stem_chain_dissection.txt`, DESIGN.md section 6) the same pair was 4290 -> 4440 ... 4501 pairs/s (66.4 -> 68.7 ... 69.7 %) and 3945 -> 4047.  Where it comes from
+(DESIGN.md 2.4): conv1's output -- 3.7 GB at 256 spectrograms -- is no longer a tensor.  In the serial pass (`kernel_stats_senet50_b256.txt`):
+`stem_gram_kernel` {kus('stem_gram_kernel<2>'):.0f} us + `conv_stem_bnpool_fwd_kernel` {kus('conv_stem_bnpool_fwd_kernel'):.0f} us + `conv_stem_wgrad_pool_kernel` {kus('conv_stem_wgrad_pool_kernel<2, false>'):.0f} us (+ 40 us of reductions) where round 5 had
+`conv_stem_kernel` 1489 + `pool_fwd_lds_kernel` ~1000 + `bnpool_bwd_partial_pooled_kernel` ~500 + `conv_stem_wgrad_bnp_kernel` 2125 us.
+Per launch on an idle device (`stem_chain_bench.txt`):
+```
+{chr(10).join(l for l in chain if l.startswith('N='))}
+```
+Student alone at batch 64: 5938 -> {st['value']} samples/s ({pct(st['model_frac_of_fp32_mfma_peak'])}); width 400: 4215 -> {w400['value']}; config-5 shard {jo['value']} pairs/s ({pct(jo['model_frac_of_fp32_mfma_peak'])}; only its student half
+changed); config 3 {te['value']} img/s (no kernel of that path changed).
+`cpu_baseline`: the OpenMP team is sized by min(affinity, cgroup CPU quota) -- {c['cores']} threads under a quota of {c.get('quota')} cores on this box:
+{c['value']} pairs/s, min {c.get('min')} / max {c.get('max')}.
 
 ## How the numbers were taken
 ```
