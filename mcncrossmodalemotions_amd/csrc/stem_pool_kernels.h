@@ -799,9 +799,14 @@ conv_stem_bnpool_fwd_kernel(const StemFwdArgs a) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
+        // (an opaque zero per tile pair: without it the seven filter fragments of the row tile are hoisted out of the unit's
+        // column loop -- 28 registers held for the whole unit in a kernel that sits on its register limit)
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        const f32x4 *const paw = pa + zero;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          const f32x4 af = pa[v * TM * 64];
+          const f32x4 af = paw[v * TM * 64];
           const int slot = (2 * r + v) % 7;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
