@@ -40,8 +40,8 @@ Everything under `{R}/` (except the files marked "own gpurun call" below) comes 
 those files by `tools/make_profiles_readme.py {R}`.  `r01/` ... `r05/` are the previous rounds' evidence, unchanged (the schedule /
 priority / variant A/Bs of rounds 3-5 -- `r03/schedule_experiments.txt`, `r04/w8_bench.txt`, `r05/dma_kernel_dissection.txt`,
 `r05/wgrad_patch_s2_bench.txt` ... -- were not repeated: no kernel they cover changed).  The boxes of the pool differ by up to 4 % from call to
-call (this collection's box is a slow one: the round-5 kernels, run as the other arm IN THE SAME CALL, give {o256['value']} pairs/s on north_star's
-line where round 5's collection had 4344); every comparison below is same-call.
+call (the round-5 kernels, run as the other arm IN THE SAME CALL, give {o256['value']} pairs/s on north_star's line here, 4115 on the box of this
+round's first collection at `e4e1a38`, 4344 in round 5's collection); every comparison below is same-call.
 
 | file | what |
 |---|---|
@@ -105,8 +105,7 @@ line where round 5's collection had 4344); every comparison below is same-call.
 | 1: ResNet50 fwd + heads, batch 32, CPU restatement | 32 | {c1['value']} img/s | {c1['ms_per_step']} | n/a |
 
 Round 5 -> round 6, same call (the round-5 stem kernels are the `XM_NO_STEM_FWD=1 XM_NO_STEM_GRAM=1` arm): north_star's line {o256['value']} -> **{se256['value']} pairs/s
-({o256['ms_per_step']} -> {se256['ms_per_step']} ms, {pct(se256['value'] / o256['value'] - 1)} more)**, default line {o32['value']} -> {d['value']} ({pct(d['value'] / o32['value'] - 1)} more).  On the boxes the A/Bs of the round ran on
-(`stem_chain_dissection.txt`) the same pair was 4290 -> 4440 ... 4501 pairs/s (66.4 -> 68.7 ... 69.7 %) and 3945 -> 4047.  Where it comes from
+({o256['ms_per_step']} -> {se256['ms_per_step']} ms, {pct(se256['value'] / o256['value'] - 1)} more)**, default line {o32['value']} -> {d['value']} ({pct(d['value'] / o32['value'] - 1)} more).  `stem_step_ab.txt` has the same pair on the other boxes the round touched.  Where it comes from
 (DESIGN.md 2.4): conv1's output -- 3.7 GB at 256 spectrograms -- is no longer a tensor.  In the serial pass (`kernel_stats_senet50_b256.txt`):
 `stem_gram_kernel` {kus('stem_gram_kernel<2>'):.0f} us + `conv_stem_bnpool_fwd_kernel` {kus('conv_stem_bnpool_fwd_kernel'):.0f} us + `conv_stem_wgrad_pool_kernel` {kus('conv_stem_wgrad_pool_kernel<2, false>'):.0f} us (+ 40 us of reductions) where round 5 had
 `conv_stem_kernel` 1489 + `pool_fwd_lds_kernel` ~1000 + `bnpool_bwd_partial_pooled_kernel` ~500 + `conv_stem_wgrad_bnp_kernel` 2125 us.
