@@ -1853,7 +1853,6 @@ template <int SY, int ONES>
 __global__ void __launch_bounds__(256, 2)
 conv_stem_wgrad_bnp_kernel(const StemWgradArgs a, const int ntiles) {
   constexpr int TM = 3, NV = kStemNV, HW = kStemHW, GRP = NV * HW, WPATCH = 2 * GRP + 4, TP = kStemWgTP;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
   for (int i = t; i < 4 * kStemWgWave / 4 + 1; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2513,7 +2512,6 @@ conv_wgrad_patch_kernel(const WgradPatchArgs a) {
   constexpr int HP = HH / 2;                                                // pixel pairs per column
   constexpr int NLA = (BM * HP + 255) / 256, NLB = (NCHN * 3 * HP + 255) / 256;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float smem[2 * STG];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5, l31 = lane & 31;
   const int wm = wave & 1, wn = wave >> 1;

@@ -17,12 +17,12 @@
 // Numerics (tools-free check on the host, 2 spectrograms, fp32 partial sums per ~9 k pixels then fp64): 1.5e-7 of the
 // largest filter-derivative entry from the fp64 composition; the Gram route to the batch moments: sigma to 2e-8.
 //
-// dz is built in LDS by SCATTER from the pooled side: a pooled element (channel, ph, pw) with routing code dh + 3 dw lands
-// on conv pixel (2 ph + dh, 2 pw + dw) -- each pooled element is touched once per candidate column instead of every conv
-// pixel testing its <= 2 x 2 covering windows (conv_stem_wgrad_bnp_kernel: 48 pooled vector-memory instructions per wave
-// and 32 pixels, each fetching 12 + 4 bytes per lane; here 16-byte loads of whole pooled columns).  ds_add_f32 from one
-// wave executes in program order and lanes of one instruction never share a target (their pooled rows are >= 4 apart),
-// so the sum of the <= 4 contributions to a pixel has a fixed order.
+// dz is never a tensor: conv_stem_wgrad_pool_kernel composes it on chip from the pooled side -- a pooled element
+// (channel, ph, pw) with routing code dh + 3 dw lands on conv pixel (2 ph + dh, 2 pw + dw); each pooled element is loaded
+// once per candidate column as part of a 16-byte quad of its pooled column (conv_stem_wgrad_bnp_kernel, the round-5 kernel:
+// 48 pooled vector-memory instructions per wave and 32 pixels, each fetching 12 + 4 bytes per lane) and the <= 4
+// contributions to a pixel are added in registers in a fixed order.  The forward half of the layer
+// (conv_stem_bnpool_fwd_kernel, second part of this file) writes the pooled output and the table without writing x either.
 #pragma once
 #include "conv_kernels.h"
 
@@ -30,7 +30,7 @@ namespace xm {
 
 struct StemPoolArgs {
   const float *X;                    // the convolution's input [H][W][1][N]
-  float *part;                       // gram: [grid][64][64], wgrad: [grid][96][64]
+  float *part;                       // gram: [grid][64][64], wgrad: [logical wave][32][64]
   int M, R, nU, nV;                  // filters, taps (nU * nV), filter rows / columns
   int PI, PJ;                        // output pixel grid
   FastDiv divJG, divG;               // stem_gram_kernel: (column pairs) * (256-row groups), 256-row groups: block unit -> (sample, pair, group)
@@ -56,9 +56,7 @@ constexpr int kSpHW = 168;                    // row pitch of a source column in
 constexpr int kSpNC = 9;                      // source columns under two output columns (stride 2: 7 + 2)
 constexpr int kSpPatch = kSpNC * kSpHW + 4;   // floats of a wave's source patch + a dummy unit
 constexpr int kSpTP = 36;                     // row pitch (floats) of a dz region: 32 pixels + 4
-constexpr int kSpWave = 2 * kSpPatch + 32 * kSpTP;   // two patches (the next unit's is written while the current one is read) + the dz region
 constexpr int kSpCst = 64;                    // 32 ones + 32 zeros: what the B lanes of the ones column / the padding columns read
-constexpr int kSpSmem = (4 * kSpWave + kSpCst) * 4;      // bytes per block of conv_stem_wgrad_pool_kernel (67 KB: two blocks per CU)
 constexpr int kSpGramSmem = (4 * kSpPatch + kSpCst > 64 * 64 ? 4 * kSpPatch + kSpCst : 64 * 64) * 4;   // bytes per block of stem_gram_kernel
 
 struct SpUnit {
@@ -244,27 +242,27 @@ stem_gram_reduce_kernel(const float *__restrict__ part, double *__restrict__ gra
   }
 }
 
-// ---- A = dz P~ with dz scattered from the pooled derivative ---------------------------------------------------------------
+// ---- A = dz P~ with dz composed from the pooled derivative -----------------------------------------------------------------
 // A WAVE owns one row tile of 32 filters (rt = logical wave index % 3, fixed for the kernel: its 32 accumulator registers
 // hold its share of A for the whole launch) and walks (sample, column pair jp, 64-row chunk pair cp) units.  Per unit it
 // loads, for window columns p = 0: jp - 1 and p = 1: jp, the 32 window rows [32 cp, 32 cp + 32) of its 64 output rows as
 // 16-byte quads (lane -> filter lane / 4 (+ 16), quad lane % 4 of chunk h) -- pooled derivative, routing codes and (GATE)
-// the pooled forward output -- plus the single window row 32 cp - 1 in front (lanes 0-31: p = 0, lanes 32-63: p = 1).  A
-// quad that would reach past its pooled column is shifted back (no load leaves the tensor) and its first `shift` elements
-// are ignored.  The derivatives are gated once and stay in registers for the four (column, chunk) steps of the unit; each
-// step zero-fills the wave's dz region [32 filters][32 pixels], scatters the elements whose code names this column (dw) with
-// ds_add_f32 -- window row r of the chunk lands on pixel 2 r + dh; row 15 with dh = 2 on pixel 0 of the NEXT chunk -- and
-// multiplies: 32 MFMAs per step.  Output column 2 jp takes dw = 0 of window column jp and dw = 2 of jp - 1; column
-// 2 jp + 1 takes dw = 1 of jp.  The next unit's operands and patch are requested under the last step's MFMAs.
-// (Second version: 96 accumulators per wave and the row tiles as an inner loop left two waves per SIMD whose load, scatter
-// and MFMA phases simply added up -- 1.8 ms at 256 spectrograms with every phase under 1 ms alone.  A third of the
-// registers per wave = three waves per SIMD to fill each other's phases.)
+// the pooled forward output -- plus the single window row 32 cp - 1 in front (lanes with lane % 4 == 0: p = 0, == 1: p = 1).
+// A quad that would reach past its pooled column reads the head of the next one (masked); in the last column of the tensor
+// it is shifted back (no load leaves the tensor) and re-aligned after the load.  The derivatives are gated once and stay in
+// registers for the four (column, chunk) steps of the unit; each step composes the wave's dz region [32 filters][32 pixels]
+// in registers (compose_slice below), stores it with two 16-byte LDS stores per filter and multiplies: 32 MFMAs per step.
+// Output column 2 jp takes dw = 0 of window column jp and dw = 2 of jp - 1; column 2 jp + 1 takes dw = 1 of jp.  The next
+// unit's operands and source patch are requested a whole unit ahead; the patch is parked in LDS behind the unit's last B
+// reads (LDS operations of a wave execute in order, no barrier in the loop).
+// (Earlier versions, profiles/r06/stem_chain_dissection.txt: 96 accumulators per wave with the row tiles as an inner loop;
+// three waves per SIMD; scatter with ds_add_f32 into a zero-filled region -- each slower)
 // GATE: the ReLU gate is taken from y_pool (> 0); false: the table marks closed windows itself (code 255, as
 // conv_stem_bnpool_fwd_kernel writes it) and y_pool is not read.
 // Logical wave index: XCD x (blocks b % 8 == x) holds a contiguous range, so that the waves that work on neighbouring
 // units at the same time -- and share pooled lines and source columns -- share an L2.
-constexpr int kSp3Wave = 2 * kSpPatch + 32 * kSpTP;      // two patches (the next unit's is parked while the current one is read) + the dz region
-constexpr int kSp3Smem = (4 * kSp3Wave + kSpCst) * 4;    // 67 KB per block: two blocks per CU
+constexpr int kSp3Wave = kSpPatch + 32 * kSpTP;          // a wave's source patch + its dz region
+constexpr int kSp3Smem = (4 * kSp3Wave + kSpCst) * 4;    // 43 KB per block (two blocks per CU: 229 registers per lane)
 template <int SY, bool GATE>
 __global__ void __launch_bounds__(256, 2)
 conv_stem_wgrad_pool_kernel(const StemPoolArgs a, const int nunits) {
@@ -287,7 +285,6 @@ conv_stem_wgrad_pool_kernel(const StemPoolArgs a, const int nunits) {
   const int pHW = a.pHo * a.pWo;
   const int cl = lane >> 2, qd = lane & 3;
   const bool mok[2] = {32 * rt + cl < a.M, 32 * rt + 16 + cl < a.M};      // filters that do not exist: nothing is routed
-  const bool emok = 32 * rt + l31 < a.M;
 
   auto unit_of = [&](int u) {
     SpUnit c;
@@ -675,7 +672,7 @@ constexpr int kSfPlane = 68;                      // floats per phase plane: 64 
 constexpr int kSfSlot = 4 * kSfPlane;             // a source column of the ring
 constexpr int kSfRing = 7 * kSfSlot;              // floats per wave
 constexpr int kSfA = kStemNV * 3 * 2 * 32 * 4;    // the folded filter bank in MFMA operand order (conv_stem_kernel's sA)
-constexpr int kSfSmem = (kSfA + 4 * kSfRing) * 4; // bytes per block (51.9 KB: three blocks per CU)
+constexpr int kSfSmem = (kSfA + 4 * kSfRing) * 4; // bytes per block (51.9 KB; XM_SF_OCC blocks per CU: 227 registers per lane)
 
 #ifndef XM_SF_OCC
 #define XM_SF_OCC 2
