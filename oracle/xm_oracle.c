@@ -225,6 +225,25 @@ static void gemm_tn_acc(int R, int N, int P, const float *A, int lda, const floa
 }
 
 /* ------------------------------------------------------------------ */
+/* fp64-accumulate helpers of vl_nnconv's acc64 path                    */
+/* ------------------------------------------------------------------ */
+/* The acc64 loops are the same sums as the fp32 path with double accumulators.  They are arranged so that the
+ * innermost loop runs over the output ROW (ho) -- independent accumulators, contiguous memory -- instead of one
+ * dependent chain per output element: the 256-spectrogram checks of tests/test_gpu_bench_sizes.py spent minutes
+ * in a chain that retires one multiply-add per floating-point latency.  Forward and dX keep, per output element, exactly
+ * the order of additions of the element-at-a-time loops they replace ((c, v, u) / (k, v, u) ascending; every product
+ * of two floats is exact in double, so fused or separate multiply-add round alike): bit-identical results.  dF keeps
+ * eight interleaved partial sums per filter element -- still fp64 throughout, the order is fixed. */
+
+/* rows ho of an output column whose source row hi = ho * s + off lies in [0, H): [*lo, *hi] (empty if *lo > *hi) */
+static void row_range(int off, int s, int H, int Ho, int *lo, int *hi) {
+  *lo = off >= 0 ? 0 : (-off + s - 1) / s;
+  int top = H - 1 - off;
+  *hi = top < 0 ? -1 : top / s;
+  if (*hi > Ho - 1) *hi = Ho - 1;
+}
+
+/* ------------------------------------------------------------------ */
 /* vl_nnconv                                                           */
 /* ------------------------------------------------------------------ */
 
@@ -313,28 +332,62 @@ int orc_nnconv_forward(const float *x, int H, int W, int C, int N, const float *
   size_t P = (size_t)Ho * Wo;
   int R = FH * FW * FC;
   if (acc64) {
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int n = 0; n < N; ++n)
-      for (int k = 0; k < K; ++k) {
-        int g = k / Kg;
-        for (int wo = 0; wo < Wo; ++wo)
-          for (int ho = 0; ho < Ho; ++ho) {
-            double acc = b ? (double)b[k] : 0.0;
+    int failed = 0;
+    int lo_u[FH], hi_u[FH]; /* rows of an output column that filter row u reaches inside the image */
+    for (int u = 0; u < FH; ++u) row_range(u * dy - pt, sy, H, Ho, &lo_u[u], &hi_u[u]);
+    /* four filters of a group share every source row they read (one load + conversion, four multiply-adds) */
+    const int KB = (Kg % 4 == 0) ? 4 : 1, nkb = K / KB;
+#pragma omp parallel
+    {
+      double *acc = (double *)malloc(sizeof(double) * (size_t)Ho * 4);
+      if (!acc) {
+#pragma omp atomic write
+        failed = 1;
+      }
+#pragma omp for collapse(2) schedule(static)
+      for (int n = 0; n < N; ++n)
+        for (int kb = 0; kb < nkb; ++kb) {
+          if (!acc) continue;
+          const int k0 = kb * KB, g = k0 / Kg;
+          double *a0 = acc, *a1 = acc + Ho, *a2 = acc + 2 * (size_t)Ho, *a3 = acc + 3 * (size_t)Ho;
+          for (int wo = 0; wo < Wo; ++wo) {
+            for (int j = 0; j < KB; ++j) {
+              const double b0 = b ? (double)b[k0 + j] : 0.0;
+              for (int ho = 0; ho < Ho; ++ho) acc[(size_t)Ho * j + ho] = b0;
+            }
             for (int c = 0; c < FC; ++c)
               for (int v = 0; v < FW; ++v) {
                 int wi = wo * sx - pl + v * dx;
                 if (wi < 0 || wi >= W) continue;
+                const float *xc = x + XI(0, wi, g * FC + c, n, H, W, C);
                 for (int u = 0; u < FH; ++u) {
-                  int hi = ho * sy - pt + u * dy;
-                  if (hi < 0 || hi >= H) continue;
-                  acc += (double)x[XI(hi, wi, g * FC + c, n, H, W, C)] *
-                         (double)f[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))];
+                  const int off = u * dy - pt, lo = lo_u[u], hi = hi_u[u];
+                  const size_t fi = (size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k0));
+                  const double f0 = (double)f[fi];
+                  if (KB == 4) {
+                    const double f1 = (double)f[fi + (size_t)R], f2 = (double)f[fi + 2 * (size_t)R],
+                                 f3 = (double)f[fi + 3 * (size_t)R];
+                    for (int ho = lo; ho <= hi; ++ho) {
+                      const double xv = (double)xc[ho * sy + off];
+                      a0[ho] += xv * f0;
+                      a1[ho] += xv * f1;
+                      a2[ho] += xv * f2;
+                      a3[ho] += xv * f3;
+                    }
+                  } else {
+                    for (int ho = lo; ho <= hi; ++ho) a0[ho] += (double)xc[ho * sy + off] * f0;
+                  }
                 }
               }
-            y[XI(ho, wo, k, n, Ho, Wo, K)] = (float)acc;
+            for (int j = 0; j < KB; ++j) {
+              float *yc = y + XI(0, wo, k0 + j, n, Ho, Wo, K);
+              for (int ho = 0; ho < Ho; ++ho) yc[ho] = (float)acc[(size_t)Ho * j + ho];
+            }
           }
-      }
-    return 0;
+        }
+      free(acc);
+    }
+    return failed ? -2 : 0;
   }
   size_t chunk = chunk_images(P * R, N);
   float *col = scratch_get(P * R * chunk);
@@ -399,37 +452,67 @@ int orc_nnconv_backward(const float *x, int H, int W, int C, int N, const float 
     }
   }
   if (acc64) {
+    int lo_u[FH], hi_u[FH]; /* rows of an output column that filter row u reaches inside the image */
+    for (int u = 0; u < FH; ++u) row_range(u * dy - pt, sy, H, Ho, &lo_u[u], &hi_u[u]);
     if (dfo) {
+      /* per filter element eight interleaved partial sums run over ALL (sample, output column) rows and are added once at
+         the end: lane j takes the rows' elements lo + j, lo + j + 8, ... -- a fixed order, fp64 throughout */
 #pragma omp parallel for collapse(2) schedule(static)
       for (int k = 0; k < K; ++k)
         for (int c = 0; c < FC; ++c) {
           int g = k / Kg;
-          for (int v = 0; v < FW; ++v)
-            for (int u = 0; u < FH; ++u) {
-              double acc = 0;
-              for (int n = 0; n < N; ++n)
-                for (int wo = 0; wo < Wo; ++wo) {
-                  int wi = wo * sx - pl + v * dx;
-                  if (wi < 0 || wi >= W) continue;
-                  for (int ho = 0; ho < Ho; ++ho) {
-                    int hi = ho * sy - pt + u * dy;
-                    if (hi < 0 || hi >= H) continue;
-                    acc += (double)x[XI(hi, wi, g * FC + c, n, H, W, C)] *
-                           (double)dzdy[XI(ho, wo, k, n, Ho, Wo, K)];
+          for (int v = 0; v < FW; ++v) {
+            double ps[FH][8];
+            for (int u = 0; u < FH; ++u)
+              for (int j = 0; j < 8; ++j) ps[u][j] = 0;
+            for (int n = 0; n < N; ++n)
+              for (int wo = 0; wo < Wo; ++wo) {
+                int wi = wo * sx - pl + v * dx;
+                if (wi < 0 || wi >= W) continue;
+                const float *xc = x + XI(0, wi, g * FC + c, n, H, W, C);
+                const float *dc = dzdy + XI(0, wo, k, n, Ho, Wo, K);
+                for (int u = 0; u < FH; ++u) {
+                  const int off = u * dy - pt, hi = hi_u[u];
+                  double *pu = ps[u];
+                  int h = lo_u[u];
+                  if (sy == 1) {
+                    for (; h + 7 <= hi; h += 8)
+                      for (int j = 0; j < 8; ++j) pu[j] += (double)xc[h + j + off] * (double)dc[h + j];
+                  } else {
+                    for (; h + 7 <= hi; h += 8)
+                      for (int j = 0; j < 8; ++j) pu[j] += (double)xc[(h + j) * sy + off] * (double)dc[h + j];
                   }
+                  for (int j = 0; h <= hi; ++h, ++j) pu[j] += (double)xc[h * sy + off] * (double)dc[h];
                 }
-              dfo[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))] = (float)acc;
+              }
+            for (int u = 0; u < FH; ++u) {
+              const double *q = ps[u];
+              dfo[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))] =
+                  (float)(((q[0] + q[4]) + (q[2] + q[6])) + ((q[1] + q[5]) + (q[3] + q[7])));
             }
+          }
         }
     }
     if (dxo) {
-#pragma omp parallel for collapse(2) schedule(static)
-      for (int n = 0; n < N; ++n)
-        for (int ci = 0; ci < C; ++ci) {
-          int g = ci / FC, c = ci % FC;
-          for (int wi = 0; wi < W; ++wi)
-            for (int hi = 0; hi < H; ++hi) {
-              double acc = 0;
+      int failed = 0;
+      /* four input channels of a group share every derivative row they read */
+      const int CB = (FC % 4 == 0) ? 4 : 1, ncb = C / CB;
+      const size_t fcs = (size_t)FH * FW;   /* filter stride between input channels */
+#pragma omp parallel
+      {
+        double *acc = (double *)malloc(sizeof(double) * (size_t)H * 4);
+        if (!acc) {
+#pragma omp atomic write
+          failed = 1;
+        }
+#pragma omp for collapse(2) schedule(static)
+        for (int n = 0; n < N; ++n)
+          for (int cb = 0; cb < ncb; ++cb) {
+            if (!acc) continue;
+            const int ci0 = cb * CB, g = ci0 / FC, c = ci0 % FC;
+            double *a0 = acc, *a1 = acc + H, *a2 = acc + 2 * (size_t)H, *a3 = acc + 3 * (size_t)H;
+            for (int wi = 0; wi < W; ++wi) {
+              for (size_t i = 0; i < (size_t)H * CB; ++i) acc[i] = 0;
               for (int kk = 0; kk < Kg; ++kk) {
                 int k = g * Kg + kk;
                 for (int v = 0; v < FW; ++v) {
@@ -437,19 +520,36 @@ int orc_nnconv_backward(const float *x, int H, int W, int C, int N, const float 
                   if (tw < 0 || tw % sx) continue;
                   int wo = tw / sx;
                   if (wo >= Wo) continue;
+                  const float *dc = dzdy + XI(0, wo, k, n, Ho, Wo, K);
                   for (int u = 0; u < FH; ++u) {
-                    int th = hi + pt - u * dy;
-                    if (th < 0 || th % sy) continue;
-                    int ho = th / sy;
-                    if (ho >= Ho) continue;
-                    acc += (double)dzdy[XI(ho, wo, k, n, Ho, Wo, K)] *
-                           (double)f[(size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k))];
+                    const int off = u * dy - pt, lo = lo_u[u], hi = hi_u[u];
+                    const size_t fi = (size_t)u + FH * ((size_t)v + FW * ((size_t)c + (size_t)FC * k));
+                    const double f0 = (double)f[fi];
+                    if (CB == 4) {
+                      const double f1 = (double)f[fi + fcs], f2 = (double)f[fi + 2 * fcs], f3 = (double)f[fi + 3 * fcs];
+                      for (int ho = lo; ho <= hi; ++ho) {
+                        const double dv = (double)dc[ho];
+                        const int hi_ = ho * sy + off;
+                        a0[hi_] += dv * f0;
+                        a1[hi_] += dv * f1;
+                        a2[hi_] += dv * f2;
+                        a3[hi_] += dv * f3;
+                      }
+                    } else {
+                      for (int ho = lo; ho <= hi; ++ho) a0[ho * sy + off] += (double)dc[ho] * f0;
+                    }
                   }
                 }
               }
-              dxo[XI(hi, wi, ci, n, H, W, C)] = (float)acc;
+              for (int j = 0; j < CB; ++j) {
+                float *xo = dxo + XI(0, wi, ci0 + j, n, H, W, C);
+                for (int hi = 0; hi < H; ++hi) xo[hi] = (float)acc[(size_t)H * j + hi];
+              }
             }
-        }
+          }
+        free(acc);
+      }
+      if (failed) return -2;
     }
     return 0;
   }
@@ -530,12 +630,12 @@ int orc_nnpool_backward(const float *x, int H, int W, int C, int N, int ph, int 
                         int pt, int pb, int pl, int pr, int method, const float *dzdy, float *dxo) {
   int Ho = out_size(H, pt, pb, ph, 1, sy), Wo = out_size(W, pl, pr, pw, 1, sx);
   if (Ho <= 0 || Wo <= 0) return -1;
-  memset(dxo, 0, sizeof(float) * (size_t)H * W * C * N);
 #pragma omp parallel for schedule(static)
   for (long cn = 0; cn < (long)C * N; ++cn) {
     const float *xp = x + (size_t)H * W * cn;
     const float *dp = dzdy + (size_t)Ho * Wo * cn;
     float *gp = dxo + (size_t)H * W * cn;
+    memset(gp, 0, sizeof(float) * (size_t)H * W);
     for (int wo = 0; wo < Wo; ++wo)
       for (int ho = 0; ho < Ho; ++ho) {
         int w1 = wo * sx - pl, h1 = ho * sy - pt;
@@ -709,13 +809,18 @@ int orc_nnbnorm_backward(const float *x, int H, int W, int C, int N, const float
 /* elementwise: vl_nnrelu, vl_nnsigmoid, dagnn.Sum, SE scale / axpy     */
 /* ------------------------------------------------------------------ */
 void orc_nnrelu(const float *x, size_t n, float leak, const float *dzdy, float *y) {
-  if (!dzdy)
+  /* (elementwise passes run on all threads: at 256 spectrograms a serial pass over conv1's output is 0.9 G elements) */
+  if (!dzdy) {
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) y[i] = x[i] > 0.f ? x[i] : leak * x[i];
-  else
+  } else {
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) y[i] = x[i] > 0.f ? dzdy[i] : leak * dzdy[i];
+  }
 }
 
 void orc_nnsigmoid(const float *x, size_t n, const float *dzdy, float *y) {
+#pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; ++i) {
     float s = 1.f / (1.f + expf(-x[i]));
     y[i] = dzdy ? dzdy[i] * s * (1.f - s) : s;
@@ -724,6 +829,7 @@ void orc_nnsigmoid(const float *x, size_t n, const float *dzdy, float *y) {
 
 /* y = sum_i x_i  (dagnn.Sum with two inputs), optional fused relu */
 void orc_sum2(const float *a, const float *b, size_t n, int relu, float *y) {
+#pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; ++i) {
     float v = a[i] + b[i];
     y[i] = (relu && v < 0.f) ? 0.f : v;
@@ -733,6 +839,7 @@ void orc_sum2(const float *a, const float *b, size_t n, int relu, float *y) {
 /* SE excite: y(h,w,c,n) = a(c,n) * x(h,w,c,n) [+ r(h,w,c,n)] [relu]   (mcnExtraLayers Scale / Axpy) */
 void orc_scale_axpy(const float *x, size_t HW, size_t CN, const float *a, const float *r, int relu,
                     float *y) {
+#pragma omp parallel for schedule(static)
   for (size_t j = 0; j < CN; ++j)
     for (size_t i = 0; i < HW; ++i) {
       float v = a[j] * x[HW * j + i] + (r ? r[HW * j + i] : 0.f);
@@ -743,6 +850,7 @@ void orc_scale_axpy(const float *x, size_t HW, size_t CN, const float *a, const 
 /* backward of y = a .* x (+ r): dx = a .* dy ; da(c,n) = sum_hw dy .* x ; dr = dy */
 void orc_scale_backward(const float *x, size_t HW, size_t CN, const float *a, const float *dzdy,
                         float *dxo, float *dao) {
+#pragma omp parallel for schedule(static)
   for (size_t j = 0; j < CN; ++j) {
     double s = 0;
     for (size_t i = 0; i < HW; ++i) {
