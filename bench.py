@@ -72,6 +72,12 @@ def parse():
     ap.add_argument("--frames", type=int, default=1,
                     help="distill: face frames per pair; F > 1 runs the teacher on nb*F faces and max-aggregates "
                          "their logits per pair (getBatchEmoVoxCeleb.m:145-158,179-185; SURVEY 8f row 1)")
+    ap.add_argument("--imdb-windows", type=int, default=0,
+                    help="distill: 1 = RAGGED frame windows as getBatch draws them from an imdb (getBatchEmoVoxCeleb.m:137-158): "
+                         "per pair a synthetic track of 4-20 s, logit rows every 6th frame at 25 fps (time2idx, :210-214), a "
+                         "random 512 x W spectrogram window -> rows time2idx(start) .. min(time2idx(end), rows the track has "
+                         "-- ffmpeg drops up to 3 of them on every 10th track); the teacher runs on exactly those frames.  "
+                         "Replaces --frames")
     ap.add_argument("--overlap-allreduce", type=int, default=1,
                     help="1: fc6-8 gradient bucket all-reduced while the rest of the backward pass runs (N > 1)")
     ap.add_argument("--exec-hint", default="auto", choices=["auto", "0", "1"],
@@ -265,13 +271,18 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------
     faces = spec = lgo = lab = flab = None
     tmult = 1
+    win = None
+    if wl == "distill" and args.imdb_windows:
+        win = imdb_windows(nb, W, seed)
     if teacher is not None:
         F = args.frames if wl == "distill" else 1
+        if win is not None:
+            F = 2                                         # (any value > 1: the multi-frame branch below; counts come from `win`)
         if wl == "distill" and F == 1 and args.teacher_batch:
             if args.teacher_batch % nb:
                 raise SystemExit("--teacher-batch must be a multiple of the per-GPU batch")
             tmult = args.teacher_batch // nb
-        faces = xbatch.getImageBatch(nb * F * tmult, seed=seed, device=dev)
+        faces = xbatch.getImageBatch(win["frames"] if win is not None else nb * F * tmult, seed=seed, device=dev)
         calib = xbatch.getImageBatch(min(nb, 16), seed=999, device=dev)
         zoo.calibrate_moments(teacher, ["data", calib])  # realistic stored moments
         teacher.mode = "test" if wl != "joint" else "normal"
@@ -289,11 +300,16 @@ def main():
             lab = vl.max_label(lgo)
 
     F = args.frames if wl == "distill" else 1
+    if win is not None:
+        F = 2
     _tp = os.environ.get("XM_TEACHER_PRIO")
     tstream = (torch.cuda.Stream(device=dev, priority=int(_tp)) if _tp is not None else torch.cuda.Stream(device=dev)) \
         if (wl == "distill" and args.overlap_teacher and F == 1) else None
     frozen = zoo.FrozenTeacher(teacher, lanes=args.teacher_lanes) if (wl == "teacher" or F > 1) else None
-    if F > 1:
+    if win is not None:
+        first = torch.tensor(win["first"], device=dev, dtype=torch.int32)      # 1-based, inclusive, ragged
+        last = torch.tensor(win["last"], device=dev, dtype=torch.int32)
+    elif F > 1:
         first = torch.arange(0, nb, device=dev, dtype=torch.int32) * F + 1   # 1-based, inclusive
         last = first + (F - 1)
     if args.wgrad_stream:
@@ -348,7 +364,7 @@ def main():
                 lg = teacher.vars["prediction"].value
             else:
                 lg = frozen.logits(faces)                              # 1 x 1 x 8 x (nb*F)
-            fl = lg.permute(3, 2, 1, 0).reshape(nb * F, 8).t().contiguous().t()   # frames x 8 mat
+            fl = lg.permute(3, 2, 1, 0).reshape(int(lg.shape[3]), 8).t().contiguous().t()   # frames x 8 mat
             tl, ml = vl.aggregate_logits(fl, first, last, "max")
             train.train_step(student, ["data", spec, "logitTarget", tl, "maxLabel", ml], opts, it,
                              parserv, nb * world)
@@ -620,7 +636,7 @@ def main():
     # student FLOPs scale with the spectrogram width (16.633 GFLOP at W = 300, 22.33 at the reference's default W = 400)
     student_gflop = 22.33 if W == 400 else GFLOP["student_fwd_bwd_300"] * (W / 300.0)
     if wl == "distill":
-        gflop_unit = F * GFLOP["%s_fwd" % args.teacher] + student_gflop
+        gflop_unit = (win["frames"] / nb if win is not None else F) * GFLOP["%s_fwd" % args.teacher] + student_gflop
     elif wl == "student":
         gflop_unit = student_gflop
     elif wl == "teacher":
@@ -641,18 +657,23 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"distill": "BASELINE config 4 shard: frozen %s teacher fwd + VGGVox student fwd/bwd/SGD" % args.teacher +
-                                               ("" if F == 1 else ", %d frames/pair" % F),
+                                               ("" if F == 1 else (", %d frames/pair" % F if win is None else
+                                                ", imdb windows: %d-%d frames/pair (%d frames for %d pairs)" % (
+                                                    win["min"], win["max"], win["frames"], nb))),
                                     "student": "VGGVox student fwd+bwd+update (BASELINE config 2)",
                                     "teacher": "senet50-ferplus teacher fwd (BASELINE config 3)",
                                     "joint": "senet50 teacher fwd+bwd + VGGVox student fwd+bwd (BASELINE config 5 shard)"}[wl],
                        "step": "run_distillation.m:170-182: teacher logits -> soft-target CE (T=2) -> backward -> "
                                "ParameterServer sum -> SGD-momentum",
                        "per_gpu_batch": nb, "global_batch": units, "face": "224x224x3",
-                       "teacher_batch": nb * (tmult if wl == "distill" else 1),
+                       "teacher_batch": (win["frames"] if win is not None else nb * F) if (wl == "distill" and F > 1) else
+                                        nb * (tmult if wl == "distill" else 1),
                        "spectrogram": "512x%dx1" % W, "parallelism": "dp%d" % world,
                        "weights": "random-init (seeded)", "parameter_server": args.parserv,
                        "streams": "serial" if args.serial else
-                                  {"distill": "teacher one batch ahead on its own stream + wgrad side stream",
+                                  {"distill": ("teacher in %d sample-slice lanes, then the student step + wgrad side stream" %
+                                               args.teacher_lanes) if F > 1 else
+                                              "teacher one batch ahead on its own stream + wgrad side stream",
                                    "student": "wgrad side stream", "joint": "wgrad side stream",
                                    "teacher": "%d sample-slice lanes" % args.teacher_lanes}[wl]},
             "model_tflops_per_gpu": round(value / world * gflop_unit / 1e3, 2),
@@ -750,6 +771,35 @@ def _cpu_pass(wl, pairs, W):
         t_total += time.perf_counter() - t0
         gflop += pairs * GFLOP["student_fwd_bwd_300"] * (W / 300.0)
     return t_total, gflop
+
+
+def imdb_windows(nb, W, seed):
+    """ragged logit windows of `nb` pairs as getBatchEmoVoxCeleb.m:137-158 draws them: the teacher's logits exist for every 6th
+    frame of a 25 fps track (time2idx, :210-214); a training sample is a random window of audSamp samples (:67-68) of the
+    track's audio, and its target aggregates the rows time2idx(start) .. min(time2idx(end), rows) (:145-158).  Synthetic imdb:
+    track lengths uniform in 4-20 s (VoxCeleb utterances are at least 4 s), every 10th track short of up to 3 rows (the
+    'ffmpeg did not produce the exact number of frames' case the reference clamps, :150-156).  Returns 1-based inclusive row
+    ranges into the concatenation of the windows' frames -- the teacher runs on exactly the frames the windows use."""
+    from mcncrossmodalemotions_amd import batch as xbatch
+    rng = np.random.default_rng(seed + 77)
+    fs = 16000.0
+    aud = xbatch.aud_samples(W)
+    first, last, pos = [], [], 1
+    for i in range(nb):
+        dur = float(rng.uniform(4.0, 20.0))
+        rows = xbatch.time2idx(dur)
+        if i % 10 == 9:
+            rows = max(1, rows - int(rng.integers(1, 4)))
+        wr = int(rng.integers(1, max(2, int(dur * fs - aud))))                  # randi(numel(z) - audSamp)
+        a = xbatch.time2idx(wr / fs)
+        b = min(xbatch.time2idx((wr + aud - 1) / fs), rows)
+        a = min(a, b)
+        n = b - a + 1
+        first.append(pos)
+        last.append(pos + n - 1)
+        pos += n
+    cnt = [b - a + 1 for a, b in zip(first, last)]
+    return {"first": first, "last": last, "frames": pos - 1, "min": min(cnt), "max": max(cnt)}
 
 
 def cpu_baseline(wl, pairs, W, passes=3, budget_s=10.0):

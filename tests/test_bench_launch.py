@@ -71,3 +71,29 @@ def test_gpus_8_functional_run_on_one_gpu(gpu):
     assert d["control_group"] == "gloo" and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8 * d["config"]["per_gpu_batch"] == 32
     assert d["value"] > 0
+
+
+def test_imdb_windows_are_time2idx_ranges():
+    """bench.py --imdb-windows: the ragged ranges follow getBatchEmoVoxCeleb.m:137-158 -- contiguous 1-based inclusive row
+    ranges, a 3 s window of a track with a logit row every 6th frame at 25 fps spans 13-14 rows (time2idx, :210-214) unless
+    the track ends first, never an empty window, the teacher's frame count is the sum of the windows."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w = bench.imdb_windows(256, 300, 0)
+    cnt = [b - a + 1 for a, b in zip(w["first"], w["last"])]
+    assert w["first"][0] == 1 and all(a == b + 1 for a, b in zip(w["first"][1:], w["last"][:-1]))
+    assert min(cnt) >= 1 and max(cnt) <= 14 and w["frames"] == sum(cnt) == w["last"][-1]
+    assert sum(c in (13, 14) for c in cnt) > 200 and (w["min"], w["max"]) == (min(cnt), max(cnt))
+    assert bench.imdb_windows(256, 300, 0) == w and bench.imdb_windows(256, 300, 1) != w
+
+
+@pytest.mark.gpu
+def test_imdb_windows_line_runs(gpu):
+    """SURVEY 8f row 1 on the bench line with ragged windows: the teacher runs on exactly the windows' frames, the per-pair
+    max goes through xm_aggregate_logits, the student steps on it; the line says what it ran."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--imdb-windows", "1", "--teacher", "senet50", "--steps",
+                        "2", "--warmup", "1", "--per-gpu-batch", "8", "--no-cpu-baseline", "--no-roofline", "--north-star", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert "imdb windows: " in d["config"]["workload"] and d["config"]["per_gpu_batch"] == 8 and d["value"] > 0

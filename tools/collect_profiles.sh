@@ -20,6 +20,7 @@ $B --teacher senet50 --no-cpu-baseline                      | tail -1 > $O/bench
 $B --teacher senet50 --per-gpu-batch 256 --no-cpu-baseline  | tail -1 > $O/bench_distill_senet50_b256_n1.json     # north_star: batch 256 on one GPU
 $B --per-gpu-batch 256 --no-cpu-baseline                    | tail -1 > $O/bench_distill_b256_n1.json
 $B --frames 13 --no-cpu-baseline --teacher senet50          | tail -1 > $O/bench_distill_13frames_senet50_n1.json
+$B --imdb-windows 1 --no-cpu-baseline --teacher senet50     | tail -1 > $O/bench_distill_imdb_windows_senet50_n1.json
 $B --workload cpu-teacher                                   | tail -1 > $O/bench_cpu_teacher.json                  # BASELINE config 1 (host cores only)
 XM_DEBUG_DIST=1 $B --parserv rccl-capi --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_capi_1rank.json
 XM_DEBUG_DIST=1 $B --parserv torch --no-cpu-baseline --no-roofline --north-star 0 | tail -1 > $O/bench_distill_torch_1rank.json

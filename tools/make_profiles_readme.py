@@ -12,6 +12,12 @@ d, dd, ds, st, te, jo, mf = (L("bench_distill_n1"), L("bench_distill_driver_flag
 se, se256, r256, c1, capi = (L("bench_distill_senet50_n1"), L("bench_distill_senet50_b256_n1"), L("bench_distill_b256_n1"),
                              L("bench_cpu_teacher"), L("bench_distill_capi_1rank"))
 tor1, late = L("bench_distill_torch_1rank"), L("bench_distill_capi_late_init")
+imdb_row = ""
+if os.path.exists(os.path.join(P, "bench_distill_imdb_windows_senet50_n1.json")):
+    iw = L("bench_distill_imdb_windows_senet50_n1")
+    imdb_row = ("| `%s/bench_distill_imdb_windows_senet50_n1.json` | the same with RAGGED windows as getBatch draws them from an imdb "
+                "(`--imdb-windows 1`: `time2idx` rows of a random 3 s window of a 4-20 s track, clamped to the rows the track has): "
+                "%s pairs/s, %s |\n" % (R, iw["value"], iw["config"]["workload"].split(", imdb windows: ")[-1]))
 w400, dw400, sh1, g2 = (L("bench_student_w400_n1"), L("bench_distill_senet50_w400_n1"), L("bench_distill_senet50_b256_serial_hint1"),
                         L("bench_distill_gpus2_gloo0"))
 tb = json.load(open(os.path.join(P, "pmc_traffic_senet50_b256.json")))
@@ -55,7 +61,7 @@ round's first collection at `e4e1a38`, 4344 in round 5's collection); every comp
 | `{R}/bench_distill_senet50_n1.json` | the reference's default teacher (`run_distillation.m:82`): `--teacher senet50`, one face per pair |
 | `{R}/bench_distill_senet50_b256_n1.json`, `bench_distill_b256_n1.json` | north_star's batch 256 on ONE GPU (`--per-gpu-batch 256`), SE-ResNet-50 / ResNet-50 teacher |
 | `{R}/bench_distill_13frames_senet50_n1.json` | SURVEY 8f row 1: 13 face frames per pair through the SE-ResNet50 teacher, max-aggregated |
-| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only): {c1['value']} img/s on {c1['cpu_baseline']['cores']} threads |
+{imdb_row}| `{R}/bench_cpu_teacher.json` | BASELINE config 1: `--workload cpu-teacher` (ResNet-50 forward + loss / classerror heads, batch 32, host cores only): {c1['value']} img/s on {c1['cpu_baseline']['cores']} threads |
 | `{R}/bench_distill_capi_1rank.json` | `XM_DEBUG_DIST=1 bench.py --parserv rccl-capi`: the library's own communicator (xm_parserv_push / sync) with a 1-rank group; `rccl_ranks` = {capi.get('rccl_ranks')} |
 | `{R}/bench_distill_torch_1rank.json`, `bench_distill_capi_late_init.json` | the same single-rank run through `torch.distributed` ({tor1['value']} pairs/s), and with the library's communicator created AFTER the networks (`XM_PS_LATE=1`: {late['value']} pairs/s -- the call-order trap of `include/xmodal.h`) |
 | `{R}/bench_student_w400_n1.json`, `bench_distill_senet50_w400_n1.json` | the reference's REAL default shape -- `numSeconds = 4`, 512 x 400 spectrograms (`run_distillation.m:74`): student at batch 64 ({w400['value']} samples/s = {pct(w400['model_frac_of_fp32_mfma_peak'])} of peak at 22.33 GFLOP per sample: re-taken with the fixed FLOP count) and the SE-ResNet50 distillation step ({dw400['value']} pairs/s) |
