@@ -23,7 +23,7 @@ WORKER = os.path.join(ROOT, "tests", "_switch_worker.py")
 LIBRARY = ["XM_NO_HYBRID", "XM_NO_HALO", "XM_NO_SKINNY", "XM_NO_SKINNY4", "XM_NO_STEM", "XM_NO_STEM_WGRAD", "XM_NO_DMA",
            "XM_NO_FUSED_STATS", "XM_DGRAD_MERGE", "XM_NO_FAST_TRANSPOSE", "XM_NO_POOL_LDS", "XM_NO_POOL_PATCH",
            "XM_NO_POOL_POOLED", "XM_NO_W8", "XM_NO_WGRAD_PATCH", "XM_NO_WGRAD_PATCH_S2", "XM_NO_DGRAD_S2", "XM_NO_STEM3"]
-EXECUTOR = ["XM_NO_FUSED_BIASDER", "XM_NO_FUSED_STEM_BWD", "XM_NO_STEM_GRAM", "XM_NO_STEM_FWD", "XM_NO_FORK_SUMS", "XM_NO_FUSED_SE", "XM_NO_FUSED_SE_BWD", "XM_NO_PREPARE",
+EXECUTOR = ["XM_NO_FUSED_BIASDER", "XM_NO_FUSED_STEM_BWD", "XM_NO_STEM_GRAM", "XM_NO_STEM_FWD", "XM_NO_FORK_SUMS", "XM_NO_FUSED_SE", "XM_NO_SE_FOLD_FC", "XM_NO_FUSED_SE_BWD", "XM_NO_PREPARE",
             "XM_WGRAD_AFTER_DGRAD"]
 
 
