@@ -1139,11 +1139,16 @@ fc_skinny4_kernel(const float *__restrict__ x, const float *__restrict__ f, cons
     if (p < NP) y[m + (size_t)M * p] = v;
   }
 }
-static bool fc_skinny_ok(const Geo &g) {
+static bool fc_skinny_ok(const Geo &g, bool dgrad = false) {
   const bool off = !path_on(kPathSkinny);
   if (off || g.FH != 1 || g.FW != 1 || g.sy != 1 || g.sx != 1 || g.dy != 1 || g.dx != 1 || g.G != 1) return false;
   if (g.pt | g.pb | g.pl | g.pr) return false;
   const long long NP = (long long)g.Ho * g.Wo * g.N;
+  // A wide FC layer over many samples is a GEMM again (the student's fc7, 4096 -> 1024: forward 19.7 / 22.5 / 41.5 / 60.9 us
+  // here against 38 / 40 / 42 / 46.6 us on the MFMA path at 32 / 64 / 128 / 256 samples; as dX = W' dY 28.6 / 39.6 / 67.7 / 111 us
+  // against 30 / 32.5 / 40.6 / 59 us): every 16-sample chunk re-reads the 16 MB of weights.  The SE layers (<= 0.26 M weights)
+  // stay here at every batch.
+  if ((long long)g.C * g.K >= (1ll << 20) && NP > (dgrad ? 32 : 128)) return false;
   const bool rows4 = g.H * g.W == 1 && (g.C & 3) == 0 && (g.K & 3) == 0;   // fc_skinny4_kernel's geometry
   if (!(g.K <= 16 || NP <= (rows4 ? 512 : 128))) return false;
   return (long long)g.K * ((NP + 31) / 32) <= 65535 && (long long)g.H * g.W * g.C * g.N < (1ll << 31);
@@ -1745,7 +1750,7 @@ static int conv_dgrad(const float *f, const float *dzdy, float *dxo, const Geo &
         gs.C = gs.FC = g.Kg;
         gs.K = gs.Kg = g.FC;
         gs.R = g.Kg;
-        if (fc_skinny_ok(gs)) {
+        if (fc_skinny_ok(gs, true)) {
           int rc = fc_skinny_forward(dzdy, Ag, nullptr, dxo, gs, 0, st);
           if (rc) return rc;
           continue;
